@@ -1,0 +1,226 @@
+"""ctypes mirror of include/beifong_hip.h and loader for libbeifong_hip.so.
+
+This is plumbing: the product is the HIP library behind the C ABI.  Loading
+fails loudly when the extension is missing — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbeifong_hip.so")
+
+BF_OK, BF_ERR_INVALID, BF_ERR_DEVICE, BF_ERR_NOMEM, BF_ERR_UNSUPPORTED = range(5)
+BF_BSDF_DIFFUSE, BF_BSDF_ROUGHCONDUCTOR, BF_BSDF_NULL = range(3)
+BF_MF_BECKMANN, BF_MF_GGX = range(2)
+BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
+BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER = range(4)
+BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
+BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER = range(4)
+BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW = range(4)
+BF_COLOR_RGB, BF_COLOR_MONO = range(2)
+BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS = 1, 2
+
+M16 = C.c_float * 16
+
+
+class bf_material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("twosided", C.c_uint32), ("reflectance", C.c_float),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("distribution", C.c_uint32),
+                ("sample_visible", C.c_uint32), ("eta", C.c_float), ("k", C.c_float),
+                ("has_specular_reflectance", C.c_uint32)]
+
+
+class bf_shape(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("material", C.c_uint32), ("emitter", C.c_int32),
+                ("is_sensor", C.c_uint32), ("to_world", M16), ("to_object", M16),
+                ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+                ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
+
+
+class bf_emitter(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("to_world", M16), ("to_object", M16),
+                ("radiance", C.c_float), ("cutoff_angle_deg", C.c_float), ("beam_width_deg", C.c_float),
+                ("signal_type", C.c_uint32), ("amplitude", C.c_float), ("freq_centre", C.c_float),
+                ("freq_ext", C.c_float), ("pulse_len", C.c_float), ("prf", C.c_float), ("gain", C.c_float),
+                ("resample_freq", C.c_uint32)]
+
+
+class bf_sensor(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("to_world", M16), ("sample_to_camera", M16),
+                ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("film_width", C.c_uint32), ("film_height", C.c_uint32),
+                ("shutter_open", C.c_float), ("shutter_open_time", C.c_float),
+                ("adc_sampling_start", C.c_float), ("adc_sampling_time", C.c_float),
+                ("t_bins", C.c_uint32), ("f_bins", C.c_uint32),
+                ("t_bandwidth", C.c_float), ("f_bandwidth", C.c_float),
+                ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float)]
+
+
+class bf_physics(C.Structure):
+    _fields_ = [("c", C.c_float), ("lambda_min_nm", C.c_float), ("lambda_max_nm", C.c_float)]
+
+
+class bf_scene_desc(C.Structure):
+    _fields_ = [("shapes", C.POINTER(bf_shape)), ("n_shapes", C.c_uint32),
+                ("materials", C.POINTER(bf_material)), ("n_materials", C.c_uint32),
+                ("emitters", C.POINTER(bf_emitter)), ("n_emitters", C.c_uint32),
+                ("sensor", bf_sensor), ("physics", bf_physics)]
+
+
+class bf_launch(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("color_mode", C.c_uint32), ("n_paths", C.c_uint64),
+                ("path_offset", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_int32),
+                ("rr_depth", C.c_int32), ("bins", C.c_uint32), ("bin_width", C.c_float),
+                ("time_c", C.c_float), ("flags", C.c_uint32)]
+
+
+class bf_path_record(C.Structure):
+    _fields_ = [("L", C.c_float), ("aux", C.c_float), ("valid", C.c_uint32), ("n_rays", C.c_uint32)]
+
+
+PATH_RECORD_DTYPE = np.dtype([("L", "<f4"), ("aux", "<f4"), ("valid", "<u4"), ("n_rays", "<u4")])
+
+
+class bf_stats(C.Structure):
+    _fields_ = [("n_paths", C.c_uint64), ("n_rays_closest", C.c_uint64), ("n_rays_shadow", C.c_uint64),
+                ("n_nodes_visited", C.c_uint64), ("n_tris_tested", C.c_uint64), ("n_invalid", C.c_uint64),
+                ("n_bounces", C.c_uint64), ("kernel_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class bf_scene_info(C.Structure):
+    _fields_ = [("n_shapes", C.c_uint32), ("n_rects", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("n_bvh_nodes", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+
+
+# every symbol include/beifong_hip.h declares
+EXPORTED_SYMBOLS = [
+    "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
+    "bf_scene_destroy", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
+    "bf_trace_closest", "bf_trace_any",
+]
+
+_lib = None
+
+
+class BeifongError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libbeifong_hip.so; raise if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise BeifongError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.bf_version.restype = C.c_int
+    lib.bf_last_error.restype = C.c_char_p
+    lib.bf_device_count.restype = C.c_int
+    lib.bf_set_device.argtypes = [C.c_int]
+    lib.bf_scene_create.argtypes = [C.POINTER(bf_scene_desc), C.POINTER(vp)]
+    lib.bf_scene_destroy.argtypes = [vp]
+    lib.bf_scene_get_info.argtypes = [vp, C.POINTER(bf_scene_info)]
+    lib.bf_launch_channels.argtypes = [C.POINTER(bf_launch)]
+    lib.bf_launch_channels.restype = C.c_uint32
+    lib.bf_render_device.argtypes = [vp, C.POINTER(bf_launch), vp, vp, vp, C.POINTER(bf_stats)]
+    lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
+    lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
+    lib.bf_trace_any.argtypes = [vp, C.c_uint64, vp, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, status, what):
+    if status != BF_OK:
+        msg = lib.bf_last_error()
+        raise BeifongError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_launch(mode, n_paths, seed=0, path_offset=0, bins=0, bin_width=0.0, color_mode=BF_COLOR_RGB,
+                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0):
+    lp = bf_launch()
+    lp.mode, lp.color_mode, lp.n_paths, lp.path_offset, lp.seed = mode, color_mode, n_paths, path_offset, seed
+    lp.max_depth, lp.rr_depth, lp.bins, lp.bin_width, lp.time_c, lp.flags = max_depth, rr_depth, bins, bin_width, time_c, flags
+    return lp
+
+
+class Scene:
+    """Device-resident immutable scene (bf_scene)."""
+
+    def __init__(self, desc_holder, lib=None):
+        self.lib = lib or load_library()
+        self.holder = desc_holder          # keeps numpy arrays alive
+        h = C.c_void_p()
+        check(self.lib, self.lib.bf_scene_create(C.byref(desc_holder.desc), C.byref(h)), "bf_scene_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.bf_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = bf_scene_info()
+        check(self.lib, self.lib.bf_scene_get_info(self.handle, C.byref(i)), "bf_scene_get_info")
+        return i
+
+    def channels(self, launch):
+        return self.lib.bf_launch_channels(C.byref(launch))
+
+    def render(self, launch, records=False):
+        """bf_render: host histogram float32[channels] (+ per-path records, stats)."""
+        n = self.channels(launch)
+        hist = np.zeros(n, dtype=np.float32)
+        rec = np.zeros(launch.n_paths, dtype=PATH_RECORD_DTYPE) if records else None
+        st = bf_stats()
+        check(self.lib, self.lib.bf_render(self.handle, C.byref(launch), _ptr(hist), _ptr(rec), C.byref(st)), "bf_render")
+        return hist, rec, st
+
+    def render_device(self, launch, hist_ptr, stream=0, records_ptr=None, want_stats=False):
+        """bf_render_device: accumulate into a device buffer (e.g. a torch tensor's data_ptr)."""
+        st = bf_stats() if want_stats else None
+        check(self.lib, self.lib.bf_render_device(self.handle, C.byref(launch), C.c_void_p(hist_ptr),
+                                                  C.c_void_p(records_ptr) if records_ptr else None,
+                                                  C.c_void_p(stream) if stream else None,
+                                                  C.byref(st) if st is not None else None), "bf_render_device")
+        return st
+
+    def trace_closest(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32)
+        shape = np.empty(n, np.uint32)
+        uv = np.empty((n, 2), np.float32)
+        check(self.lib, self.lib.bf_trace_closest(self.handle, n, _ptr(rays), _ptr(t), _ptr(prim), _ptr(shape), _ptr(uv)),
+              "bf_trace_closest")
+        return t, prim, shape, uv
+
+    def trace_any(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.empty(n, np.uint8)
+        check(self.lib, self.lib.bf_trace_any(self.handle, n, _ptr(rays), _ptr(hit)), "bf_trace_any")
+        return hit

@@ -1,0 +1,107 @@
+"""The BASELINE.json configurations as flat scene descriptions.
+
+C1 follows python_scripts/trans_rad.xml tag by tag; C2-C4 follow the
+geometry/materials of python_scripts/Render.py:196-392 and the gen-2
+integrator of python_scripts/animated_trans_rad.py:163-169, with seeded
+synthetic meshes standing in for the stripped scans.
+"""
+import numpy as np
+
+from . import capi, meshgen
+from .scenedesc import SceneDesc, Transform4f
+
+T = Transform4f
+
+
+def trans_rad(spp=16):
+    """C1: python_scripts/trans_rad.xml (gen-1 `time` o `pathtime`)."""
+    sd = SceneDesc()
+    mat = sd.add_diffuse(1.0, twosided=True)                     # :35-39
+    rx_mat = sd.add_diffuse(0.5)                                 # shape.cpp:89-98 default bsdf
+    # receiveAntenna :16-31 — <scale .05 .05/> then <lookat/> => lookat * scale
+    rx = sd.add_rectangle(T.look_at([0, 0, 0], [0, -1, 0], [0, 0, 1]) * T.scale([0.05, 0.05, 1]), rx_mat)
+    sd.set_fluxmeter(rx)
+    # spot :43-50
+    sd.add_spot(T.look_at([0, 0, 0], [0, -1, 0], [0, 0, 1]), intensity=1.0, cutoff_angle=25.0, beam_width=20.0)
+    # target :65-71, gnd :73-79 (lookat without up: xml.cpp:911-913)
+    sd.add_rectangle(T.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1]) * T.scale([1, 1, 1]), mat)
+    sd.add_rectangle(T.look_at([0, 0, -0.5], [0, 0, 0.5], [0, 0, 0]) * T.scale([20, 20, 1]), mat)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_TIME, spp, seed=0, bins=50, bin_width=0.5e-9, time_c=3.0e8,
+                              color_mode=capi.BF_COLOR_RGB)
+    return sd, launch
+
+
+def _radar_frontend(sd, radiance=1000.0):
+    """Monostatic front end of Render.py:196-271: a 20 x 50 mm TX aperture at
+    (0,0,0.3) looking +x carrying an area emitter (gen-2 stand-in for the
+    wignertransmitter), and a perspective RX at the same position."""
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)        # txa_d0 = align_x * align_z
+    tx_mat = sd.add_diffuse(0.0)                                  # emitter shape: rho = 0 (shape.cpp:89-98)
+    txa = sd.add_rectangle(T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1]), tx_mat)
+    sd.add_area_emitter(txa, radiance)
+    sd.set_perspective(T.translate([0, 0, 0.3]) * d0, fov=45.0, near_clip=0.1, far_clip=100.0)
+
+
+def _ground(sd):
+    gnd = sd.add_diffuse(0.5, twosided=True)                      # B_GND Render.py:322-334
+    sd.add_rectangle(T.translate([0, 0, 0]) * T.scale([20, 20, 1]), gnd)
+
+
+def bus_radar(n_tris=200_000, n_paths=64, bins=256, dr=0.1, seed=1):
+    """C2: Bus.obj-class monostatic radar scene, gen-2 `range` o `pathlength`."""
+    sd = SceneDesc()
+    _radar_frontend(sd)
+    _ground(sd)
+    car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)   # B_CAR :353-363
+    v, f = meshgen.bus(n_tris, seed=1)
+    # car_trafo Render.py:305-316: translate(10,3,1) * yaw(-20) (scan-axis alignment folded into the generator)
+    v = meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7))
+    sd.add_mesh(v, f, car)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RANGE, n_paths, seed=seed, bins=bins, bin_width=dr, color_mode=capi.BF_COLOR_RGB)
+    return sd, launch
+
+
+def car_radar(n_tris=1_000_000, n_paths=1 << 20, bins=1024, dr=0.03, seed=2):
+    """C3: Car-body.ply-class shell (vertex normals) + ground."""
+    sd = SceneDesc()
+    _radar_frontend(sd)
+    _ground(sd)
+    car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
+    v, f, n = meshgen.car_body(n_tris, seed=2)
+    a = np.radians(-20.0)
+    r = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    v = meshgen.place(v, yaw_deg=-20.0, translate=(8.0, 1.5, 0.75))
+    n = (n.astype(np.float64) @ r.T).astype(np.float32)
+    sd.add_mesh(v, f, car, normals=n)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RANGE, n_paths, seed=seed, bins=bins, bin_width=dr, color_mode=capi.BF_COLOR_RGB)
+    return sd, launch
+
+
+def multi_mesh_radar(n_paths=4096 << 10, bins=4096, dr=0.01, seed=3, scale=1.0):
+    """C4: bus + car + motorbike on the ground plane."""
+    sd = SceneDesc()
+    _radar_frontend(sd)
+    _ground(sd)
+    mat = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
+    v, f = meshgen.bus(int(200_000 * scale), seed=1)
+    sd.add_mesh(meshgen.place(v, -20.0, (12.0, 3.0, 1.7)), f, mat)
+    v, f, n = meshgen.car_body(int(1_000_000 * scale), seed=2, with_normals=False)
+    sd.add_mesh(meshgen.place(v, 15.0, (7.0, -2.5, 0.75)), f, mat)
+    v, f = meshgen.motorbike(int(300_000 * scale), seed=5)
+    sd.add_mesh(meshgen.place(v, 40.0, (5.0, 1.0, 0.0)), f, mat)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RANGE, n_paths, seed=seed, bins=bins, bin_width=dr, color_mode=capi.BF_COLOR_RGB)
+    return sd, launch
+
+
+def single_mesh(v, f, normals=None):
+    """Bare mesh scene for Scene::ray_intersect tests (test_kdtrees.py style)."""
+    sd = SceneDesc()
+    m = sd.add_diffuse(0.5)
+    sd.add_mesh(v, f, m, normals=normals)
+    sd.set_perspective(T.translate([0, 0, 0]), fov=45.0, near_clip=0.1, far_clip=100.0)
+    sd.finalize()
+    return sd

@@ -1,0 +1,249 @@
+/*
+ * beifong_hip.h — flat C ABI of the MI355X radar path-tracing core
+ * (libbeifong_hip.so).  This is the drop-in boundary for beifong's
+ * transient-radar hot path:
+ *
+ *   SamplingIntegrator::render / render_sample   src/librender/integrator.cpp:58-310
+ *   SamplingIntegrator::receive / receive_sample src/librender/integrator.cpp:315-768,1538-1667
+ *   PathIntegrator::sample                       src/integrators/path.cpp:100-226
+ *   PathLengthIntegrator / RangeIntegrator       src/integrators/pathlength.cpp:114-337, range.cpp:89-190
+ *   PathTimeIntegrator / TimeIntegrator          src/integrators/pathtime.cpp:114-302, time.cpp:86-190
+ *   PathTimeFrequencyIntegrator::sample          src/integrators/pathtimefrequency.cpp:103-460
+ *   Scene::ray_intersect / ray_test              src/librender/scene.cpp:129-178
+ *   ImageBlock::put / SignalBlock::put           src/librender/imageblock.cpp:79+, signalblock.cpp:79-172
+ *
+ * The reference's plugin ABI is C++ templates over enoki types and cannot be
+ * bound binary-for-binary; the host layer (beifong_amd/host) keeps the
+ * source-level plugin surface and flattens a loaded scene into the POD
+ * description below.  Everything that crosses this boundary is plain C:
+ * pointers, sizes, integer status codes.  No exceptions, no torch types.
+ *
+ * Ownership: the caller owns every input array for the duration of
+ * bf_scene_create (they are deep-copied to the device) and owns every output
+ * buffer.  A bf_scene is immutable after creation and may be shared by
+ * threads; bf_render is re-entrant per (scene, stream).
+ *
+ * Conventions: all arithmetic fp32, indices uint32, RNG state uint64.
+ * Matrices are row-major float[16].  Spectra are a single grey lane (all
+ * radar scenes use uniform spectra; see DESIGN.md "Spectrum").
+ */
+#ifndef BEIFONG_HIP_H
+#define BEIFONG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_ABI_VERSION 1
+
+typedef int bf_status;
+enum {
+    BF_OK = 0,
+    BF_ERR_INVALID = 1,   /* bad argument / inconsistent description        */
+    BF_ERR_DEVICE = 2,    /* HIP runtime failure (message in bf_last_error)  */
+    BF_ERR_NOMEM = 3,
+    BF_ERR_UNSUPPORTED = 4
+};
+
+/* ---------------- materials: BSDF plugins flattened ----------------------
+ * diffuse.cpp:78-135, roughconductor.cpp:145-392, twosided.cpp:62-180 */
+enum { BF_BSDF_DIFFUSE = 0, BF_BSDF_ROUGHCONDUCTOR = 1, BF_BSDF_NULL = 2 };
+enum { BF_MF_BECKMANN = 0, BF_MF_GGX = 1 };
+
+typedef struct bf_material {
+    uint32_t type;           /* BF_BSDF_*                                    */
+    uint32_t twosided;       /* 1: wrapped in <bsdf type="twosided">         */
+    float reflectance;       /* diffuse: reflectance; conductor: specular_reflectance */
+    float alpha_u, alpha_v;  /* roughconductor roughness                     */
+    uint32_t distribution;   /* BF_MF_*                                      */
+    uint32_t sample_visible; /* roughconductor sample_visible (default 1)    */
+    float eta, k;            /* conductor complex IOR (defaults 0, 1)        */
+    uint32_t has_specular_reflectance;
+} bf_material;
+
+/* ---------------- shapes ------------------------------------------------- */
+enum { BF_SHAPE_RECTANGLE = 0, BF_SHAPE_MESH = 1 };
+
+typedef struct bf_shape {
+    uint32_t type;           /* BF_SHAPE_*                                   */
+    uint32_t material;       /* index into materials                         */
+    int32_t  emitter;        /* index into emitters if an area emitter / surface
+                                transmitter is attached, else -1             */
+    uint32_t is_sensor;      /* shape carries the sensor / receiver          */
+    /* rectangle (src/shapes/rectangle.cpp): unit square [-1,1]^2, z=0.
+       The reference's Transform carries its own inverse (transform.h), so the
+       host layer supplies both; the core never inverts a matrix.            */
+    float to_world[16];
+    float to_object[16];
+    /* mesh (include/mitsuba/render/mesh.h:344-348): world-space vertices
+       (to_world already applied, as obj.cpp / ply.cpp do at load time)      */
+    const float *positions;  /* [3 * n_vertices]                             */
+    const float *normals;    /* [3 * n_vertices] or NULL                     */
+    const uint32_t *indices; /* [3 * n_faces]                                */
+    uint32_t n_vertices;
+    uint32_t n_faces;
+} bf_shape;
+
+/* ---------------- emitters / transmitters -------------------------------- */
+enum {
+    BF_EMITTER_SPOT = 0,         /* src/emitters/spot.cpp:64-170             */
+    BF_EMITTER_AREA = 1,         /* src/emitters/area.cpp:64-150             */
+    BF_TRANSMITTER_AREA = 2,     /* src/transmitters/areatransmitter.cpp     */
+    BF_TRANSMITTER_WIGNER = 3    /* src/transmitters/wignertransmitter.cpp   */
+};
+enum { BF_SIGNAL_CW = 0, BF_SIGNAL_PULSE = 1, BF_SIGNAL_LINFMCW = 2 };
+
+typedef struct bf_emitter {
+    uint32_t type;
+    int32_t  shape;          /* area types: index of the carrying shape      */
+    float to_world[16];      /* spot                                         */
+    float to_object[16];     /* spot: trafo.inverse() (spot.cpp:153)         */
+    float radiance;          /* spot: intensity; area: radiance              */
+    float cutoff_angle_deg;  /* spot                                         */
+    float beam_width_deg;    /* spot                                         */
+    /* wigner transmitter signal model (wignertransmitter.cpp:53-146)        */
+    uint32_t signal_type;
+    float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
+    uint32_t resample_freq;
+} bf_emitter;
+
+/* ---------------- sensor / receiver + film / adc ------------------------- */
+enum {
+    BF_SENSOR_FLUXMETER = 0,     /* src/sensors/fluxmeter.cpp:63-105         */
+    BF_SENSOR_PERSPECTIVE = 1,   /* src/sensors/perspective.cpp:95-199       */
+    BF_RECEIVER_OMNI = 2,        /* src/receivers/omnidirectional.cpp:51-139 */
+    BF_RECEIVER_WIGNER = 3       /* src/receivers/wignerreceiver.cpp:43-299  */
+};
+
+typedef struct bf_sensor {
+    uint32_t type;
+    int32_t  shape;          /* fluxmeter / receivers: carrying shape        */
+    float to_world[16];      /* perspective: camera-to-world                 */
+    float sample_to_camera[16]; /* perspective: m_sample_to_camera
+                                   (perspective.cpp:104-109, sensor.h:196-231) */
+    float fov_x_deg;         /* perspective (already resolved to the x axis) */
+    float near_clip, far_clip;
+    uint32_t film_width, film_height;     /* hdrfilm size (no crop)          */
+    float shutter_open, shutter_open_time;
+    /* receiver / ADC (receiver.cpp:16-62, adc.cpp:18-46)                    */
+    float adc_sampling_start, adc_sampling_time;
+    uint32_t t_bins, f_bins;
+    float t_bandwidth, f_bandwidth;
+    float freq_centre, freq_ext, gain;     /* wigner receiver                */
+} bf_sensor;
+
+/* ---------------- scene --------------------------------------------------- */
+typedef struct bf_physics {
+    float c;                 /* MTS_C (spectrum.h:32-35); gen-1 uses 3.0e8   */
+    float lambda_min_nm;     /* MTS_WAVELENGTH_MIN (spectrum.h:15-21)        */
+    float lambda_max_nm;     /* MTS_WAVELENGTH_MAX (spectrum.h:23-29)        */
+} bf_physics;
+
+typedef struct bf_scene_desc {
+    const bf_shape *shapes;       uint32_t n_shapes;
+    const bf_material *materials; uint32_t n_materials;
+    const bf_emitter *emitters;   uint32_t n_emitters;
+    bf_sensor sensor;
+    bf_physics physics;
+} bf_scene_desc;
+
+typedef struct bf_scene bf_scene;   /* opaque, device resident */
+
+/* ---------------- launch --------------------------------------------------- */
+enum {
+    BF_MODE_PATH = 0,         /* path.cpp; channels X,Y,Z,A,W                 */
+    BF_MODE_RANGE = 1,        /* range.cpp o pathlength.cpp; +bins channels   */
+    BF_MODE_TIME = 2,         /* time.cpp o pathtime.cpp; +3*bins channels    */
+    BF_MODE_RECEIVE_RAW = 3   /* receive() o pathtimefrequency.cpp; Y,A,W     */
+};
+enum { BF_COLOR_RGB = 0, BF_COLOR_MONO = 1 };
+
+typedef struct bf_launch {
+    uint32_t mode;            /* BF_MODE_*                                    */
+    uint32_t color_mode;      /* BF_COLOR_*: scalar_rgb -> XYZ via srgb_to_xyz */
+    uint64_t n_paths;         /* paths rendered by THIS call                  */
+    uint64_t path_offset;     /* first global path index (multi-GPU sharding) */
+    uint64_t seed;            /* sampler base seed (sampler.cpp:83-96)        */
+    int32_t  max_depth;       /* -1 = infinite (integrator.cpp:1713-1728)     */
+    int32_t  rr_depth;        /* default 5                                    */
+    uint32_t bins;            /* range/time bins                              */
+    float    bin_width;       /* dr [m] (range) or dt [s] (time)              */
+    float    time_c;          /* gen-1 divides by (Float)3.0e8 (pathtime.cpp:140) */
+    uint32_t flags;           /* BF_FLAG_*                                    */
+} bf_launch;
+
+enum {
+    BF_FLAG_STATS = 1u,       /* count BVH nodes visited / triangles tested   */
+    BF_FLAG_GLOBAL_ATOMICS = 2u /* skip LDS privatisation (debug / ablation)  */
+};
+
+/* per-path record for exact parity tests (optional output) */
+typedef struct bf_path_record {
+    float L;                  /* sensor-weighted grey radiance of the path    */
+    float aux;                /* pathlength [m] / pathtime [s] / receive time */
+    uint32_t valid;           /* first hit valid (alpha)                      */
+    uint32_t n_rays;          /* closest + any-hit queries issued             */
+} bf_path_record;
+
+typedef struct bf_stats {
+    uint64_t n_paths;
+    uint64_t n_rays_closest;
+    uint64_t n_rays_shadow;
+    uint64_t n_nodes_visited;  /* only with BF_FLAG_STATS                     */
+    uint64_t n_tris_tested;    /* only with BF_FLAG_STATS                     */
+    uint64_t n_invalid;        /* samples dropped by ImageBlock::put's checks */
+    uint64_t n_bounces;        /* path vertices shaded                        */
+    float    kernel_ms;        /* HIP-event time of the render kernels        */
+} bf_stats;
+
+typedef struct bf_scene_info {
+    uint32_t n_shapes, n_rects, n_triangles, n_bvh_nodes;
+    uint32_t node_bytes, tri_bytes;
+    uint64_t device_bytes;
+    float bbox_min[3], bbox_max[3];
+} bf_scene_info;
+
+/* ---------------- entry points --------------------------------------------- */
+int bf_version(void);
+const char *bf_last_error(void);                 /* thread-local              */
+int bf_device_count(void);
+bf_status bf_set_device(int device);
+
+bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out);
+bf_status bf_scene_destroy(bf_scene *scene);
+bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info);
+
+/* number of float channels per pixel the given launch produces */
+uint32_t bf_launch_channels(const bf_launch *launch);
+
+/* Render into a DEVICE buffer hist_dev[film_h*film_w*channels] (accumulates;
+ * caller zeroes).  stream is a hipStream_t (NULL = default stream).  The call
+ * is asynchronous with respect to the host unless stats_out/records are
+ * requested.  This is the entry the multi-GPU driver uses: the histogram stays
+ * in HBM for the RCCL reduce. */
+bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch,
+                           float *hist_dev, bf_path_record *records_dev,
+                           void *stream, bf_stats *stats_out);
+
+/* Convenience: render into a HOST buffer (zeroed by the callee). */
+bf_status bf_render(const bf_scene *scene, const bf_launch *launch,
+                    float *hist_out, bf_path_record *records_out,
+                    bf_stats *stats_out);
+
+/* Scene::ray_intersect / ray_test over a batch of HOST rays (tests, tools).
+ * rays: [n][8] = o.xyz, mint, d.xyz, maxt.  Outputs may be NULL.
+ * out_t = +inf on miss; out_prim = global primitive index (shape prefix sum,
+ * kdtree.h:2335-2355); out_uv = prim_uv. */
+bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays,
+                           float *out_t, uint32_t *out_prim, uint32_t *out_shape,
+                           float *out_uv);
+bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays,
+                       uint8_t *out_hit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEIFONG_HIP_H */

@@ -1,0 +1,1470 @@
+/*
+ * bf_oracle.cpp — CPU ORACLE for beifong's transient-radar hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is a scalar CPU restatement of the
+ * reference algorithm (JacobMackay/beifong, a Mitsuba 2 fork), written from the
+ * reference source text; every function cites the reference file:line it
+ * follows.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product path (beifong_amd/, libbeifong_hip.so) never
+ * links, imports or calls anything in oracle/.
+ *
+ * Parity status: the reference cannot be compiled or imported here (all ext/
+ * submodules are empty: enoki, tbb, embree, pugixml, pybind11 ...), so this
+ * restatement is pinned by the known-answer values in the reference's own unit
+ * tests (tests/test_oracle_known_answers.py lists each one with file:line).
+ * END-TO-END RADAR HISTOGRAMS: PARITY UNPINNED — the reference holds no test
+ * or stored output for them.
+ *
+ * Third-party arithmetic that lives outside /root/reference (enoki, unpinned
+ * submodule): PCG32 (O'Neill's published pcg32 algorithm and constants),
+ * dot/cross/normalize/fmadd conventions (enoki's generic array
+ * implementation: dot = fma chain from lane 0, cross = fmsub form,
+ * normalize = v * (1/sqrt(dot))), scalar sin/cos/acos/exp/log/erf (libm;
+ * evaluated here in double and rounded once to float, which is what glibc's
+ * float routines deliver to within rounding), erfinv (Giles' single precision
+ * polynomial, the algorithm enoki cites).
+ *
+ * Build: see oracle/Makefile (g++ -O2 -ffp-contract=off; fused multiply-adds
+ * appear only where the reference writes fmadd/fmsub/fnmadd).
+ */
+#include "../include/beifong_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// constants — include/mitsuba/core/math.h:18-41
+// ---------------------------------------------------------------------------
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+constexpr float kInvSqrtPi = 0.56418958354775628695f;
+constexpr float kEpsilon = 5.9604644775390625e-8f;       // FLT_EPSILON / 2
+constexpr float kRayEpsilon = kEpsilon * 1500.f;
+constexpr float kShadowEpsilon = kRayEpsilon * 10.f;
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+inline float fmadd(float a, float b, float c) { return std::fmaf(a, b, c); }
+inline float fmsub(float a, float b, float c) { return std::fmaf(a, b, -c); }
+inline float fnmadd(float a, float b, float c) { return std::fmaf(-a, b, c); }
+inline float sqr(float x) { return x * x; }
+inline float rcp(float x) { return 1.f / x; }
+inline float safe_sqrt(float x) { return std::sqrt(std::max(x, 0.f)); }
+inline float sinf_cr(float x) { return (float) std::sin((double) x); }
+inline float cosf_cr(float x) { return (float) std::cos((double) x); }
+inline float acosf_cr(float x) { return (float) std::acos((double) x); }
+inline float expf_cr(float x) { return (float) std::exp((double) x); }
+inline float logf_cr(float x) { return (float) std::log((double) x); }
+inline float erff_cr(float x) { return (float) std::erf((double) x); }
+inline float mulsign(float a, float b) { return std::signbit(b) ? -a : a; }
+inline float mulsign_neg(float a, float b) { return std::signbit(b) ? a : -a; }
+
+// erfinv — Giles, "Approximating the erfinv function" (single precision);
+// enoki/special.h cites the same source.  Horner evaluation with fma.
+inline float erfinv_giles(float x) {
+    float w = -logf_cr((1.f - x) * (1.f + x));
+    float p;
+    if (w < 5.f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmadd(p, w, 3.43273939e-07f);
+        p = fmadd(p, w, -3.5233877e-06f);
+        p = fmadd(p, w, -4.39150654e-06f);
+        p = fmadd(p, w, 0.00021858087f);
+        p = fmadd(p, w, -0.00125372503f);
+        p = fmadd(p, w, -0.00417768164f);
+        p = fmadd(p, w, 0.246640727f);
+        p = fmadd(p, w, 1.50140941f);
+    } else {
+        w = std::sqrt(w) - 3.f;
+        p = -0.000200214257f;
+        p = fmadd(p, w, 0.000100950558f);
+        p = fmadd(p, w, 0.00134934322f);
+        p = fmadd(p, w, -0.00367342844f);
+        p = fmadd(p, w, 0.00573950773f);
+        p = fmadd(p, w, -0.0076224613f);
+        p = fmadd(p, w, 0.00943887047f);
+        p = fmadd(p, w, 1.00167406f);
+        p = fmadd(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+// enoki generic dot_: result = a0*b0; result = fmadd(a_i, b_i, result)
+inline float dot(V3 a, V3 b) { return fmadd(a.z, b.z, fmadd(a.y, b.y, a.x * b.x)); }
+inline float squared_norm(V3 a) { return dot(a, a); }
+inline float norm(V3 a) { return std::sqrt(squared_norm(a)); }
+inline V3 normalize(V3 a) { return a * (1.f / std::sqrt(squared_norm(a))); }
+// enoki cross: fmsub(a.yzx, b.zxy, a.zxy * b.yzx)
+inline V3 cross(V3 a, V3 b) {
+    return {fmsub(a.y, b.z, a.z * b.y), fmsub(a.z, b.x, a.x * b.z), fmsub(a.x, b.y, a.y * b.x)};
+}
+inline float hmax_abs(V3 a) { return std::max(std::max(std::fabs(a.x), std::fabs(a.y)), std::fabs(a.z)); }
+inline V3 fmadd3(V3 d, float t, V3 o) { return {fmadd(d.x, t, o.x), fmadd(d.y, t, o.y), fmadd(d.z, t, o.z)}; }
+
+// include/mitsuba/core/vector.h:116-136 (Duff et al.)
+inline void coordinate_system(V3 n, V3 &s, V3 &t) {
+    float sign = std::copysign(1.f, n.z);
+    float a = -rcp(sign + n.z);
+    float b = n.x * n.y * a;
+    s = {mulsign(sqr(n.x) * a, n.z) + 1.f, mulsign(b, n.z), mulsign_neg(n.x, n.z)};
+    t = {b, sign + sqr(n.y) * a, -n.y};
+}
+
+// include/mitsuba/core/frame.h:20-40
+struct Frame {
+    V3 s, t, n;
+    V3 to_local(V3 v) const { return {dot(v, s), dot(v, t), dot(v, n)}; }
+    V3 to_world(V3 v) const { return s * v.x + t * v.y + n * v.z; }
+};
+inline Frame frame_from_normal(V3 n) {
+    Frame f;
+    f.n = n;
+    coordinate_system(n, f.s, f.t);
+    return f;
+}
+
+// row-major 4x4; enoki Transform::operator* / transform_affine start from the
+// translation column and fmadd the columns in (include/mitsuba/core/transform.h)
+struct M4 {
+    float m[16];
+};
+inline V3 xf_point(const M4 &M, V3 p) {
+    V3 r = {M.m[3], M.m[7], M.m[11]};
+    r = {fmadd(M.m[0], p.x, r.x), fmadd(M.m[4], p.x, r.y), fmadd(M.m[8], p.x, r.z)};
+    r = {fmadd(M.m[1], p.y, r.x), fmadd(M.m[5], p.y, r.y), fmadd(M.m[9], p.y, r.z)};
+    r = {fmadd(M.m[2], p.z, r.x), fmadd(M.m[6], p.z, r.y), fmadd(M.m[10], p.z, r.z)};
+    return r;
+}
+inline V3 xf_vector(const M4 &M, V3 v) {
+    V3 r = {M.m[0] * v.x, M.m[4] * v.x, M.m[8] * v.x};
+    r = {fmadd(M.m[1], v.y, r.x), fmadd(M.m[5], v.y, r.y), fmadd(M.m[9], v.y, r.z)};
+    r = {fmadd(M.m[2], v.z, r.x), fmadd(M.m[6], v.z, r.y), fmadd(M.m[10], v.z, r.z)};
+    return r;
+}
+// full projective transform of a point (w divide), transform.h operator*(Point)
+inline V3 xf_point_proj(const M4 &M, V3 p) {
+    float r[4];
+    for (int i = 0; i < 4; ++i) {
+        float acc = M.m[4 * i + 3];
+        acc = fmadd(M.m[4 * i + 0], p.x, acc);
+        acc = fmadd(M.m[4 * i + 1], p.y, acc);
+        acc = fmadd(M.m[4 * i + 2], p.z, acc);
+        r[i] = acc;
+    }
+    return {r[0] / r[3], r[1] / r[3], r[2] / r[3]};
+}
+// ---------------------------------------------------------------------------
+// PCG32 — enoki/random.h (absent); O'Neill's pcg32 reference algorithm.
+// Seeding per src/librender/sampler.cpp:83-96, draws per
+// src/samplers/independent.cpp:73-82.
+// ---------------------------------------------------------------------------
+constexpr uint64_t PCG32_DEFAULT_STATE = 0x853c49e6748fea9bULL;
+constexpr uint64_t PCG32_DEFAULT_STREAM = 0xda3e39cb94b95bdbULL;
+constexpr uint64_t PCG32_MULT = 0x5851f42d4c957f2dULL;
+struct PCG32 {
+    uint64_t state = PCG32_DEFAULT_STATE, inc = PCG32_DEFAULT_STREAM;
+    void seed(uint64_t initstate, uint64_t initseq = PCG32_DEFAULT_STREAM) {
+        state = 0;
+        inc = (initseq << 1) | 1ULL;
+        next_u32();
+        state += initstate;
+        next_u32();
+    }
+    uint32_t next_u32() {
+        uint64_t old = state;
+        state = old * PCG32_MULT + inc;
+        uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t) (old >> 59);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+    }
+    float next_float() {
+        uint32_t u = (next_u32() >> 9) | 0x3f800000u;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f - 1.f;
+    }
+};
+struct Sampler {
+    PCG32 rng;
+    uint64_t n_draws = 0;
+    float next_1d() {
+        ++n_draws;
+        return rng.next_float();
+    }
+    void next_2d(float &a, float &b) {
+        a = next_1d();
+        b = next_1d();
+    }
+};
+
+// include/mitsuba/core/random.h sample_tea_32 / sample_tea_float32
+inline uint32_t tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *out_v0) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    if (out_v0) *out_v0 = v0;
+    return v1;
+}
+
+// ---------------------------------------------------------------------------
+// warps — include/mitsuba/core/warp.h:54-90, 325-350, 446-490
+// ---------------------------------------------------------------------------
+inline void square_to_uniform_disk_concentric(float sx, float sy, float &ox, float &oy) {
+    float x = fmsub(2.f, sx, 1.f), y = fmsub(2.f, sy, 1.f);
+    bool is_zero = (x == 0.f) && (y == 0.f);
+    bool q13 = std::fabs(x) < std::fabs(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = .25f * kPi * rp / r;
+    if (q13) phi = .5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s = sinf_cr(phi), c = cosf_cr(phi);
+    ox = r * c;
+    oy = r * s;
+}
+inline V3 square_to_cosine_hemisphere(float sx, float sy) {
+    float px, py;
+    square_to_uniform_disk_concentric(sx, sy, px, py);
+    // squared_norm of a 2-vector: fmadd(py, py, px*px)
+    float z = safe_sqrt(1.f - fmadd(py, py, px * px));
+    return {px, py, z};
+}
+inline float square_to_cosine_hemisphere_pdf(V3 v) { return kInvPi * v.z; }
+inline V3 square_to_uniform_cone(float sx, float sy, float cos_cutoff) {
+    float omc = 1.f - cos_cutoff;
+    float px, py;
+    square_to_uniform_disk_concentric(sx, sy, px, py);
+    float pn = fmadd(py, py, px * px);
+    float z = cos_cutoff + omc * (1.f - pn);
+    float s = safe_sqrt(omc * (2.f - omc * pn));
+    return {px * s, py * s, z};
+}
+
+// ---------------------------------------------------------------------------
+// scene representation
+// ---------------------------------------------------------------------------
+struct Rect {
+    M4 to_world, to_object;
+    Frame frame;              // rectangle.cpp:83-92 (s = dp_du, t = dp_dv, n)
+    float inv_area;
+};
+struct Tri {
+    V3 p0, p1, p2;
+    V3 n0, n1, n2;
+    bool has_normals;
+};
+struct Shape {
+    uint32_t type, material;
+    int32_t emitter;
+    uint32_t prim_offset, prim_count;
+    int32_t rect;             // index into rects
+    uint32_t tri_offset;      // index into tris
+};
+struct Emitter {
+    bf_emitter d;
+    M4 to_world, to_object;
+    float cutoff, beam, inv_transition, cos_cutoff, cos_beam;
+};
+struct BVHNode {
+    float lo[3], hi[3];
+    int32_t left, right;      // children (internal) or -1
+    uint32_t first, count;    // leaf range in tri_order
+};
+struct Hit {
+    float t = kInf;
+    float u = 0, v = 0;
+    uint32_t prim = 0, shape = 0;
+    bool valid() const { return t != kInf; }
+};
+struct Ray {
+    V3 o, d;
+    float mint, maxt, time;
+};
+// SurfaceInteraction — include/mitsuba/render/interaction.h
+struct SI {
+    float t = kInf, time = 0;
+    V3 p, n, wi;
+    Frame sh;
+    uint32_t shape = 0, prim = 0;
+    bool valid() const { return t != kInf; }
+};
+
+struct OScene {
+    std::vector<Shape> shapes;
+    std::vector<Rect> rects;
+    std::vector<uint32_t> rect_shape;     // shape index of each rect
+    std::vector<Tri> tris;                // all mesh triangles, global order
+    std::vector<uint32_t> tri_shape;      // shape index of each triangle
+    std::vector<bf_material> materials;
+    std::vector<Emitter> emitters;
+    bf_sensor sensor;
+    bf_physics physics;
+    M4 cam_to_world, sample_to_camera;    // perspective
+    // accel
+    std::vector<BVHNode> nodes;
+    std::vector<uint32_t> tri_order;
+    bool brute_force = false;
+    mutable std::atomic<uint64_t> n_nodes{0}, n_tris{0};
+};
+
+// ---------------------------------------------------------------------------
+// primitive tests
+// ---------------------------------------------------------------------------
+// Mesh::ray_intersect_triangle — include/mitsuba/render/mesh.h:190-224
+inline bool tri_intersect(const Tri &tr, const Ray &ray, float &t, float &u, float &v) {
+    V3 e1 = tr.p1 - tr.p0, e2 = tr.p2 - tr.p0;
+    V3 pvec = cross(ray.d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = ray.o - tr.p0;
+    u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, e1);
+    v = dot(ray.d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    t = dot(e2, qvec) * inv_det;
+    active = active && t >= ray.mint && t <= ray.maxt;
+    return active;
+}
+// Rectangle::ray_intersect_preliminary — src/shapes/rectangle.cpp:229-249
+inline bool rect_intersect(const Rect &rc, const Ray &ray, float &t, float &lx, float &ly) {
+    V3 o = xf_point(rc.to_object, ray.o);
+    V3 d = xf_vector(rc.to_object, ray.d);
+    float d_rcp_z = rcp(d.z);
+    t = -o.z * d_rcp_z;
+    V3 local = fmadd3(d, t, o);
+    lx = local.x;
+    ly = local.y;
+    return t >= ray.mint && t <= ray.maxt && std::fabs(local.x) <= 1.f && std::fabs(local.y) <= 1.f;
+}
+
+// Closest-hit tie rule.  The reference keeps ray.maxt = t and accepts
+// `t <= maxt` (kdtree.h:2139-2156, ray_intersect_naive), so among equal t the
+// LATER primitive in test order wins; with the naive order that is the larger
+// global primitive index.  We fix exactly that rule so the result does not
+// depend on the accelerator's traversal order.
+inline void consider(Hit &best, float t, float u, float v, uint32_t prim, uint32_t shape) {
+    if (t < best.t || (t == best.t && prim > best.prim)) {
+        best.t = t;
+        best.u = u;
+        best.v = v;
+        best.prim = prim;
+        best.shape = shape;
+    }
+}
+
+inline bool box_hit(const BVHNode &nd, const Ray &ray, V3 inv_d, float tmax) {
+    float t0x = (nd.lo[0] - ray.o.x) * inv_d.x, t1x = (nd.hi[0] - ray.o.x) * inv_d.x;
+    float t0y = (nd.lo[1] - ray.o.y) * inv_d.y, t1y = (nd.hi[1] - ray.o.y) * inv_d.y;
+    float t0z = (nd.lo[2] - ray.o.z) * inv_d.z, t1z = (nd.hi[2] - ray.o.z) * inv_d.z;
+    float tn = std::fmax(std::fmax(std::fmin(t0x, t1x), std::fmin(t0y, t1y)),
+                         std::fmax(std::fmin(t0z, t1z), ray.mint));
+    float tf = std::fmin(std::fmin(std::fmax(t0x, t1x), std::fmax(t0y, t1y)),
+                         std::fmin(std::fmax(t0z, t1z), tmax));
+    return tn <= tf * 1.0000004f;
+}
+
+template <bool Any> static bool traverse(const OScene &sc, const Ray &ray, Hit &best) {
+    // analytic rectangles: tested for every ray (scenes hold a handful)
+    for (size_t i = 0; i < sc.rects.size(); ++i) {
+        float t, lx, ly;
+        if (rect_intersect(sc.rects[i], ray, t, lx, ly)) {
+            if (Any) return true;
+            uint32_t s = sc.rect_shape[i];
+            consider(best, t, lx, ly, sc.shapes[s].prim_offset, s);
+        }
+    }
+    if (sc.tris.empty()) return best.valid();
+    auto test_tri = [&](uint32_t ti) -> bool {
+        float t, u, v;
+        if (tri_intersect(sc.tris[ti], ray, t, u, v)) {
+            if (Any) return true;
+            uint32_t s = sc.tri_shape[ti];
+            const Shape &sh = sc.shapes[s];
+            consider(best, t, u, v, sh.prim_offset + (ti - sh.tri_offset), s);
+        }
+        return false;
+    };
+    if (sc.brute_force) {
+        for (uint32_t ti = 0; ti < sc.tris.size(); ++ti)
+            if (test_tri(ti)) return true;
+        return best.valid();
+    }
+    V3 inv_d = {1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z};
+    int stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    uint64_t nn = 0, nt = 0;
+    bool found = false;
+    while (sp) {
+        const BVHNode &nd = sc.nodes[stack[--sp]];
+        ++nn;
+        float tmax = Any ? ray.maxt : std::fmin(ray.maxt, best.t);
+        if (!box_hit(nd, ray, inv_d, tmax)) continue;
+        if (nd.left < 0) {
+            for (uint32_t i = 0; i < nd.count; ++i) {
+                ++nt;
+                if (test_tri(sc.tri_order[nd.first + i])) {
+                    found = true;
+                    break;
+                }
+            }
+            if (found) break;
+        } else {
+            stack[sp++] = nd.left;
+            stack[sp++] = nd.right;
+        }
+    }
+    sc.n_nodes.fetch_add(nn, std::memory_order_relaxed);
+    sc.n_tris.fetch_add(nt, std::memory_order_relaxed);
+    if (Any) return found;
+    return best.valid();
+}
+
+// median-split BVH over triangle centroids (oracle's own accelerator; results
+// are accelerator-independent thanks to the tie rule above)
+static void build_bvh(OScene &sc) {
+    size_t n = sc.tris.size();
+    sc.tri_order.resize(n);
+    for (size_t i = 0; i < n; ++i) sc.tri_order[i] = (uint32_t) i;
+    sc.nodes.clear();
+    if (!n) return;
+    std::vector<V3> cent(n), lo(n), hi(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Tri &t = sc.tris[i];
+        lo[i] = {std::min({t.p0.x, t.p1.x, t.p2.x}), std::min({t.p0.y, t.p1.y, t.p2.y}), std::min({t.p0.z, t.p1.z, t.p2.z})};
+        hi[i] = {std::max({t.p0.x, t.p1.x, t.p2.x}), std::max({t.p0.y, t.p1.y, t.p2.y}), std::max({t.p0.z, t.p1.z, t.p2.z})};
+        cent[i] = (lo[i] + hi[i]) * 0.5f;
+    }
+    struct Job {
+        uint32_t node, first, count;
+    };
+    std::vector<Job> todo;
+    sc.nodes.push_back({});
+    todo.push_back({0, 0, (uint32_t) n});
+    while (!todo.empty()) {
+        Job j = todo.back();
+        todo.pop_back();
+        V3 blo = {kInf, kInf, kInf}, bhi = {-kInf, -kInf, -kInf}, clo = blo, chi = bhi;
+        for (uint32_t i = 0; i < j.count; ++i) {
+            uint32_t ti = sc.tri_order[j.first + i];
+            blo = {std::min(blo.x, lo[ti].x), std::min(blo.y, lo[ti].y), std::min(blo.z, lo[ti].z)};
+            bhi = {std::max(bhi.x, hi[ti].x), std::max(bhi.y, hi[ti].y), std::max(bhi.z, hi[ti].z)};
+            clo = {std::min(clo.x, cent[ti].x), std::min(clo.y, cent[ti].y), std::min(clo.z, cent[ti].z)};
+            chi = {std::max(chi.x, cent[ti].x), std::max(chi.y, cent[ti].y), std::max(chi.z, cent[ti].z)};
+        }
+        // pad: fp32 hit distances can land a hair outside the exact box
+        V3 ext = bhi - blo;
+        float pad = 1e-5f * std::max({ext.x, ext.y, ext.z, hmax_abs(blo), hmax_abs(bhi)}) + 1e-30f;
+        BVHNode nd;
+        nd.lo[0] = blo.x - pad; nd.lo[1] = blo.y - pad; nd.lo[2] = blo.z - pad;
+        nd.hi[0] = bhi.x + pad; nd.hi[1] = bhi.y + pad; nd.hi[2] = bhi.z + pad;
+        nd.left = nd.right = -1;
+        nd.first = j.first;
+        nd.count = j.count;
+        if (j.count > 4) {
+            V3 ce = chi - clo;
+            int ax = (ce.x >= ce.y && ce.x >= ce.z) ? 0 : (ce.y >= ce.z ? 1 : 2);
+            auto key = [&](uint32_t ti) { return ax == 0 ? cent[ti].x : (ax == 1 ? cent[ti].y : cent[ti].z); };
+            uint32_t mid = j.count / 2;
+            std::nth_element(sc.tri_order.begin() + j.first, sc.tri_order.begin() + j.first + mid,
+                             sc.tri_order.begin() + j.first + j.count,
+                             [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+            nd.left = (int32_t) sc.nodes.size();
+            nd.right = nd.left + 1;
+            sc.nodes.push_back({});
+            sc.nodes.push_back({});
+            todo.push_back({(uint32_t) nd.left, j.first, mid});
+            todo.push_back({(uint32_t) nd.right, j.first + mid, j.count - mid});
+        }
+        sc.nodes[j.node] = nd;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// surface interaction
+// ---------------------------------------------------------------------------
+// PreliminaryIntersection::compute_surface_interaction
+// (include/mitsuba/render/interaction.h:613-644) +
+// Mesh::compute_surface_interaction (src/librender/mesh.cpp:452-548) /
+// Rectangle::compute_surface_interaction (src/shapes/rectangle.cpp:265-298)
+static SI make_si(const OScene &sc, const Ray &ray, const Hit &h) {
+    SI si;
+    if (!h.valid()) {            // scene_native.inl:34-38
+        si.wi = -ray.d;
+        si.t = kInf;
+        return si;
+    }
+    const Shape &sh = sc.shapes[h.shape];
+    si.t = h.t;
+    si.shape = h.shape;
+    si.prim = h.prim;
+    si.time = ray.time;
+    V3 dp_du;
+    if (sh.type == BF_SHAPE_RECTANGLE) {
+        const Rect &rc = sc.rects[sh.rect];
+        si.p = fmadd3(ray.d, h.t, ray.o);
+        si.n = rc.frame.n;
+        si.sh.n = rc.frame.n;
+        dp_du = rc.frame.s;
+    } else {
+        const Tri &tr = sc.tris[sh.tri_offset + (h.prim - sh.prim_offset)];
+        float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
+        V3 dp0 = tr.p1 - tr.p0, dp1 = tr.p2 - tr.p0;
+        si.p = tr.p0 * b0 + tr.p1 * b1 + tr.p2 * b2;
+        si.n = normalize(cross(dp0, dp1));
+        V3 dp_dv;
+        coordinate_system(si.n, dp_du, dp_dv);
+        if (tr.has_normals)
+            si.sh.n = normalize(tr.n0 * b0 + tr.n1 * b1 + tr.n2 * b2);
+        else
+            si.sh.n = si.n;
+    }
+    // initialize_sh_frame — interaction.h:159-162
+    float d_ = dot(si.sh.n, dp_du);
+    si.sh.s = normalize(V3{fnmadd(si.sh.n.x, d_, dp_du.x), fnmadd(si.sh.n.y, d_, dp_du.y), fnmadd(si.sh.n.z, d_, dp_du.z)});
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = si.sh.to_local(-ray.d);
+    return si;
+}
+
+static SI ray_intersect(const OScene &sc, const Ray &ray) {
+    Hit h;
+    traverse<false>(sc, ray, h);
+    return make_si(sc, ray, h);
+}
+static bool ray_test(const OScene &sc, const Ray &ray) {
+    Hit h;
+    return traverse<true>(sc, ray, h);
+}
+
+// ---------------------------------------------------------------------------
+// BSDFs
+// ---------------------------------------------------------------------------
+struct BSDFSample {
+    V3 wo = {0, 0, 0};
+    float pdf = 0, eta = 1;
+    bool delta = false;
+};
+
+// MicrofacetDistribution — include/mitsuba/render/microfacet.h
+struct Microfacet {
+    uint32_t type;
+    float au, av;
+    bool sample_visible;
+    Microfacet(const bf_material &m)
+        : type(m.distribution), au(std::max(m.alpha_u, 1e-4f)), av(std::max(m.alpha_v, 1e-4f)),
+          sample_visible(m.sample_visible != 0) {}
+    float eval(V3 m) const {   // microfacet.h eval()
+        float alpha_uv = au * av, cos_theta = m.z, cos_theta_2 = sqr(cos_theta), result;
+        if (type == BF_MF_BECKMANN)
+            result = expf_cr(-(sqr(m.x / au) + sqr(m.y / av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
+        else
+            result = rcp(kPi * alpha_uv * sqr(sqr(m.x / au) + sqr(m.y / av) + sqr(m.z)));
+        return (result * cos_theta > 1e-20f) ? result : 0.f;
+    }
+    float smith_g1(V3 v, V3 m) const {
+        float xy_alpha_2 = sqr(au * v.x) + sqr(av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z), result;
+        if (type == BF_MF_BECKMANN) {
+            float a = 1.f / std::sqrt(tan_theta_alpha_2), a_sqr = sqr(a);
+            result = (a >= 1.6f) ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+        } else {
+            result = 2.f / (1.f + std::sqrt(1.f + tan_theta_alpha_2));
+        }
+        if (xy_alpha_2 == 0.f) result = 1.f;
+        if (dot(v, m) * v.z <= 0.f) result = 0.f;
+        return result;
+    }
+    float G(V3 wi, V3 wo, V3 m) const { return smith_g1(wi, m) * smith_g1(wo, m); }
+    void sample_visible_11(float cos_theta_i, float sx, float sy, float &ox, float &oy) const {
+        if (type == BF_MF_BECKMANN) {
+            float tan_theta_i = safe_sqrt(fnmadd(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i;
+            float cot_theta_i = rcp(tan_theta_i);
+            float maxval = erff_cr(cot_theta_i);
+            sx = std::max(std::min(sx, 1.f - 1e-6f), 1e-6f);
+            sy = std::max(std::min(sy, 1.f - 1e-6f), 1e-6f);
+            float x = maxval - (maxval + 1.f) * erff_cr(std::sqrt(-logf_cr(sx)));
+            sx *= 1.f + maxval + kInvSqrtPi * tan_theta_i * expf_cr(-sqr(cot_theta_i));
+            for (int i = 0; i < 3; ++i) {
+                float slope = erfinv_giles(x);
+                float value = 1.f + x + kInvSqrtPi * tan_theta_i * expf_cr(-sqr(slope)) - sx;
+                float derivative = 1.f - slope * tan_theta_i;
+                x -= value / derivative;
+            }
+            ox = erfinv_giles(x);
+            oy = erfinv_giles(fmsub(2.f, sy, 1.f));
+        } else {
+            float px, py;
+            square_to_uniform_disk_concentric(sx, sy, px, py);
+            float s = .5f * (1.f + cos_theta_i);
+            float a = safe_sqrt(1.f - sqr(px));
+            py = fmadd(py, s, fnmadd(a, s, a));   // lerp(a, py, s)
+            float x = px, y = py, z = safe_sqrt(1.f - fmadd(py, py, px * px));
+            float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+            float nrm = rcp(fmadd(sin_theta_i, y, cos_theta_i * z));
+            ox = fmsub(cos_theta_i, y, sin_theta_i * z) * nrm;
+            oy = x * nrm;
+        }
+    }
+    // sample(): visible-normal branch and the plain branch, microfacet.h
+    void sample(V3 wi, float sx, float sy, V3 &m, float &pdf) const {
+        if (!sample_visible) {
+            float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+            if (au == av) {
+                float ang = (2.f * kPi) * sy;
+                sin_phi = sinf_cr(ang);
+                cos_phi = cosf_cr(ang);
+                alpha_2 = au * au;
+            } else {
+                float ratio = av / au, tmp = ratio * (float) std::tan((double) ((2.f * kPi) * sy));
+                cos_phi = 1.f / std::sqrt(fmadd(tmp, tmp, 1.f));
+                cos_phi = mulsign(cos_phi, std::fabs(sy - .5f) - .25f);
+                sin_phi = cos_phi * tmp;
+                alpha_2 = rcp(sqr(cos_phi / au) + sqr(sin_phi / av));
+            }
+            if (type == BF_MF_BECKMANN) {
+                cos_theta = 1.f / std::sqrt(fnmadd(alpha_2, logf_cr(1.f - sx), 1.f));
+                cos_theta_2 = sqr(cos_theta);
+                float cos_theta_3 = std::max(cos_theta_2 * cos_theta, 1e-20f);
+                pdf = (1.f - sx) / (kPi * au * av * cos_theta_3);
+            } else {
+                float tan_theta_m_2 = alpha_2 * sx / (1.f - sx);
+                cos_theta = 1.f / std::sqrt(1.f + tan_theta_m_2);
+                cos_theta_2 = sqr(cos_theta);
+                float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = std::max(cos_theta_2 * cos_theta, 1e-20f);
+                pdf = rcp(kPi * au * av * cos_theta_3 * sqr(temp));
+            }
+            float sin_theta = std::sqrt(1.f - cos_theta_2);
+            m = {cos_phi * sin_theta, sin_phi * sin_theta, cos_theta};
+        } else {
+            V3 wi_p = normalize(V3{au * wi.x, av * wi.y, wi.z});
+            // Frame::sincos_phi — frame.h
+            float sin_theta_2 = fmadd(wi_p.x, wi_p.x, sqr(wi_p.y));
+            float inv_sin_theta = 1.f / std::sqrt(sin_theta_2);
+            float sin_phi, cos_phi;
+            if (std::fabs(sin_theta_2) <= 4.f * kEpsilon) {
+                sin_phi = 0.f;
+                cos_phi = 1.f;
+            } else {
+                sin_phi = std::min(std::max(wi_p.y * inv_sin_theta, -1.f), 1.f);
+                cos_phi = std::min(std::max(wi_p.x * inv_sin_theta, -1.f), 1.f);
+            }
+            float cos_theta = wi_p.z;
+            float slx, sly;
+            sample_visible_11(cos_theta, sx, sy, slx, sly);
+            float rx = fmsub(cos_phi, slx, sin_phi * sly) * au;
+            float ry = fmadd(sin_phi, slx, cos_phi * sly) * av;
+            m = normalize(V3{-rx, -ry, 1.f});
+            pdf = eval(m) * smith_g1(wi, m) * std::fabs(dot(wi, m)) / wi.z;
+        }
+    }
+    float pdf(V3 wi, V3 m) const {
+        float result = eval(m);
+        if (sample_visible)
+            result *= smith_g1(wi, m) * std::fabs(dot(wi, m)) / wi.z;
+        else
+            result *= m.z;
+        return result;
+    }
+};
+
+// fresnel_conductor — include/mitsuba/render/fresnel.h:92-116
+inline float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2,
+          sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+          a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return .5f * (r_s + r_p);
+}
+inline V3 reflect(V3 wi, V3 m) {   // include/mitsuba/render/fresnel.h reflect(wi, m)
+    float d2 = 2.f * dot(wi, m);
+    return {fmsub(m.x, d2, wi.x), fmsub(m.y, d2, wi.y), fmsub(m.z, d2, wi.z)};
+}
+
+// one-sided BSDFs: diffuse.cpp:78-135, roughconductor.cpp:196-392
+static float bsdf_sample_1(const bf_material &mat, V3 wi, float /*s1*/, float s2x, float s2y, BSDFSample &bs) {
+    bs = BSDFSample();
+    float cos_theta_i = wi.z;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        if (!(cos_theta_i > 0.f)) return 0.f;
+        bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+        bs.pdf = square_to_cosine_hemisphere_pdf(bs.wo);
+        bs.eta = 1.f;
+        return (bs.pdf > 0.f) ? mat.reflectance : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        if (!(cos_theta_i > 0.f)) return 0.f;
+        Microfacet distr(mat);
+        V3 m;
+        distr.sample(wi, s2x, s2y, m, bs.pdf);
+        bs.wo = reflect(wi, m);
+        bs.eta = 1.f;
+        bool active = bs.pdf != 0.f && bs.wo.z > 0.f;
+        float weight;
+        if (distr.sample_visible)
+            weight = distr.smith_g1(bs.wo, m);
+        else
+            weight = distr.G(wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
+        bs.pdf /= 4.f * dot(bs.wo, m);
+        float F = fresnel_conductor(dot(wi, m), mat.eta, mat.k);
+        if (mat.has_specular_reflectance) weight *= mat.reflectance;
+        return active ? F * weight : 0.f;
+    }
+    return 0.f;
+}
+static float bsdf_eval_1(const bf_material &mat, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
+        float value = mat.reflectance * kInvPi * cos_theta_o;
+        return active ? value : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
+        if (!active) return 0.f;
+        V3 H = normalize(wo + wi);
+        Microfacet distr(mat);
+        float D = distr.eval(H);
+        active = active && D != 0.f;
+        float G = distr.G(wi, wo, H);
+        float result = D * G / (4.f * wi.z);
+        float F = fresnel_conductor(dot(wi, H), mat.eta, mat.k);
+        if (mat.has_specular_reflectance) result *= mat.reflectance;
+        return active ? F * result : 0.f;
+    }
+    return 0.f;
+}
+static float bsdf_pdf_1(const bf_material &mat, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        float pdf = square_to_cosine_hemisphere_pdf(wo);
+        return (cos_theta_i > 0.f && cos_theta_o > 0.f) ? pdf : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        V3 m = normalize(wo + wi);
+        bool active = cos_theta_i > 0.f && cos_theta_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
+        if (!active) return 0.f;
+        Microfacet distr(mat);
+        float result;
+        if (distr.sample_visible)
+            result = distr.eval(m) * distr.smith_g1(wi, m) / (4.f * cos_theta_i);
+        else
+            result = distr.pdf(wi, m) / (4.f * dot(wo, m));
+        return result;
+    }
+    return 0.f;
+}
+// TwoSidedBRDF — src/bsdfs/twosided.cpp:94-180 (same nested BSDF on both sides)
+static float bsdf_sample(const bf_material &mat, V3 wi, float s1, float s2x, float s2y, BSDFSample &bs) {
+    if (!mat.twosided) return bsdf_sample_1(mat, wi, s1, s2x, s2y, bs);
+    bs = BSDFSample();
+    if (wi.z > 0.f) return bsdf_sample_1(mat, wi, s1, s2x, s2y, bs);
+    if (wi.z < 0.f) {
+        wi.z *= -1.f;
+        float r = bsdf_sample_1(mat, wi, s1, s2x, s2y, bs);
+        bs.wo.z *= -1.f;
+        return r;
+    }
+    return 0.f;
+}
+static float bsdf_eval(const bf_material &mat, V3 wi, V3 wo) {
+    if (!mat.twosided) return bsdf_eval_1(mat, wi, wo);
+    if (wi.z > 0.f) return bsdf_eval_1(mat, wi, wo);
+    if (wi.z < 0.f) {
+        wi.z *= -1.f;
+        wo.z *= -1.f;
+        return bsdf_eval_1(mat, wi, wo);
+    }
+    return 0.f;
+}
+static float bsdf_pdf(const bf_material &mat, V3 wi, V3 wo) {
+    if (!mat.twosided) return bsdf_pdf_1(mat, wi, wo);
+    if (wi.z > 0.f) return bsdf_pdf_1(mat, wi, wo);
+    if (wi.z < 0.f) {
+        wi.z *= -1.f;
+        wo.z *= -1.f;
+        return bsdf_pdf_1(mat, wi, wo);
+    }
+    return 0.f;
+}
+inline bool bsdf_smooth(const bf_material &mat) {
+    // BSDFFlags::Smooth = Diffuse | Glossy (include/mitsuba/render/bsdf.h)
+    return mat.type == BF_BSDF_DIFFUSE || mat.type == BF_BSDF_ROUGHCONDUCTOR;
+}
+
+// ---------------------------------------------------------------------------
+// emitters
+// ---------------------------------------------------------------------------
+struct DirectionSample {
+    V3 p = {0, 0, 0}, n = {0, 0, 0}, d = {0, 0, 0};
+    float pdf = 0, dist = 0, time = 0;
+    bool delta = false;
+};
+
+// SpotLight::falloff_curve — src/emitters/spot.cpp:97-116
+static float spot_falloff(const Emitter &e, V3 d) {
+    float result = e.d.radiance;
+    V3 local_dir = normalize(d);
+    float cos_theta = local_dir.z;
+    float beam_res = (cos_theta >= e.cos_beam) ? result : result * ((e.cutoff - acosf_cr(cos_theta)) * e.inv_transition);
+    return (cos_theta <= e.cos_cutoff) ? 0.f : beam_res;
+}
+
+// Shape::sample_direction — src/librender/shape.cpp:323-342 on a rectangle
+// (Rectangle::sample_position — src/shapes/rectangle.cpp:111-125)
+static DirectionSample rect_sample_direction(const Rect &rc, V3 ref_p, float time, float sx, float sy) {
+    DirectionSample ds;
+    ds.p = xf_point(rc.to_world, V3{sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f});
+    ds.n = rc.frame.n;
+    ds.pdf = rc.inv_area;
+    ds.time = time;
+    ds.delta = false;
+    ds.d = ds.p - ref_p;
+    float dist_squared = squared_norm(ds.d);
+    ds.dist = std::sqrt(dist_squared);
+    ds.d = ds.d / ds.dist;
+    float dp = std::fabs(dot(ds.d, ds.n));
+    ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+    return ds;
+}
+
+// Emitter::sample_direction: spot.cpp:137-160, area.cpp:117-165
+static float emitter_sample_direction(const OScene &sc, const Emitter &e, const SI &ref, float sx, float sy, DirectionSample &ds) {
+    if (e.d.type == BF_EMITTER_SPOT) {
+        ds = DirectionSample();
+        ds.p = {e.to_world.m[3], e.to_world.m[7], e.to_world.m[11]};
+        ds.pdf = 1.f;
+        ds.time = ref.time;
+        ds.delta = true;
+        ds.d = ds.p - ref.p;
+        ds.dist = norm(ds.d);
+        float inv_dist = rcp(ds.dist);
+        ds.d = ds.d * inv_dist;
+        V3 local_d = xf_vector(e.to_object, -ds.d);
+        float falloff = spot_falloff(e, local_d);
+        return falloff * (inv_dist * inv_dist);
+    } else {  // BF_EMITTER_AREA
+        const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
+        ds = rect_sample_direction(rc, ref.p, ref.time, sx, sy);
+        bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+        float spec = e.d.radiance / ds.pdf;
+        return active ? spec : 0.f;
+    }
+}
+// Emitter::pdf_direction: spot.cpp:162-164, area.cpp:167-186 + shape.cpp:344-356
+static float emitter_pdf_direction(const OScene &sc, const Emitter &e, const DirectionSample &ds) {
+    if (e.d.type == BF_EMITTER_SPOT) return 0.f;
+    const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
+    float dp = dot(ds.d, ds.n);
+    bool active = dp < 0.f;
+    float pdf = rc.inv_area, adp = std::fabs(dot(ds.d, ds.n));
+    pdf *= (adp != 0.f) ? (ds.dist * ds.dist) / adp : 0.f;
+    return active ? pdf : 0.f;
+}
+// Emitter::eval: spot.cpp:166, area.cpp:66-74
+static float emitter_eval(const Emitter &e, const SI &si) {
+    if (e.d.type == BF_EMITTER_SPOT) return 0.f;
+    return (si.wi.z > 0.f) ? e.d.radiance : 0.f;
+}
+
+// Scene::sample_emitter_direction — src/librender/scene.cpp:180-230
+static float scene_sample_emitter_direction(const OScene &sc, const SI &ref, float sx, float sy, DirectionSample &ds,
+                                            uint32_t &n_shadow, int *emitter_idx = nullptr) {
+    float spec;
+    size_t k = sc.emitters.size();
+    if (k == 0) {
+        ds = DirectionSample();
+        return 0.f;
+    }
+    if (k == 1) {
+        spec = emitter_sample_direction(sc, sc.emitters[0], ref, sx, sy, ds);
+        if (emitter_idx) *emitter_idx = 0;
+    } else {
+        float emitter_pdf = 1.f / (float) k;
+        uint32_t index = std::min((uint32_t) (sx * (float) k), (uint32_t) k - 1);
+        sx = (sx - index * emitter_pdf) * (float) k;
+        spec = emitter_sample_direction(sc, sc.emitters[index], ref, sx, sy, ds);
+        ds.pdf *= emitter_pdf;
+        spec *= rcp(emitter_pdf);
+        if (emitter_idx) *emitter_idx = (int) index;
+    }
+    bool active = ds.pdf != 0.f;
+    if (active) {
+        Ray ray;
+        ray.o = ref.p;
+        ray.d = ds.d;
+        ray.mint = kRayEpsilon * (1.f + hmax_abs(ref.p));
+        ray.maxt = ds.dist * (1.f - kShadowEpsilon);
+        ray.time = ref.time;
+        ++n_shadow;
+        if (ray_test(sc, ray)) spec = 0.f;
+    }
+    return spec;
+}
+// Scene::pdf_emitter_direction — src/librender/scene.cpp:232-247
+static float scene_pdf_emitter_direction(const OScene &sc, int emitter, const DirectionSample &ds) {
+    if (sc.emitters.size() == 1) return emitter_pdf_direction(sc, sc.emitters[0], ds);
+    return emitter_pdf_direction(sc, sc.emitters[emitter], ds) * (1.f / (float) sc.emitters.size());
+}
+
+// ---------------------------------------------------------------------------
+// sensors
+// ---------------------------------------------------------------------------
+// FluxMeter::sample_ray_differential — src/sensors/fluxmeter.cpp:63-85
+// PerspectiveCamera::sample_ray_differential — src/sensors/perspective.cpp:172-199
+static float sensor_sample_ray(const OScene &sc, float time, float /*wl_sample*/, float px, float py, float ax, float ay,
+                               Ray &ray) {
+    const bf_sensor &s = sc.sensor;
+    if (s.type == BF_SENSOR_FLUXMETER) {
+        const Rect &rc = sc.rects[sc.shapes[s.shape].rect];
+        V3 p = xf_point(rc.to_world, V3{px * 2.f - 1.f, py * 2.f - 1.f, 0.f});
+        V3 local = square_to_cosine_hemisphere(ax, ay);
+        Frame f = frame_from_normal(rc.frame.n);
+        ray.o = p;
+        ray.d = f.to_world(local);
+        ray.mint = kRayEpsilon;
+        ray.maxt = kInf;
+        ray.time = time;
+        return 1.f * kPi;        // wav_weight (RGB: 1) * Pi
+    } else {  // perspective
+        V3 near_p = xf_point_proj(sc.sample_to_camera, V3{px, py, 0.f});
+        V3 d = normalize(near_p);
+        float inv_z = rcp(d.z);
+        ray.mint = s.near_clip * inv_z;
+        ray.maxt = s.far_clip * inv_z;
+        ray.o = xf_point(sc.cam_to_world, V3{0.f, 0.f, 0.f});
+        ray.d = xf_vector(sc.cam_to_world, d);
+        ray.time = time;
+        return 1.f;
+    }
+}
+inline bool sensor_needs_aperture_sample(const bf_sensor &s) {
+    // endpoint.h:241 default true; perspective.cpp:130 sets false
+    return s.type != BF_SENSOR_PERSPECTIVE;
+}
+
+// ---------------------------------------------------------------------------
+// integrators
+// ---------------------------------------------------------------------------
+inline float mis_weight(float pdf_a, float pdf_b) {   // path.cpp:222-226
+    pdf_a *= pdf_a;
+    pdf_b *= pdf_b;
+    return pdf_a > 0.f ? pdf_a / (pdf_a + pdf_b) : 0.f;
+}
+
+struct PathResult {
+    float L = 0, aux = 0;
+    bool valid = false;
+    uint32_t n_closest = 0, n_shadow = 0, n_bounces = 0;
+};
+
+// PathIntegrator::sample (path.cpp:100-210), PathLengthIntegrator::sample
+// (pathlength.cpp:114-324) and PathTimeIntegrator::sample (pathtime.cpp:114-284)
+// share one loop; they differ only in the auxiliary scalar:
+//   PATH  : none
+//   RANGE : pathlength, with the reference's extra adds (:146, :161, :209, :307)
+//   TIME  : pathtime = t/3e8 (overwrite at first hit :140, add per bounce :228)
+static PathResult path_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray) {
+    PathResult r;
+    float eta = 1.f, emission_weight = 1.f, throughput = 1.f, result = 0.f, aux = 0.f;
+    bool active = true;
+    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+
+    SI si = ray_intersect(sc, ray);
+    ++r.n_closest;
+    bool valid_ray = si.valid();
+    int emitter = si.valid() ? sc.shapes[si.shape].emitter : -1;
+    if (is_range) aux += valid_ray ? si.t : 0.f;
+    if (is_time) aux = si.valid() ? si.t / lp.time_c : 0.f;
+
+    for (int depth = 1;; ++depth) {
+        if (emitter >= 0) {
+            if (active) result += emission_weight * throughput * emitter_eval(sc.emitters[emitter], si);
+            if (is_range) aux += si.valid() ? si.t : 0.f;
+        }
+        active = active && si.valid();
+        if (depth > lp.rr_depth) {
+            float q = std::min(throughput * sqr(eta), .95f);
+            active = (smp.next_1d() < q) && active;
+            throughput *= rcp(q);
+        }
+        if ((uint32_t) depth >= (uint32_t) lp.max_depth || !active) break;
+
+        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+        ++r.n_bounces;
+        bool active_e = active && bsdf_smooth(mat);
+        if (active_e) {
+            float sx, sy;
+            smp.next_2d(sx, sy);
+            DirectionSample ds;
+            float emitter_val = scene_sample_emitter_direction(sc, si, sx, sy, ds, r.n_shadow);
+            active_e = active_e && ds.pdf != 0.f;
+            V3 wo = si.sh.to_local(ds.d);
+            float bsdf_val = bsdf_eval(mat, si.wi, wo);
+            float bsdf_pdf_ = bsdf_pdf(mat, si.wi, wo);
+            float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf_);
+            if (active_e) result += mis * throughput * bsdf_val * emitter_val;
+            if (is_range) aux += si.valid() ? si.t : 0.f;
+        }
+
+        float s1 = smp.next_1d(), s2x, s2y;
+        smp.next_2d(s2x, s2y);
+        BSDFSample bs;
+        float bsdf_val = bsdf_sample(mat, si.wi, s1, s2x, s2y, bs);
+        throughput = throughput * bsdf_val;
+        active = active && (throughput != 0.f);
+        if (!active) break;
+        eta *= bs.eta;
+
+        // si.spawn_ray — interaction.h:61-64
+        Ray nray;
+        nray.o = si.p;
+        nray.d = si.sh.to_world(bs.wo);
+        nray.mint = (1.f + hmax_abs(si.p)) * kRayEpsilon;
+        nray.maxt = kInf;
+        nray.time = si.time;
+        SI si_bsdf = ray_intersect(sc, nray);
+        ++r.n_closest;
+
+        emitter = si_bsdf.valid() ? sc.shapes[si_bsdf.shape].emitter : -1;
+        if (emitter >= 0) {
+            // DirectionSample(si_bsdf, si) — records.h:168-174
+            DirectionSample ds;
+            ds.p = si_bsdf.p;
+            ds.n = si_bsdf.sh.n;
+            ds.d = si_bsdf.p - si.p;
+            ds.dist = norm(ds.d);
+            ds.d = ds.d / ds.dist;
+            float emitter_pdf = bs.delta ? 0.f : scene_pdf_emitter_direction(sc, emitter, ds);
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
+        }
+        si = si_bsdf;
+        if (is_range) aux += si.valid() ? si.t : 0.f;
+        if (is_time) aux += si.valid() ? si.t / lp.time_c : 0.f;
+    }
+    r.L = result;
+    r.valid = valid_ray;
+    r.aux = aux;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// film: SamplingIntegrator::render_sample (integrator.cpp:259-310) +
+// RangeIntegrator / TimeIntegrator AOV fill (range.cpp:141-161,
+// time.cpp:118-153) + ImageBlock::put box-filter branch (imageblock.cpp)
+// ---------------------------------------------------------------------------
+inline void srgb_to_xyz_grey(float l, float *xyz) {
+    // include/mitsuba/core/spectrum.h:281-287, M * (l,l,l): enoki matrix*vector
+    // = col0*v0, then fmadd(col_j, v_j, acc)
+    const float M[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f, 0.072169f, 0.019334f, 0.119193f, 0.950227f};
+    for (int i = 0; i < 3; ++i) xyz[i] = fmadd(M[3 * i + 2], l, fmadd(M[3 * i + 1], l, M[3 * i + 0] * l));
+}
+
+struct SampleOut {
+    bool put;            // sample reached the film
+    float L;             // ray_weight * result
+    PathResult pr;
+};
+
+static uint32_t launch_channels(const bf_launch &lp) {
+    switch (lp.mode) {
+        case BF_MODE_PATH: return 5;
+        case BF_MODE_RANGE: return 5 + lp.bins;
+        case BF_MODE_TIME: return 5 + 3 * lp.bins;
+        case BF_MODE_RECEIVE_RAW: return 3;
+    }
+    return 0;
+}
+
+// one render_sample(); accumulates into hist (double accumulators so the CPU
+// sum itself is not the error source when compared with the GPU's fp32 atomics)
+static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, double *hist) {
+    SampleOut out;
+    float fx, fy;
+    smp.next_2d(fx, fy);                                    // :263 (pos = 0 for the 1x1 film)
+    float ax = .5f, ay = .5f;
+    if (sensor_needs_aperture_sample(sc.sensor)) smp.next_2d(ax, ay);   // :265-267
+    float time = sc.sensor.shutter_open;
+    if (sc.sensor.shutter_open_time > 0.f) time += smp.next_1d() * sc.sensor.shutter_open_time;   // :269-271
+    float wl = smp.next_1d();                               // :273
+    // adjusted_position = (position_sample - crop_offset) / crop_size, 1x1 film
+    Ray ray;
+    float w = sensor_sample_ray(sc, time, wl, fx / 1.f, fy / 1.f, ax, ay, ray);
+    out.pr = path_sample(sc, lp, smp, ray);
+    float L = w * out.pr.L;
+    out.L = L;
+
+    const uint32_t nchan = launch_channels(lp);
+    std::vector<float> aovs(nchan, 0.f);
+    float xyz[3];
+    if (lp.color_mode == BF_COLOR_RGB)
+        srgb_to_xyz_grey(L, xyz);
+    else
+        xyz[0] = xyz[1] = xyz[2] = L;
+    aovs[0] = xyz[0];
+    aovs[1] = xyz[1];
+    aovs[2] = xyz[2];
+    aovs[3] = out.pr.valid ? 1.f : 0.f;
+    aovs[4] = 1.f;
+    if (lp.mode == BF_MODE_RANGE || lp.mode == BF_MODE_TIME) {
+        // NOTE the AOV value is the integrator's radiance BEFORE ray_weight is
+        // applied (range.cpp:126 reads std::get<0>(result) inside sample()).
+        float l_aov = out.pr.L;
+        float a[3];
+        if (lp.mode == BF_MODE_TIME && lp.color_mode == BF_COLOR_RGB)
+            srgb_to_xyz_grey(l_aov, a);
+        else
+            a[0] = a[1] = a[2] = l_aov;
+        for (uint32_t i = 0; i < lp.bins; ++i) {
+            float lo = (float) i * lp.bin_width, hi = (float) i * lp.bin_width + lp.bin_width;
+            bool in = out.pr.aux >= lo && out.pr.aux < hi;
+            if (lp.mode == BF_MODE_RANGE)
+                aovs[5 + i] = in ? a[0] : 0.f;
+            else
+                for (int k = 0; k < 3; ++k) aovs[5 + 3 * i + k] = in ? a[k] : 0.f;
+        }
+    }
+    // ImageBlock::put: warn_invalid drops non-finite samples; box filter:
+    // lo = ceil(pos - .5 - .5) must be 0 in both axes for the 1x1 film
+    bool ok = true;
+    for (uint32_t k = 0; k < nchan; ++k) ok = ok && std::isfinite(aovs[k]);
+    int lox = (int) std::ceil((fx - .5f) - .5f), loy = (int) std::ceil((fy - .5f) - .5f);
+    ok = ok && lox == 0 && loy == 0;
+    out.put = ok;
+    if (ok)
+        for (uint32_t k = 0; k < nchan; ++k) hist[k] += (double) aovs[k];
+    return out;
+}
+
+static thread_local std::string g_err;
+
+}  // namespace
+
+// ===========================================================================
+// C interface (prefix bfo_): same POD structs as include/beifong_hip.h
+// ===========================================================================
+extern "C" {
+
+struct bfo_scene {
+    OScene sc;
+};
+
+const char *bfo_last_error(void) { return g_err.c_str(); }
+
+bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **out) {
+    if (!d || !out) return BF_ERR_INVALID;
+    bfo_scene *h = new bfo_scene();
+    OScene &sc = h->sc;
+    sc.brute_force = brute_force != 0;
+    sc.sensor = d->sensor;
+    sc.physics = d->physics;
+    sc.materials.assign(d->materials, d->materials + d->n_materials);
+    uint32_t prim = 0;
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const bf_shape &s = d->shapes[i];
+        Shape sh;
+        sh.type = s.type;
+        sh.material = s.material;
+        sh.emitter = s.emitter;
+        sh.prim_offset = prim;
+        sh.rect = -1;
+        sh.tri_offset = 0;
+        if (s.material >= d->n_materials) {
+            g_err = "shape material index out of range";
+            delete h;
+            return BF_ERR_INVALID;
+        }
+        if (s.type == BF_SHAPE_RECTANGLE) {
+            Rect rc;
+            std::memcpy(rc.to_world.m, s.to_world, sizeof(float) * 16);
+            std::memcpy(rc.to_object.m, s.to_object, sizeof(float) * 16);
+            // Rectangle::update — rectangle.cpp:83-92
+            rc.frame.s = xf_vector(rc.to_world, V3{2.f, 0.f, 0.f});
+            rc.frame.t = xf_vector(rc.to_world, V3{0.f, 2.f, 0.f});
+            // Transform * Normal uses the inverse transpose: row 2 of to_object
+            rc.frame.n = normalize(V3{rc.to_object.m[8], rc.to_object.m[9], rc.to_object.m[10]});
+            rc.inv_area = rcp(norm(cross(rc.frame.s, rc.frame.t)));
+            sh.rect = (int32_t) sc.rects.size();
+            sh.prim_count = 1;
+            sc.rects.push_back(rc);
+            sc.rect_shape.push_back(i);
+        } else {
+            sh.tri_offset = (uint32_t) sc.tris.size();
+            sh.prim_count = s.n_faces;
+            for (uint32_t f = 0; f < s.n_faces; ++f) {
+                Tri t;
+                uint32_t i0 = s.indices[3 * f], i1 = s.indices[3 * f + 1], i2 = s.indices[3 * f + 2];
+                if (i0 >= s.n_vertices || i1 >= s.n_vertices || i2 >= s.n_vertices) {
+                    g_err = "face index out of range";
+                    delete h;
+                    return BF_ERR_INVALID;
+                }
+                auto P = [&](uint32_t k) { return V3{s.positions[3 * k], s.positions[3 * k + 1], s.positions[3 * k + 2]}; };
+                t.p0 = P(i0); t.p1 = P(i1); t.p2 = P(i2);
+                t.has_normals = s.normals != nullptr;
+                if (t.has_normals) {
+                    auto N = [&](uint32_t k) { return V3{s.normals[3 * k], s.normals[3 * k + 1], s.normals[3 * k + 2]}; };
+                    t.n0 = N(i0); t.n1 = N(i1); t.n2 = N(i2);
+                } else {
+                    t.n0 = t.n1 = t.n2 = V3{0, 0, 0};
+                }
+                sc.tris.push_back(t);
+                sc.tri_shape.push_back(i);
+            }
+        }
+        prim += sh.prim_count;
+        sc.shapes.push_back(sh);
+    }
+    for (uint32_t i = 0; i < d->n_emitters; ++i) {
+        Emitter e;
+        e.d = d->emitters[i];
+        std::memcpy(e.to_world.m, e.d.to_world, sizeof(float) * 16);
+        if (e.d.type == BF_EMITTER_SPOT) {
+            std::memcpy(e.to_object.m, e.d.to_object, sizeof(float) * 16);
+            // SpotLight ctor — spot.cpp:83-93 (deg_to_rad = x * (Pi/180))
+            e.cutoff = e.d.cutoff_angle_deg * (kPi / 180.f);
+            e.beam = e.d.beam_width_deg * (kPi / 180.f);
+            e.inv_transition = 1.0f / (e.cutoff - e.beam);
+            e.cos_cutoff = cosf_cr(e.cutoff);
+            e.cos_beam = cosf_cr(e.beam);
+        } else {
+            std::memset(e.to_object.m, 0, sizeof(e.to_object.m));
+            e.cutoff = e.beam = e.inv_transition = e.cos_cutoff = e.cos_beam = 0;
+        }
+        sc.emitters.push_back(e);
+    }
+    if (d->sensor.type == BF_SENSOR_PERSPECTIVE) {
+        std::memcpy(sc.cam_to_world.m, d->sensor.to_world, sizeof(float) * 16);
+        // m_sample_to_camera (perspective.cpp:104-109) is supplied by the host
+        std::memcpy(sc.sample_to_camera.m, d->sensor.sample_to_camera, sizeof(float) * 16);
+    }
+    if (d->sensor.film_width != 1 || d->sensor.film_height != 1) {
+        g_err = "only 1x1 films are supported";
+        delete h;
+        return BF_ERR_UNSUPPORTED;
+    }
+    build_bvh(sc);
+    *out = h;
+    return BF_OK;
+}
+
+bf_status bfo_scene_destroy(bfo_scene *s) {
+    delete s;
+    return BF_OK;
+}
+
+uint32_t bfo_launch_channels(const bf_launch *lp) { return launch_channels(*lp); }
+
+/* rng_mode 0: per-path streams seed(base + path_index) (parallelisable;
+ *             this is what the HIP path implements)
+ * rng_mode 1: reference-literal single stream — sampler->seed(block_id *
+ *             pixel_count + i) once per pixel, spp samples drawn in sequence
+ *             (integrator.cpp:219-231); serial by construction. */
+bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int n_threads, float *hist_out,
+                     bf_path_record *records_out, bf_stats *stats_out) {
+    if (!s || !lp || !hist_out) return BF_ERR_INVALID;
+    if (lp->mode == BF_MODE_RECEIVE_RAW) {
+        g_err = "receive mode: use bfo_receive";
+        return BF_ERR_UNSUPPORTED;
+    }
+    const OScene &sc = s->sc;
+    const uint32_t nchan = launch_channels(*lp);
+    if (rng_mode == 1) n_threads = 1;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::vector<double>> th_hist(n_threads, std::vector<double>(nchan, 0.0));
+    std::vector<bf_stats> th_stats(n_threads);
+    for (auto &t : th_stats) std::memset(&t, 0, sizeof(t));
+    sc.n_nodes = 0;
+    sc.n_tris = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int tid) {
+        uint64_t lo = lp->n_paths * tid / n_threads, hi = lp->n_paths * (tid + 1) / n_threads;
+        Sampler smp;
+        if (rng_mode == 1) smp.rng.seed(lp->seed + 0);
+        for (uint64_t i = lo; i < hi; ++i) {
+            if (rng_mode == 0) smp.rng.seed(lp->seed + lp->path_offset + i);
+            SampleOut o = render_sample(sc, *lp, smp, th_hist[tid].data());
+            bf_stats &st = th_stats[tid];
+            st.n_paths++;
+            st.n_rays_closest += o.pr.n_closest;
+            st.n_rays_shadow += o.pr.n_shadow;
+            st.n_bounces += o.pr.n_bounces;
+            if (!o.put) st.n_invalid++;
+            if (records_out) {
+                records_out[i].L = o.L;
+                records_out[i].aux = o.pr.aux;
+                records_out[i].valid = o.pr.valid;
+                records_out[i].n_rays = o.pr.n_closest + o.pr.n_shadow;
+            }
+        }
+    };
+    if (n_threads == 1)
+        work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    for (uint32_t k = 0; k < nchan; ++k) {
+        double acc = 0;
+        for (int t = 0; t < n_threads; ++t) acc += th_hist[t][k];
+        hist_out[k] = (float) acc;
+    }
+    if (stats_out) {
+        std::memset(stats_out, 0, sizeof(*stats_out));
+        for (auto &st : th_stats) {
+            stats_out->n_paths += st.n_paths;
+            stats_out->n_rays_closest += st.n_rays_closest;
+            stats_out->n_rays_shadow += st.n_rays_shadow;
+            stats_out->n_bounces += st.n_bounces;
+            stats_out->n_invalid += st.n_invalid;
+        }
+        stats_out->n_nodes_visited = sc.n_nodes;
+        stats_out->n_tris_tested = sc.n_tris;
+        stats_out->kernel_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    }
+    return BF_OK;
+}
+
+bf_status bfo_trace_closest(const bfo_scene *s, uint64_t n, const float *rays, float *out_t, uint32_t *out_prim,
+                            uint32_t *out_shape, float *out_uv) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float *r = rays + 8 * i;
+        Ray ray;
+        ray.o = {r[0], r[1], r[2]};
+        ray.mint = r[3];
+        ray.d = {r[4], r[5], r[6]};
+        ray.maxt = r[7];
+        ray.time = 0;
+        Hit h;
+        traverse<false>(s->sc, ray, h);
+        if (out_t) out_t[i] = h.t;
+        if (out_prim) out_prim[i] = h.valid() ? h.prim : 0xffffffffu;
+        if (out_shape) out_shape[i] = h.valid() ? h.shape : 0xffffffffu;
+        if (out_uv) {
+            out_uv[2 * i] = h.u;
+            out_uv[2 * i + 1] = h.v;
+        }
+    }
+    return BF_OK;
+}
+bf_status bfo_trace_any(const bfo_scene *s, uint64_t n, const float *rays, uint8_t *out_hit) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float *r = rays + 8 * i;
+        Ray ray;
+        ray.o = {r[0], r[1], r[2]};
+        ray.mint = r[3];
+        ray.d = {r[4], r[5], r[6]};
+        ray.maxt = r[7];
+        ray.time = 0;
+        Hit h;
+        out_hit[i] = traverse<true>(s->sc, ray, h) ? 1 : 0;
+    }
+    return BF_OK;
+}
+
+/* full SurfaceInteraction for one ray (known-answer tests: test_mesh.py,
+ * test_rectangle.py).  out[0..]: t, p.xyz, n.xyz, sh_n.xyz, sh_s.xyz,
+ * sh_t.xyz, wi.xyz, prim_uv.xy, prim, shape  (21 floats) */
+bf_status bfo_ray_intersect_full(const bfo_scene *s, const float *r, float *out) {
+    Ray ray;
+    ray.o = {r[0], r[1], r[2]};
+    ray.mint = r[3];
+    ray.d = {r[4], r[5], r[6]};
+    ray.maxt = r[7];
+    ray.time = 0;
+    Hit h;
+    traverse<false>(s->sc, ray, h);
+    SI si = make_si(s->sc, ray, h);
+    float o[21] = {si.t, si.p.x, si.p.y, si.p.z, si.n.x, si.n.y, si.n.z, si.sh.n.x, si.sh.n.y, si.sh.n.z,
+                   si.sh.s.x, si.sh.s.y, si.sh.s.z, si.sh.t.x, si.sh.t.y, si.sh.t.z, si.wi.x, si.wi.y, si.wi.z, h.u, h.v};
+    std::memcpy(out, o, sizeof(o));
+    return BF_OK;
+}
+
+/* ---- unit-level entry points for the known-answer tests ------------------ */
+float bfo_tea_float32(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t u = (tea32(v0, v1, rounds, nullptr) >> 9) | 0x3f800000u;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f - 1.f;
+}
+double bfo_tea_float64(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t a;
+    uint32_t b = tea32(v0, v1, rounds, &a);
+    uint64_t u = (((uint64_t) a + ((uint64_t) b << 32)) >> 12) | 0x3ff0000000000000ULL;   // random.h:115
+    double d;
+    std::memcpy(&d, &u, 8);
+    return d - 1.0;
+}
+void bfo_pcg32_u32(uint64_t initstate, uint64_t initseq, int seeded, uint32_t n, uint32_t *out) {
+    PCG32 r;
+    if (seeded)
+        r.seed(initstate, initseq);
+    else {
+        r.state = PCG32_DEFAULT_STATE;
+        r.inc = PCG32_DEFAULT_STREAM;
+    }
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.next_u32();
+}
+void bfo_sampler_floats(uint64_t seed, uint32_t n, float *out) {
+    PCG32 r;
+    r.seed(seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.next_float();
+}
+void bfo_square_to_uniform_disk_concentric(float x, float y, float *o) { square_to_uniform_disk_concentric(x, y, o[0], o[1]); }
+void bfo_square_to_cosine_hemisphere(float x, float y, float *o) {
+    V3 v = square_to_cosine_hemisphere(x, y);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+}
+void bfo_square_to_uniform_cone(float x, float y, float c, float *o) {
+    V3 v = square_to_uniform_cone(x, y, c);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z;
+}
+void bfo_coordinate_system(const float *n, float *s, float *t) {
+    V3 a, b;
+    coordinate_system(V3{n[0], n[1], n[2]}, a, b);
+    s[0] = a.x; s[1] = a.y; s[2] = a.z;
+    t[0] = b.x; t[1] = b.y; t[2] = b.z;
+}
+float bfo_bsdf_eval(const bf_material *m, const float *wi, const float *wo) {
+    return bsdf_eval(*m, V3{wi[0], wi[1], wi[2]}, V3{wo[0], wo[1], wo[2]});
+}
+float bfo_bsdf_pdf(const bf_material *m, const float *wi, const float *wo) {
+    return bsdf_pdf(*m, V3{wi[0], wi[1], wi[2]}, V3{wo[0], wo[1], wo[2]});
+}
+float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x, float s2y, float *wo, float *pdf) {
+    BSDFSample bs;
+    float w = bsdf_sample(*m, V3{wi[0], wi[1], wi[2]}, s1, s2x, s2y, bs);
+    wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z;
+    *pdf = bs.pdf;
+    return w;
+}
+float bfo_erfinv(float x) { return erfinv_giles(x); }
+float bfo_rect_area(const bfo_scene *s, uint32_t rect) { return 1.f / s->sc.rects[rect].inv_area; }
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""Pin the CPU oracle against every known answer the reference's own tests
+hold for the building blocks of the hot path.  Each test names
+the reference test file:line the expected values come from."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from beifong_amd import capi, meshgen, scenes
+from beifong_amd.scenedesc import SceneDesc, Transform4f
+from tests.oracle_lib import OracleScene
+
+f32 = np.float32
+
+
+def test_tea_float32(oracle):
+    # src/libcore/tests/test_random.py:6-16
+    exp = {(1, 1): 0.5424730777740479, (1, 2): 0.5079904794692993, (1, 3): 0.4171961545944214,
+           (1, 4): 0.008385419845581055, (1, 5): 0.8085528612136841, (2, 1): 0.6939879655838013,
+           (3, 1): 0.6978365182876587, (4, 1): 0.4897364377975464}
+    for (a, b), v in exp.items():
+        assert oracle.bfo_tea_float32(a, b, 4) == f32(v)
+
+
+def test_tea_float64(oracle):
+    # src/libcore/tests/test_random.py:19-29
+    exp = {(1, 1): 0.5424730799533735, (1, 2): 0.5079905082233922, (1, 3): 0.4171962610608142,
+           (1, 4): 0.008385529523330604, (1, 5): 0.80855288317879, (2, 1): 0.6939880404156831,
+           (3, 1): 0.6978365636630994, (4, 1): 0.48973647949223253}
+    for (a, b), v in exp.items():
+        assert oracle.bfo_tea_float64(a, b, 4) == v
+
+
+def test_pcg32_reference_vectors(oracle):
+    # O'Neill's pcg32-demo published output for seed(42, 54) (the algorithm
+    # enoki::PCG32 implements; src/samplers/tests/test_independent.py:30-36
+    # only pins "sampler == enoki PCG32").
+    out = np.zeros(6, np.uint32)
+    oracle.bfo_pcg32_u32(42, 54, 1, 6, out.ctypes.data_as(C.c_void_p))
+    assert [hex(x) for x in out] == ["0xa15c02b7", "0x7b47f409", "0xba1d3330", "0x83d2f293", "0xbfa4784b", "0xcbed606e"]
+
+
+def test_sampler_float_range(oracle):
+    out = np.zeros(4096, f32)
+    oracle.bfo_sampler_floats(0, 4096, out.ctypes.data_as(C.c_void_p))
+    assert out.min() >= 0.0 and out.max() < 1.0
+    assert abs(out.mean() - 0.5) < 0.02
+
+
+def test_warp_fixed_points(oracle):
+    # src/libcore/tests/test_warp.py:68-78 (concentric disk), :142-166 (cosine hemisphere, cone)
+    o2 = np.zeros(2, f32)
+    p = o2.ctypes.data_as(C.c_void_p)
+    oracle.bfo_square_to_uniform_disk_concentric(0, 0, p)
+    assert np.allclose(o2 * math.sqrt(2), [-1, -1], atol=1e-6)
+    oracle.bfo_square_to_uniform_disk_concentric(0.5, .5, p)
+    assert np.allclose(o2, [0, 0], atol=1e-6)
+    oracle.bfo_square_to_uniform_disk_concentric(1, 1, p)
+    assert np.allclose(o2 * math.sqrt(2), [1, 1], atol=1e-6)
+    o3 = np.zeros(3, f32)
+    p3 = o3.ctypes.data_as(C.c_void_p)
+    oracle.bfo_square_to_cosine_hemisphere(0.5, 0.5, p3)
+    assert np.allclose(o3, [0, 0, 1], atol=1e-6)
+    oracle.bfo_square_to_cosine_hemisphere(0.5, 0, p3)
+    assert np.allclose(o3, [0, -1, 0], atol=1e-6)
+    oracle.bfo_square_to_uniform_cone(0.5, 0.5, 1.0, p3)
+    assert np.allclose(o3, [0, 0, 1], atol=1e-6)
+    oracle.bfo_square_to_uniform_cone(0.5, 0, 1.0, p3)
+    assert np.allclose(o3, [0, 0, 1], atol=1e-6)
+    oracle.bfo_square_to_uniform_cone(0.5, 0, 0.0, p3)
+    assert np.allclose(o3, [0, -1, 0], atol=1e-6)
+
+
+def test_coordinate_system_orthonormal(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        n = rng.standard_normal(3)
+        n = (n / np.linalg.norm(n)).astype(f32)
+        s, t = np.zeros(3, f32), np.zeros(3, f32)
+        oracle.bfo_coordinate_system(n.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+        assert abs(np.dot(s, t)) < 1e-6 and abs(np.dot(s, n)) < 1e-6 and abs(np.dot(t, n)) < 1e-6
+        assert np.allclose(np.cross(s, t), n, atol=1e-6)
+
+
+def _rect_scene(to_world):
+    sd = SceneDesc()
+    m = sd.add_diffuse(0.5)
+    sd.add_rectangle(to_world, m)
+    sd.set_perspective(Transform4f.translate([0, 0, 0]))
+    return sd.finalize()
+
+
+def test_rectangle_area_and_hits():
+    # src/shapes/tests/test_rectangle.py:7-13 (area 4), :37-63 (7 of 15 rays hit)
+    o = OracleScene(_rect_scene(Transform4f()))
+    assert np.isclose(o.lib.bfo_rect_area(o.handle, 0), 4.0)
+    o = OracleScene(_rect_scene(Transform4f.scale([2.0, 0.5, 1.0])))
+    coords = np.linspace(-1, 1, 15, dtype=f32)
+    rays = np.array([[a, a, 5, capi_eps(), 0, 0, -1, np.inf] for a in coords], f32)
+    t, prim, shape, uv = o.trace_closest(rays)
+    hit = o.trace_any(rays)
+    valid = np.isfinite(t)
+    assert np.array_equal(valid, np.abs(coords) <= 0.5)
+    assert np.array_equal(hit.astype(bool), valid)
+    assert valid.sum() == 7
+    assert np.allclose(t[valid], 5.0)
+
+
+def capi_eps():
+    return f32(1500 * 2.0 ** -24)
+
+
+def test_rectangle_sheared_areas():
+    # src/shapes/tests/test_rectangle.py:94-126
+    for m, area in [(np.diag([2, 2, 1, 1]), 16.0),
+                    ([[1, 0, 0, 0], [0, 1, 0, 0], [1, 0, 1, 0], [0, 0, 0, 1]], 4 * math.sqrt(2)),
+                    ([[1, 1, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], 4.0)]:
+        o = OracleScene(_rect_scene(Transform4f(np.array(m, f32))))
+        assert np.isclose(o.lib.bfo_rect_area(o.handle, 0), area)
+
+
+def test_mesh_rectangle_obj_known_answers():
+    # src/librender/tests/test_mesh.py:257-298 on a synthesised rectangle.obj
+    v, f = meshgen.rectangle_obj()
+    o = OracleScene(scenes.single_mesh(v, f))
+    r = o.intersect_full([-0.3, -0.3, -10, capi_eps(), 0, 0, 1, np.inf])
+    t, prim, _, uv = o.trace_closest([[-0.3, -0.3, -10, capi_eps(), 0, 0, 1, np.inf]])
+    assert np.isclose(r["t"], 10) and prim[0] == 0
+    assert np.allclose(r["prim_uv"], [0.35, 0.3], atol=1e-6)
+    assert np.allclose(r["p"], [-0.3, -0.3, 0.0], atol=1e-6)
+    r = o.intersect_full([0.3, 0.3, -10, capi_eps(), 0, 0, 1, np.inf])
+    t, prim, _, uv = o.trace_closest([[0.3, 0.3, -10, capi_eps(), 0, 0, 1, np.inf]])
+    assert np.isclose(r["t"], 10) and prim[0] == 1
+    assert np.allclose(r["prim_uv"], [0.3, 0.35], atol=1e-6)
+    assert np.allclose(r["p"], [0.3, 0.3, 0.0], atol=1e-6)
+    assert np.allclose(r["n"], [0, 0, 1], atol=1e-6)
+    assert np.allclose(r["wi"], [0, 0, -1], atol=1e-6)
+
+
+@pytest.mark.parametrize("brute", [False, True])
+def test_stairs_depth(brute):
+    # src/librender/tests/test_kdtrees.py:25-57: t = 2 - floor(y*n_steps)/n_steps,
+    # shadow ray == closest valid == naive
+    n_steps = 20
+    v, f = meshgen.stairs(n_steps)
+    o = OracleScene(scenes.single_mesh(v, f), brute_force=brute)
+    n = 128
+    inv_n = 1.0 / (n - 1)
+    rays, exp = [], []
+    for x in range(n - 1):
+        for y in range(n - 1):
+            rays.append([x * inv_n, y * inv_n, 2, 0, 0, 0, -1, 100])
+            exp.append(2.0 - math.floor((y * inv_n) * n_steps) / n_steps)
+    rays = np.array(rays, f32)
+    t, prim, shape, uv = o.trace_closest(rays)
+    assert np.all(o.trace_any(rays) == 1)
+    assert np.allclose(t, np.array(exp, f32), atol=1e-6)
+
+
+def test_bvh_equals_brute_force_random_soup():
+    v, f = meshgen.triangle_soup(2000, seed=7)
+    sd = scenes.single_mesh(v, f)
+    a, b = OracleScene(sd), OracleScene(sd, brute_force=True)
+    rng = np.random.default_rng(11)
+    n = 4000
+    o = rng.uniform(-1.5, 1.5, (n, 3))
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, np.full((n, 1), capi_eps()), d, np.full((n, 1), np.inf)], 1).astype(f32)
+    ta, pa, sa, ua = a.trace_closest(rays)
+    tb, pb, sb, ub = b.trace_closest(rays)
+    assert np.array_equal(ta, tb) and np.array_equal(pa, pb) and np.array_equal(ua, ub)
+    assert np.array_equal(a.trace_any(rays), b.trace_any(rays))
+    assert np.isfinite(ta).sum() > 500
+
+
+def _mat(**kw):
+    sd = SceneDesc()
+    if kw.pop("kind", "diffuse") == "diffuse":
+        sd.add_diffuse(**kw)
+    else:
+        sd.add_roughconductor(**kw)
+    return sd.materials[0]
+
+
+def test_diffuse_eval_pdf(oracle):
+    # src/bsdfs/tests/test_diffuse.py:16-39: pdf = cos/pi, eval = 0.5 cos/pi
+    m = _mat(reflectance=0.5)
+    wi = np.array([0, 0, 1], f32)
+    for i in range(20):
+        theta = i / 19.0 * (math.pi / 2)
+        wo = np.array([math.sin(theta), 0, math.cos(theta)], f32)
+        pdf = oracle.bfo_bsdf_pdf(C.byref(m), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+        ev = oracle.bfo_bsdf_eval(C.byref(m), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+        if wo[2] > 0:
+            assert np.isclose(pdf, wo[2] / math.pi, atol=1e-7)
+            assert np.isclose(ev, 0.5 * wo[2] / math.pi, atol=1e-7)
+        else:
+            assert pdf == 0 and ev == 0
+
+
+def test_twosided_pdf(oracle):
+    # src/bsdfs/tests/test_twosided.py:43-60
+    m = _mat(reflectance=0.5, twosided=True)
+    wi = np.array([0, 0, 1], f32)
+    p = lambda wo: oracle.bfo_bsdf_pdf(C.byref(m), wi.ctypes.data_as(C.c_void_p), np.array(wo, f32).ctypes.data_as(C.c_void_p))
+    assert np.isclose(p([0, 0, 1]), 1 / math.pi)
+    assert p([0, 0, -1]) == 0.0
+    # back side mirrors the front side
+    wi = np.array([0, 0, -1], f32)
+    assert np.isclose(p([0, 0, -1]), 1 / math.pi)
+    assert p([0, 0, 1]) == 0.0
+
+
+@pytest.mark.parametrize("kind,kw", [("diffuse", dict(reflectance=0.7)),
+                                     ("conductor", dict(alpha=0.1)),
+                                     ("conductor", dict(alpha=0.3, distribution="ggx")),
+                                     ("conductor", dict(alpha=0.25, sample_visible=False))])
+def test_bsdf_sample_consistent_with_eval_pdf(oracle, kind, kw):
+    """chi2-style consistency (src/python/python/chi2.py in spirit): the sample
+    weight equals eval/pdf and pdf() agrees with the sampled density."""
+    m = _mat(kind=kind, **kw)
+    rng = np.random.default_rng(5)
+    wi = np.array([0.3, -0.2, 0.9], f32)
+    wi /= np.linalg.norm(wi)
+    n_ok = 0
+    for _ in range(300):
+        u = rng.uniform(0.01, 0.99, 3).astype(f32)
+        wo, pdf = np.zeros(3, f32), C.c_float()
+        w = oracle.bfo_bsdf_sample(C.byref(m), wi.ctypes.data_as(C.c_void_p), u[0], u[1], u[2],
+                                   wo.ctypes.data_as(C.c_void_p), C.byref(pdf))
+        if w == 0:
+            continue
+        ev = oracle.bfo_bsdf_eval(C.byref(m), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+        pd = oracle.bfo_bsdf_pdf(C.byref(m), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+        assert np.isclose(pd, pdf.value, rtol=2e-3), (pd, pdf.value)
+        assert np.isclose(w, ev / pd, rtol=5e-3), (w, ev / pd)
+        assert abs(np.linalg.norm(wo) - 1) < 1e-4
+        n_ok += 1
+    assert n_ok > 200
+
+
+def test_conductor_default_fresnel_is_one(oracle):
+    # roughconductor.cpp:149-150 defaults eta=0, k=1 => F == 1
+    m = _mat(kind="conductor", alpha=0.1)
+    mr = _mat(kind="conductor", alpha=0.1, specular_reflectance=0.5)
+    wi = np.array([0, 0.6, 0.8], f32)
+    wo = np.array([0, -0.6, 0.8], f32)
+    a = oracle.bfo_bsdf_eval(C.byref(m), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+    b = oracle.bfo_bsdf_eval(C.byref(mr), wi.ctypes.data_as(C.c_void_p), wo.ctypes.data_as(C.c_void_p))
+    assert a > 0 and np.isclose(b, 0.5 * a, rtol=1e-6)
+
+
+def test_erfinv(oracle):
+    from scipy.special import erfinv
+    for x in np.linspace(-0.999, 0.999, 41):
+        assert np.isclose(oracle.bfo_erfinv(f32(x)), erfinv(x), rtol=2e-6, atol=1e-6)
