@@ -1,0 +1,480 @@
+// C ABI of libbeifong_hip.so (include/beifong_hip.h): scene flattening, BVH
+// build, device upload and kernel launches.  Plain pointers and sizes in,
+// integer status out; no exceptions cross the boundary.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bf_bvh.h"
+#include "bf_device.h"
+
+extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunch *lp, float *g_hist, bf_path_record *records,
+                                        unsigned long long *counters, int stats, unsigned grid, size_t lds_bytes,
+                                        hipStream_t stream);
+extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
+                                       uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
+                                       hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_err;
+
+bf_status fail(bf_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(BF_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T> bf_status upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned, uint64_t &bytes) {
+    *out = nullptr;
+    if (v.empty()) return BF_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+    owned.push_back(p);
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    bytes += v.size() * sizeof(T);
+    *out = reinterpret_cast<const T *>(p);
+    return BF_OK;
+}
+
+void m34(const float *m16, float *out12) { std::memcpy(out12, m16, 12 * sizeof(float)); }
+
+inline float fmaf_(float a, float b, float c) { return std::fmaf(a, b, c); }
+struct V3 {
+    float x, y, z;
+};
+// same conventions as the device code (bf_device_math.h)
+inline V3 xf_vector(const float *m, V3 v) {
+    V3 r = {m[0] * v.x, m[4] * v.x, m[8] * v.x};
+    r = {fmaf_(m[1], v.y, r.x), fmaf_(m[5], v.y, r.y), fmaf_(m[9], v.y, r.z)};
+    r = {fmaf_(m[2], v.z, r.x), fmaf_(m[6], v.z, r.y), fmaf_(m[10], v.z, r.z)};
+    return r;
+}
+inline float dot(V3 a, V3 b) { return fmaf_(a.z, b.z, fmaf_(a.y, b.y, a.x * b.x)); }
+inline V3 cross(V3 a, V3 b) {
+    return {fmaf_(a.y, b.z, -(a.z * b.y)), fmaf_(a.z, b.x, -(a.x * b.z)), fmaf_(a.x, b.y, -(a.y * b.x))};
+}
+inline V3 normalize(V3 a) {
+    float s = 1.f / std::sqrt(dot(a, a));
+    return {a.x * s, a.y * s, a.z * s};
+}
+
+}  // namespace
+
+struct bf_scene {
+    bfd::DScene d;
+    std::vector<void *> owned;
+    bf_scene_info info;
+    int device = 0;
+    int n_cus = 256;
+    // per-scene scratch for bf_render_device (counters), allocated once
+    unsigned long long *counters = nullptr;
+};
+
+extern "C" {
+
+int bf_version(void) { return BF_ABI_VERSION; }
+const char *bf_last_error(void) { return g_err.c_str(); }
+
+int bf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+bf_status bf_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return BF_OK;
+}
+
+uint32_t bf_launch_channels(const bf_launch *lp) {
+    if (!lp) return 0;
+    switch (lp->mode) {
+        case BF_MODE_PATH: return 5;
+        case BF_MODE_RANGE: return 5 + lp->bins;
+        case BF_MODE_TIME: return 5 + 3 * lp->bins;
+        case BF_MODE_RECEIVE_RAW: return 3;
+    }
+    return 0;
+}
+
+bf_status bf_scene_destroy(bf_scene *s) {
+    if (!s) return BF_OK;
+    for (void *p : s->owned) (void) hipFree(p);
+    if (s->counters) (void) hipFree(s->counters);
+    delete s;
+    return BF_OK;
+}
+
+bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
+    if (!desc || !out) return fail(BF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
+    if (desc->n_materials == 0 || !desc->materials) return fail(BF_ERR_INVALID, "at least one material is required");
+    if (desc->sensor.film_width != 1 || desc->sensor.film_height != 1)
+        return fail(BF_ERR_UNSUPPORTED, "only 1x1 films are supported (all radar scenes; fluxmeter.cpp:51-52)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(BF_ERR_DEVICE, "no HIP device available: the HIP path has no CPU fallback");
+
+    std::vector<bfd::DShape> shapes;
+    std::vector<bfd::DRect> rects;
+    std::vector<bf::BuildTri> btris;
+    struct TriMeta {
+        uint32_t prim, shape;
+        const float *n0, *n1, *n2;
+    };
+    std::vector<TriMeta> meta;
+    bool any_normals = false;
+    uint32_t prim = 0;
+    for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+        const bf_shape &s = desc->shapes[i];
+        if (s.material >= desc->n_materials) return fail(BF_ERR_INVALID, "shape %u: material index out of range", i);
+        if (s.emitter >= (int32_t) desc->n_emitters) return fail(BF_ERR_INVALID, "shape %u: emitter index out of range", i);
+        bfd::DShape ds;
+        ds.type = s.type;
+        ds.material = s.material;
+        ds.emitter = s.emitter;
+        ds.rect = -1;
+        if (s.type == BF_SHAPE_RECTANGLE) {
+            bfd::DRect rc;
+            m34(s.to_world, rc.to_world);
+            m34(s.to_object, rc.to_object);
+            // Rectangle::update — src/shapes/rectangle.cpp:83-92
+            V3 dp_du = xf_vector(rc.to_world, V3{2.f, 0.f, 0.f});
+            V3 dp_dv = xf_vector(rc.to_world, V3{0.f, 2.f, 0.f});
+            V3 n = normalize(V3{s.to_object[8], s.to_object[9], s.to_object[10]});   // inverse-transpose * (0,0,1)
+            rc.s[0] = dp_du.x; rc.s[1] = dp_du.y; rc.s[2] = dp_du.z;
+            rc.t[0] = dp_dv.x; rc.t[1] = dp_dv.y; rc.t[2] = dp_dv.z;
+            rc.n[0] = n.x; rc.n[1] = n.y; rc.n[2] = n.z;
+            V3 c = cross(dp_du, dp_dv);
+            float area = std::sqrt(dot(c, c));
+            if (!(area > 0.f) || !std::isfinite(area)) return fail(BF_ERR_INVALID, "shape %u: degenerate rectangle", i);
+            rc.inv_area = 1.f / area;
+            rc.shape = i;
+            rc.prim = prim;
+            ds.rect = (int32_t) rects.size();
+            rects.push_back(rc);
+            prim += 1;
+        } else if (s.type == BF_SHAPE_MESH) {
+            if (s.n_faces && (!s.positions || !s.indices)) return fail(BF_ERR_INVALID, "shape %u: null mesh arrays", i);
+            for (uint32_t f = 0; f < s.n_faces; ++f) {
+                uint32_t i0 = s.indices[3 * f], i1 = s.indices[3 * f + 1], i2 = s.indices[3 * f + 2];
+                if (i0 >= s.n_vertices || i1 >= s.n_vertices || i2 >= s.n_vertices)
+                    return fail(BF_ERR_INVALID, "shape %u face %u: vertex index out of range", i, f);
+                bf::BuildTri t;
+                std::memcpy(t.p0, s.positions + 3 * i0, 12);
+                std::memcpy(t.p1, s.positions + 3 * i1, 12);
+                std::memcpy(t.p2, s.positions + 3 * i2, 12);
+                btris.push_back(t);
+                TriMeta m{prim + f, i, nullptr, nullptr, nullptr};
+                if (s.normals) {
+                    m.n0 = s.normals + 3 * i0;
+                    m.n1 = s.normals + 3 * i1;
+                    m.n2 = s.normals + 3 * i2;
+                    any_normals = true;
+                }
+                meta.push_back(m);
+            }
+            prim += s.n_faces;
+        } else {
+            return fail(BF_ERR_UNSUPPORTED, "shape %u: unknown type %u", i, s.type);
+        }
+        shapes.push_back(ds);
+    }
+    if (btris.size() >= (1u << 28)) return fail(BF_ERR_UNSUPPORTED, "too many triangles");
+
+    std::vector<bfd::DEmitter> emitters;
+    for (uint32_t i = 0; i < desc->n_emitters; ++i) {
+        const bf_emitter &e = desc->emitters[i];
+        bfd::DEmitter de;
+        std::memset(&de, 0, sizeof(de));
+        de.type = e.type;
+        de.rect = -1;
+        de.radiance = e.radiance;
+        if (e.type == BF_EMITTER_SPOT) {
+            m34(e.to_world, de.to_world);
+            m34(e.to_object, de.to_object);
+            // SpotLight ctor — src/emitters/spot.cpp:83-93
+            const float pi = 3.14159265358979323846f;
+            de.cutoff = e.cutoff_angle_deg * (pi / 180.f);
+            de.beam = e.beam_width_deg * (pi / 180.f);
+            de.inv_transition = 1.0f / (de.cutoff - de.beam);
+            de.cos_cutoff = (float) std::cos((double) de.cutoff);
+            de.cos_beam = (float) std::cos((double) de.beam);
+        } else if (e.type == BF_EMITTER_AREA) {
+            if (e.shape < 0 || e.shape >= (int32_t) desc->n_shapes || desc->shapes[e.shape].type != BF_SHAPE_RECTANGLE)
+                return fail(BF_ERR_UNSUPPORTED, "emitter %u: area emitters must sit on a rectangle", i);
+            de.rect = shapes[e.shape].rect;
+        } else {
+            return fail(BF_ERR_UNSUPPORTED, "emitter %u: type %u not supported by this build", i, e.type);
+        }
+        emitters.push_back(de);
+    }
+
+    bf_scene *sc = new (std::nothrow) bf_scene();
+    if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
+    std::memset(&sc->d, 0, sizeof(sc->d));
+    std::memset(&sc->info, 0, sizeof(sc->info));
+    bfd::DSensor &sen = sc->d.sensor;
+    sen.type = desc->sensor.type;
+    sen.rect = -1;
+    if (desc->sensor.type == BF_SENSOR_FLUXMETER) {
+        int32_t sh = desc->sensor.shape;
+        if (sh < 0 || sh >= (int32_t) desc->n_shapes || desc->shapes[sh].type != BF_SHAPE_RECTANGLE) {
+            delete sc;
+            return fail(BF_ERR_UNSUPPORTED, "fluxmeter must sit on a rectangle");
+        }
+        sen.rect = shapes[sh].rect;
+    } else if (desc->sensor.type == BF_SENSOR_PERSPECTIVE) {
+        m34(desc->sensor.to_world, sen.to_world);
+        std::memcpy(sen.sample_to_camera, desc->sensor.sample_to_camera, 16 * sizeof(float));
+    } else {
+        delete sc;
+        return fail(BF_ERR_UNSUPPORTED, "sensor type %u not supported by this build", desc->sensor.type);
+    }
+    sen.near_clip = desc->sensor.near_clip;
+    sen.far_clip = desc->sensor.far_clip;
+    sen.shutter_open = desc->sensor.shutter_open;
+    sen.shutter_open_time = desc->sensor.shutter_open_time;
+
+    // BVH over all mesh triangles; triangles stored in leaf order
+    bf::BVH bvh;
+    bf::build_bvh(btris, bvh);
+    std::vector<float4> tri_data(3 * btris.size()), nrm_data;
+    if (any_normals) nrm_data.resize(3 * btris.size());
+    for (size_t slot = 0; slot < btris.size(); ++slot) {
+        uint32_t src = bvh.order[slot];
+        const bf::BuildTri &t = btris[src];
+        const TriMeta &m = meta[src];
+        uint32_t has_n = m.n0 ? 1u : 0u;
+        float w0, w1, w2;
+        std::memcpy(&w0, &m.prim, 4);
+        std::memcpy(&w1, &m.shape, 4);
+        std::memcpy(&w2, &has_n, 4);
+        tri_data[3 * slot + 0] = make_float4(t.p0[0], t.p0[1], t.p0[2], w0);
+        tri_data[3 * slot + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], w1);
+        tri_data[3 * slot + 2] = make_float4(t.p2[0], t.p2[1], t.p2[2], w2);
+        if (any_normals) {
+            if (m.n0) {
+                nrm_data[3 * slot + 0] = make_float4(m.n0[0], m.n0[1], m.n0[2], 0.f);
+                nrm_data[3 * slot + 1] = make_float4(m.n1[0], m.n1[1], m.n1[2], 0.f);
+                nrm_data[3 * slot + 2] = make_float4(m.n2[0], m.n2[1], m.n2[2], 0.f);
+            } else {
+                nrm_data[3 * slot + 0] = nrm_data[3 * slot + 1] = nrm_data[3 * slot + 2] = make_float4(0, 0, 0, 0);
+            }
+        }
+    }
+    std::vector<float4> node_data(4 * bvh.nodes.size());
+    if (!bvh.nodes.empty()) std::memcpy(node_data.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(bf::Node));
+    std::vector<bf_material> mats(desc->materials, desc->materials + desc->n_materials);
+
+    uint64_t bytes = 0;
+    bf_status st;
+#define UP(vec, field)                                              \
+    if ((st = upload(vec, &sc->d.field, sc->owned, bytes)) != BF_OK) { \
+        bf_scene_destroy(sc);                                       \
+        return st;                                                  \
+    }
+    UP(node_data, nodes);
+    UP(tri_data, tris);
+    UP(nrm_data, normals);
+    UP(rects, rects);
+    UP(shapes, shapes);
+    UP(mats, materials);
+    UP(emitters, emitters);
+#undef UP
+    sc->d.n_tris = (uint32_t) btris.size();
+    sc->d.n_rects = (uint32_t) rects.size();
+    sc->d.n_emitters = (uint32_t) emitters.size();
+    sc->d.n_nodes = (uint32_t) bvh.nodes.size();
+    sc->d.root = bvh.root_child;
+
+    hipError_t e = hipMalloc((void **) &sc->counters, sizeof(unsigned long long) * bfd::CTR_COUNT);
+    if (e != hipSuccess) {
+        bf_scene_destroy(sc);
+        return fail(BF_ERR_DEVICE, "hipMalloc(counters): %s", hipGetErrorString(e));
+    }
+    (void) hipGetDevice(&sc->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) sc->n_cus = prop.multiProcessorCount;
+
+    bf_scene_info &inf = sc->info;
+    inf.n_shapes = desc->n_shapes;
+    inf.n_rects = sc->d.n_rects;
+    inf.n_triangles = sc->d.n_tris;
+    inf.n_bvh_nodes = sc->d.n_nodes;
+    inf.node_bytes = (uint32_t) sizeof(bf::Node);
+    inf.tri_bytes = 48;
+    inf.device_bytes = bytes;
+    for (int k = 0; k < 3; ++k) {
+        inf.bbox_min[k] = bvh.lo[k];
+        inf.bbox_max[k] = bvh.hi[k];
+    }
+    *out = sc;
+    return BF_OK;
+}
+
+bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
+    if (!scene || !info) return fail(BF_ERR_INVALID, "null argument");
+    *info = scene->info;
+    return BF_OK;
+}
+
+bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
+                           void *stream_, bf_stats *stats_out) {
+    if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
+    if (launch->mode == BF_MODE_RECEIVE_RAW) return fail(BF_ERR_UNSUPPORTED, "receive mode is not built yet");
+    if (launch->mode > BF_MODE_RECEIVE_RAW) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);
+    if ((launch->mode == BF_MODE_RANGE || launch->mode == BF_MODE_TIME) && (launch->bins == 0 || !(launch->bin_width > 0.f)))
+        return fail(BF_ERR_INVALID, "range/time mode needs bins > 0 and bin_width > 0");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    bfd::DLaunch lp;
+    std::memset(&lp, 0, sizeof(lp));
+    lp.mode = launch->mode;
+    lp.color_mode = launch->color_mode;
+    lp.n_paths = launch->n_paths;
+    lp.path_offset = launch->path_offset;
+    lp.seed = launch->seed;
+    lp.max_depth = launch->max_depth;
+    lp.rr_depth = launch->rr_depth;
+    lp.bins = launch->bins;
+    lp.bin_width = launch->bin_width;
+    lp.time_c = launch->time_c;
+    lp.n_chan = bf_launch_channels(launch);
+    lp.lds_hist = (lp.n_chan <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
+    size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan : 0);
+    lds = (lds + 15) & ~size_t(15);
+
+    // persistent grid: enough workgroups to fill the chip, never more than the work
+    uint64_t want = (launch->n_paths + bfd::kBlock - 1) / bfd::kBlock;
+    unsigned blocks_per_cu = (unsigned) std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+    unsigned grid = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t) scene->n_cus * blocks_per_cu));
+
+    HIP_TRY(hipMemsetAsync(scene->counters, 0, sizeof(unsigned long long) * bfd::CTR_COUNT, stream));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats_out) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    if (launch->n_paths) {
+        HIP_TRY(bfk_launch_render(&scene->d, &lp, hist_dev, records_dev, scene->counters,
+                                  (launch->flags & BF_FLAG_STATS) ? 1 : 0, grid, lds, stream));
+    }
+    if (stats_out) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        unsigned long long c[bfd::CTR_COUNT];
+        HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
+        std::memset(stats_out, 0, sizeof(*stats_out));
+        stats_out->n_paths = launch->n_paths;
+        stats_out->n_rays_closest = c[bfd::CTR_CLOSEST];
+        stats_out->n_rays_shadow = c[bfd::CTR_SHADOW];
+        stats_out->n_nodes_visited = c[bfd::CTR_NODES];
+        stats_out->n_tris_tested = c[bfd::CTR_TRIS];
+        stats_out->n_invalid = c[bfd::CTR_INVALID];
+        stats_out->n_bounces = c[bfd::CTR_BOUNCES];
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        stats_out->kernel_ms = ms;
+        (void) hipEventDestroy(ev0);
+        (void) hipEventDestroy(ev1);
+    }
+    return BF_OK;
+}
+
+bf_status bf_render(const bf_scene *scene, const bf_launch *launch, float *hist_out, bf_path_record *records_out,
+                    bf_stats *stats_out) {
+    if (!scene || !launch || !hist_out) return fail(BF_ERR_INVALID, "null argument");
+    uint32_t nchan = bf_launch_channels(launch);
+    if (nchan == 0) return fail(BF_ERR_INVALID, "unknown mode");
+    float *d_hist = nullptr;
+    bf_path_record *d_rec = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_hist, nchan * sizeof(float)));
+    hipError_t e = hipMemset(d_hist, 0, nchan * sizeof(float));
+    if (e == hipSuccess && records_out && launch->n_paths)
+        e = hipMalloc((void **) &d_rec, launch->n_paths * sizeof(bf_path_record));
+    if (e != hipSuccess) {
+        (void) hipFree(d_hist);
+        return fail(BF_ERR_DEVICE, "bf_render: %s", hipGetErrorString(e));
+    }
+    bf_stats local;
+    bf_status st = bf_render_device(scene, launch, d_hist, d_rec, nullptr, stats_out ? stats_out : &local);
+    if (st == BF_OK) {
+        e = hipMemcpy(hist_out, d_hist, nchan * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && d_rec)
+            e = hipMemcpy(records_out, d_rec, launch->n_paths * sizeof(bf_path_record), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(BF_ERR_DEVICE, "bf_render copy back: %s", hipGetErrorString(e));
+    }
+    (void) hipFree(d_hist);
+    if (d_rec) (void) hipFree(d_rec);
+    return st;
+}
+
+static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *rays, int any_hit, float *out_t,
+                              uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit) {
+    if (!scene || (n && !rays)) return fail(BF_ERR_INVALID, "null argument");
+    if (n == 0) return BF_OK;
+    float *d_rays = nullptr, *d_t = nullptr, *d_uv = nullptr;
+    uint32_t *d_prim = nullptr, *d_shape = nullptr;
+    uint8_t *d_hit = nullptr;
+    std::vector<void *> tmp;
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) tmp.push_back(*p);
+        return e;
+    };
+    auto cleanup = [&]() {
+        for (void *p : tmp) (void) hipFree(p);
+    };
+    hipError_t e = alloc((void **) &d_rays, n * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && any_hit) e = alloc((void **) &d_hit, n);
+    if (e == hipSuccess && !any_hit) {
+        e = alloc((void **) &d_t, n * 4);
+        if (e == hipSuccess) e = alloc((void **) &d_prim, n * 4);
+        if (e == hipSuccess) e = alloc((void **) &d_shape, n * 4);
+        if (e == hipSuccess) e = alloc((void **) &d_uv, n * 8);
+    }
+    if (e == hipSuccess) e = bfk_launch_trace(&scene->d, n, d_rays, any_hit, d_t, d_prim, d_shape, d_uv, d_hit, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && any_hit && out_hit) e = hipMemcpy(out_hit, d_hit, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && !any_hit) {
+        if (out_t) e = hipMemcpy(out_t, d_t, n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_prim) e = hipMemcpy(out_prim, d_prim, n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_shape) e = hipMemcpy(out_shape, d_shape, n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_uv) e = hipMemcpy(out_uv, d_uv, n * 8, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(BF_ERR_DEVICE, "bf_trace: %s", hipGetErrorString(e));
+    return BF_OK;
+}
+
+bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays, float *out_t, uint32_t *out_prim,
+                           uint32_t *out_shape, float *out_uv) {
+    return trace_common(scene, n, rays, 0, out_t, out_prim, out_shape, out_uv, nullptr);
+}
+
+bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays, uint8_t *out_hit) {
+    return trace_common(scene, n, rays, 1, nullptr, nullptr, nullptr, nullptr, out_hit);
+}
+
+}  // extern "C"

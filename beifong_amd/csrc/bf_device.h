@@ -1,0 +1,81 @@
+// Device-resident scene layout shared by the host API (bf_api) and the
+// kernels (bf_kernels.hip).  Everything is read-only during a render.
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   nodes   : bf::Node[n_nodes]      64 B each, 16-B aligned, both child boxes
+//   tris    : float4[3 * n_tris]     48 B per triangle, BVH leaf order:
+//               q0 = (p0.xyz, bits(global prim index))
+//               q1 = (p1.xyz, bits(shape index))
+//               q2 = (p2.xyz, bits(has_normals))
+//   normals : float4[3 * n_tris]     only if some mesh carries vertex normals
+//   rects, shapes, materials, emitters : small tables (scenes hold a handful)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/beifong_hip.h"
+
+namespace bfd {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kStackDepth = 32;      // per-lane traversal stack entries in LDS
+constexpr int kMaxLdsHist = 12288;   // floats of LDS-privatised histogram (48 KiB)
+
+struct DRect {
+    float to_world[12];   // 3x4 row-major affine
+    float to_object[12];
+    float s[3], t[3], n[3];   // Rectangle::update frame (dp_du, dp_dv, normal)
+    float inv_area;
+    uint32_t shape;
+    uint32_t prim;        // global primitive index
+};
+
+struct DShape {
+    uint32_t type, material;
+    int32_t emitter;
+    int32_t rect;         // index into rects or -1
+};
+
+struct DEmitter {
+    uint32_t type;
+    int32_t rect;         // area types: rectangle index
+    float to_world[12], to_object[12];
+    float radiance, cutoff, beam, inv_transition, cos_cutoff, cos_beam;
+};
+
+struct DSensor {
+    uint32_t type;
+    int32_t rect;
+    float to_world[12];
+    float sample_to_camera[16];
+    float near_clip, far_clip, shutter_open, shutter_open_time;
+};
+
+struct DScene {
+    const float4 *nodes;      // 4 float4 per node
+    const float4 *tris;       // 3 float4 per triangle
+    const float4 *normals;    // 3 float4 per triangle or nullptr
+    const DRect *rects;
+    const DShape *shapes;
+    const bf_material *materials;
+    const DEmitter *emitters;
+    uint32_t n_tris, n_rects, n_emitters, n_nodes;
+    int32_t root;             // child reference of the BVH root
+    DSensor sensor;
+};
+
+struct DLaunch {
+    uint32_t mode, color_mode;
+    uint64_t n_paths, path_offset, seed;
+    int32_t max_depth, rr_depth;
+    uint32_t bins;
+    float bin_width, time_c;
+    uint32_t n_chan;
+    uint32_t lds_hist;        // 1: histogram privatised in LDS
+    uint32_t pad;
+};
+
+// device counters (uint64 each)
+enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_COUNT };
+
+}  // namespace bfd
