@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s + HBM-roofline fraction of the radar path-tracing hot path.
+
+Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 the driver launches one rank per GPU through torch.distributed.run
+(RCCL).  A step is one pass of the hot path over one batch of synthetic input:
+BASELINE.json configs[1] — the Bus.obj-class monostatic radar scene (200 k
+triangle synthetic bus + ground, 256 range bins, 64 spp per pulse) — rendered
+for a batch of pulses (2^24 paths per GPU per step) and followed, for N > 1, by
+the RCCL all-reduce of the per-GPU range histograms.  Weak scaling: per-GPU
+work is fixed; GPU g renders global path indices [g*P, (g+1)*P) via
+bf_launch.path_offset, so the union is one sample set.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: bf_render_kernel)
+and `cpu_baseline` (the CPU oracle, a port of the reference's scalar path,
+timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths", type=int, default=1 << 24, help="paths per GPU per step")
+    ap.add_argument("--tris", type=int, default=200_000)
+    ap.add_argument("--cpu-paths", type=int, default=1 << 21, help="bounded sample for the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+
+    import numpy as np
+    import torch                      # first: its libamdhip64.so.7 is the one HIP runtime of the process
+    import torch.distributed as dist
+
+    from beifong_amd import capi, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = capi.load_library()
+    capi.check(lib, lib.bf_set_device(local_rank), "bf_set_device")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sd, lp = scenes.bus_radar(n_tris=args.tris, n_paths=args.paths, bins=256, dr=0.1, seed=1)
+    scene = capi.Scene(sd, lib)
+    info = scene.info()
+    n_chan = scene.channels(lp)
+    hist = torch.zeros(n_chan, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(i, want_stats=True, flags=0):
+        l = capi.make_launch(lp.mode, args.paths, seed=lp.seed + 1000003 * i, path_offset=rank * args.paths,
+                             bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode, flags=flags)
+        hist.zero_()
+        st = scene.render_device(l, hist.data_ptr(), stream=stream, want_stats=want_stats)
+        if world > 1:
+            dist.all_reduce(hist)     # RCCL sum of the per-GPU range histograms over xGMI
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # algorithmic bytes per ray: V_n * 64 + V_t * 48 + 48, with
+    # V_n / V_t counted by the instrumented kernel on exactly this workload
+    st = step(0, flags=capi.BF_FLAG_STATS)
+    rays0 = st.n_rays_closest + st.n_rays_shadow
+    v_n = st.n_nodes_visited / rays0
+    v_t = st.n_tris_tested / rays0
+    b_ray = v_n * info.node_bytes + v_t * info.tri_bytes + 48.0
+    for i in range(args.warmup):
+        step(i)
+
+    sync()
+    t0 = time.perf_counter()
+    rays = 0
+    paths = 0
+    kernel_ms = 0.0
+    for i in range(args.steps):
+        st = step(i)
+        rays += st.n_rays_closest + st.n_rays_shadow
+        paths += st.n_paths
+        kernel_ms += st.kernel_ms
+    sync()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(rays), float(paths), kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+        rays_all, paths_all = float(sm[1]), float(sm[2])
+    else:
+        rays_all, paths_all = float(rays), float(paths)
+
+    out = None
+    if rank == 0:
+        mrays = rays_all / dt / 1e6
+        avg_kernel_s = kernel_ms / args.steps / 1e3
+        rays_per_launch = rays / args.steps
+        achieved = b_ray * rays_per_launch / avg_kernel_s / 1e9
+        out = {
+            "metric": "Mrays/s (closest + any-hit BVH queries), Bus.obj-class radar scene",
+            "value": round(mrays, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2 bus_radar: synthetic %d-triangle bus (Bus.obj stand-in) + 20x20 m ground, monostatic "
+                            "20x50 mm TX aperture + perspective RX, gen-2 range(pathlength) integrator, 256 range "
+                            "bins dr=0.1 m, 64 spp x %d pulses = %d paths per GPU per step"
+                            % (info.n_triangles, args.paths // 64, args.paths),
+                "paths_per_gpu_per_step": args.paths,
+                "range_bins": 256,
+                "triangles": int(info.n_triangles),
+                "bvh_nodes": int(info.n_bvh_nodes),
+                "parallelism": "sample-sharded x%d, RCCL all-reduce of the range histogram" % world,
+                "mpaths_per_s": round(paths_all / dt / 1e6, 2),
+                "rays_per_path": round(rays_all / paths_all, 3),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "bf_render_kernel",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "bytes_per_ray": round(b_ray, 1),
+                "nodes_per_ray": round(v_n, 2),
+                "tris_per_ray": round(v_t, 2),
+                "rays_per_launch": int(rays_per_launch),
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sd, lp, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, lp, args):
+    """The oracle (kind "port": a CPU restatement of the reference's scalar
+    path; the reference itself cannot be built offline) on this box's host
+    cores, on a bounded sample of the same workload."""
+    from beifong_amd import capi
+    from tests.oracle_lib import OracleScene
+    # the GPU box's CPU share for one GPU is 16 cores (task brief); affinity may list the whole host
+    cores = min(16, len(os.sched_getaffinity(0)))
+    o = OracleScene(sd)
+    l = capi.make_launch(lp.mode, args.cpu_paths, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
+    t0 = time.perf_counter()
+    _, _, st = o.render(l, rng_mode=0, threads=cores)
+    dt = time.perf_counter() - t0
+    rays = st.n_rays_closest + st.n_rays_shadow
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d paths of the same C2 scene (same seed, per-path PCG32 streams), oracle/bf_oracle.cpp with its "
+                  "own median-split BVH, %d std::threads, %.1f s wall" % (args.cpu_paths, cores, dt),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -291,6 +291,7 @@ struct BVHNode {
     float lo[3], hi[3];
     int32_t left, right;      // children (internal) or -1
     uint32_t first, count;    // leaf range in tri_order
+    int axis;                 // split axis (front-to-back ordering)
 };
 struct Hit {
     float t = kInf;
@@ -326,7 +327,6 @@ struct OScene {
     std::vector<BVHNode> nodes;
     std::vector<uint32_t> tri_order;
     bool brute_force = false;
-    mutable std::atomic<uint64_t> n_nodes{0}, n_tris{0};
 };
 
 // ---------------------------------------------------------------------------
@@ -385,6 +385,9 @@ inline bool box_hit(const BVHNode &nd, const Ray &ray, V3 inv_d, float tmax) {
     return tn <= tf * 1.0000004f;
 }
 
+// per-thread instrumentation (BVH nodes visited / triangles tested)
+static thread_local uint64_t t_nodes = 0, t_tris = 0;
+
 template <bool Any> static bool traverse(const OScene &sc, const Ray &ray, Hit &best) {
     // analytic rectangles: tested for every ray (scenes hold a handful)
     for (size_t i = 0; i < sc.rects.size(); ++i) {
@@ -432,12 +435,19 @@ template <bool Any> static bool traverse(const OScene &sc, const Ray &ray, Hit &
             }
             if (found) break;
         } else {
-            stack[sp++] = nd.left;
-            stack[sp++] = nd.right;
+            // front-to-back: the child on the ray's near side is popped first
+            float dax = nd.axis == 0 ? ray.d.x : (nd.axis == 1 ? ray.d.y : ray.d.z);
+            if (dax >= 0.f) {
+                stack[sp++] = nd.right;
+                stack[sp++] = nd.left;
+            } else {
+                stack[sp++] = nd.left;
+                stack[sp++] = nd.right;
+            }
         }
     }
-    sc.n_nodes.fetch_add(nn, std::memory_order_relaxed);
-    sc.n_tris.fetch_add(nt, std::memory_order_relaxed);
+    t_nodes += nn;
+    t_tris += nt;
     if (Any) return found;
     return best.valid();
 }
@@ -481,12 +491,14 @@ static void build_bvh(OScene &sc) {
         nd.lo[0] = blo.x - pad; nd.lo[1] = blo.y - pad; nd.lo[2] = blo.z - pad;
         nd.hi[0] = bhi.x + pad; nd.hi[1] = bhi.y + pad; nd.hi[2] = bhi.z + pad;
         nd.left = nd.right = -1;
+        nd.axis = 0;
         nd.first = j.first;
         nd.count = j.count;
         if (j.count > 4) {
             V3 ce = chi - clo;
             int ax = (ce.x >= ce.y && ce.x >= ce.z) ? 0 : (ce.y >= ce.z ? 1 : 2);
             auto key = [&](uint32_t ti) { return ax == 0 ? cent[ti].x : (ax == 1 ? cent[ti].y : cent[ti].z); };
+            nd.axis = ax;
             uint32_t mid = j.count / 2;
             std::nth_element(sc.tri_order.begin() + j.first, sc.tri_order.begin() + j.first + mid,
                              sc.tri_order.begin() + j.first + j.count,
@@ -1118,7 +1130,8 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     out.L = L;
 
     const uint32_t nchan = launch_channels(lp);
-    std::vector<float> aovs(nchan, 0.f);
+    static thread_local std::vector<float> aovs;
+    aovs.assign(nchan, 0.f);
     float xyz[3];
     if (lp.color_mode == BF_COLOR_RGB)
         srgb_to_xyz_grey(L, xyz);
@@ -1297,11 +1310,11 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
     std::vector<std::vector<double>> th_hist(n_threads, std::vector<double>(nchan, 0.0));
     std::vector<bf_stats> th_stats(n_threads);
     for (auto &t : th_stats) std::memset(&t, 0, sizeof(t));
-    sc.n_nodes = 0;
-    sc.n_tris = 0;
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](int tid) {
         uint64_t lo = lp->n_paths * tid / n_threads, hi = lp->n_paths * (tid + 1) / n_threads;
+        t_nodes = 0;
+        t_tris = 0;
         Sampler smp;
         if (rng_mode == 1) smp.rng.seed(lp->seed + 0);
         for (uint64_t i = lo; i < hi; ++i) {
@@ -1313,6 +1326,8 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
             st.n_rays_shadow += o.pr.n_shadow;
             st.n_bounces += o.pr.n_bounces;
             if (!o.put) st.n_invalid++;
+            st.n_nodes_visited = t_nodes;
+            st.n_tris_tested = t_tris;
             if (records_out) {
                 records_out[i].L = o.L;
                 records_out[i].aux = o.pr.aux;
@@ -1342,9 +1357,9 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
             stats_out->n_rays_shadow += st.n_rays_shadow;
             stats_out->n_bounces += st.n_bounces;
             stats_out->n_invalid += st.n_invalid;
+            stats_out->n_nodes_visited += st.n_nodes_visited;
+            stats_out->n_tris_tested += st.n_tris_tested;
         }
-        stats_out->n_nodes_visited = sc.n_nodes;
-        stats_out->n_tris_tested = sc.n_tris;
         stats_out->kernel_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     }
     return BF_OK;
