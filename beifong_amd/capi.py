@@ -20,7 +20,7 @@ BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER = range(4)
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW = range(4)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
-BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS = 1, 2
+BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL = 1, 2, 4
 
 M16 = C.c_float * 16
 
@@ -86,7 +86,9 @@ PATH_RECORD_DTYPE = np.dtype([("L", "<f4"), ("aux", "<f4"), ("valid", "<u4"), ("
 class bf_stats(C.Structure):
     _fields_ = [("n_paths", C.c_uint64), ("n_rays_closest", C.c_uint64), ("n_rays_shadow", C.c_uint64),
                 ("n_nodes_visited", C.c_uint64), ("n_tris_tested", C.c_uint64), ("n_invalid", C.c_uint64),
-                ("n_bounces", C.c_uint64), ("kernel_ms", C.c_float)]
+                ("n_bounces", C.c_uint64), ("kernel_ms", C.c_float), ("trace_ms", C.c_float),
+                ("shade_ms", C.c_float), ("tail_ms", C.c_float), ("n_launches_trace", C.c_uint32),
+                ("n_bounce_iters", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -14,6 +14,7 @@
 
 #include "bf_bvh.h"
 #include "bf_device.h"
+#include "bf_wavefront.h"
 
 extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunch *lp, float *g_hist, bf_path_record *records,
                                         unsigned long long *counters, int stats, unsigned grid, size_t lds_bytes,
@@ -21,6 +22,15 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
                                        hipStream_t stream);
+
+extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
+                                   float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
+                                   hipStream_t stream);
+extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
+                                   hipStream_t stream);
+extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
+                                      uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
+                                      hipStream_t stream);
 
 namespace {
 
@@ -86,6 +96,14 @@ struct bf_scene {
     int n_cus = 256;
     // per-scene scratch for bf_render_device (counters), allocated once
     unsigned long long *counters = nullptr;
+    // wavefront workspace, allocated on first use (mutable: lazily grown cache)
+    mutable bfd::WF wf;
+    mutable std::vector<void *> wf_owned;
+    mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
+    mutable hipEvent_t wf_event = nullptr;
+    mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only)
+    mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render
+    mutable uint32_t wf_iters = 0, wf_trace_launches = 0;
 };
 
 extern "C" {
@@ -118,6 +136,10 @@ uint32_t bf_launch_channels(const bf_launch *lp) {
 bf_status bf_scene_destroy(bf_scene *s) {
     if (!s) return BF_OK;
     for (void *p : s->owned) (void) hipFree(p);
+    for (void *p : s->wf_owned) (void) hipFree(p);
+    if (s->wf_host) (void) hipHostFree(s->wf_host);
+    if (s->wf_event) (void) hipEventDestroy(s->wf_event);
+    for (hipEvent_t e : s->wf_timing) (void) hipEventDestroy(e);
     if (s->counters) (void) hipFree(s->counters);
     delete s;
     return BF_OK;
@@ -233,6 +255,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
     std::memset(&sc->d, 0, sizeof(sc->d));
     std::memset(&sc->info, 0, sizeof(sc->info));
+    std::memset(&sc->wf, 0, sizeof(sc->wf));
     bfd::DSensor &sen = sc->d.sensor;
     sen.type = desc->sensor.type;
     sen.rect = -1;
@@ -338,6 +361,143 @@ bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
     return BF_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// wavefront driver
+// ---------------------------------------------------------------------------
+static uint32_t wf_pool_capacity() {
+    const char *e = getenv("BF_WF_POOL");
+    uint64_t v = e ? strtoull(e, nullptr, 10) : (1ull << 22);
+    v = std::max<uint64_t>(1024, std::min<uint64_t>(v, 1ull << 26));
+    return (uint32_t) v;
+}
+
+static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
+    bfd::WF &wf = scene->wf;
+    if (wf.capacity >= capacity) return BF_OK;
+    for (void *p : scene->wf_owned) (void) hipFree(p);
+    scene->wf_owned.clear();
+    std::memset(&wf, 0, sizeof(wf));
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) scene->wf_owned.push_back(*p);
+        return e;
+    };
+    size_t n = capacity;
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(alloc((void **) &wf.ray0[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.ray1[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.sa[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.sb[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.sc[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.sd[b], n * 16));
+    }
+    HIP_TRY(alloc((void **) &wf.hit, n * 16));
+    HIP_TRY(alloc((void **) &wf.sh0, n * 16));
+    HIP_TRY(alloc((void **) &wf.sh1, n * 16));
+    HIP_TRY(alloc((void **) &wf.sh2, n * 8));
+    uint32_t *ctr = nullptr;
+    HIP_TRY(alloc((void **) &ctr, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
+    wf.n_q = ctr;
+    wf.n_sh = ctr + (bfd::kWfMaxIter + 2);
+    wf.head_shade = ctr + 2 * (bfd::kWfMaxIter + 2);
+    wf.head_trace = ctr + 3 * (bfd::kWfMaxIter + 2);
+    wf.counters = scene->counters;
+    wf.capacity = capacity;
+    if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
+    if (!scene->wf_event) HIP_TRY(hipEventCreateWithFlags(&scene->wf_event, hipEventDisableTiming));
+    return BF_OK;
+}
+
+static uint32_t wf_tail_threshold() {
+    const char *e = getenv("BF_WF_TAIL");
+    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 17);
+}
+
+// Host control loop.  Per bounce `it`: wf_shade(it) -> [copy the two queue
+// counters] -> wf_trace(it).  The host waits for the counters of bounce `it`
+// while wf_trace(it) is still running, so the device never idles on the
+// decision; once the path supply is exhausted and at most wf_tail_threshold()
+// paths survive, one tail launch finishes them.
+static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float *hist_dev, bf_path_record *records_dev,
+                           hipStream_t stream, bool count_nodes, bool stats) {
+    uint32_t cap = (uint32_t) std::min<uint64_t>(wf_pool_capacity(), std::max<uint64_t>(lp.n_paths, 1024));
+    bf_status st = wf_ensure(scene, cap);
+    if (st != BF_OK) return st;
+    const bfd::WF &wf = scene->wf;
+    uint32_t pool = (uint32_t) std::min<uint64_t>(wf.capacity, lp.n_paths);
+    HIP_TRY(hipMemsetAsync(wf.n_q, 0, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemcpyAsync(wf.n_q, &pool, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan + 15) & ~size_t(15)) : 0;
+    size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
+    // persistent grids: shade is register-heavy (2 workgroups per CU), trace is
+    // LDS-stack bound (5 workgroups of 32 KiB per CU)
+    const unsigned grid_shade = (unsigned) scene->n_cus * 2, grid_trace = (unsigned) scene->n_cus * 5;
+    const uint32_t tail_max = wf_tail_threshold();
+    uint32_t n_cur = pool;                       // live slots entering bounce `it` (host's view)
+    volatile uint32_t *hq = scene->wf_host;      // [0] = n_q[it+1], [2..3] = next path counter
+    // per-kernel timing (stats renders only): events bracket every launch
+    const size_t kMaxTimed = 96;
+    size_t n_ev = 0;
+    std::vector<int> ev_kind;                    // 0 trace, 1 shade, 2 tail (per event pair)
+    if (stats)
+        while (scene->wf_timing.size() < 2 * kMaxTimed) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            scene->wf_timing.push_back(e);
+        }
+    auto tic = [&](int kind) -> hipError_t {
+        if (!stats || n_ev >= kMaxTimed) return hipSuccess;
+        ev_kind.push_back(kind);
+        return hipEventRecord(scene->wf_timing[2 * n_ev], stream);
+    };
+    auto toc = [&]() -> hipError_t {
+        if (!stats || n_ev >= kMaxTimed) return hipSuccess;
+        return hipEventRecord(scene->wf_timing[2 * n_ev++ + 1], stream);
+    };
+    auto finish = [&](uint32_t iters, uint32_t traces) -> bf_status {
+        scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
+        scene->wf_iters = iters;
+        scene->wf_trace_launches = traces;
+        if (!stats) return BF_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t k = 0; k < n_ev; ++k) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, scene->wf_timing[2 * k], scene->wf_timing[2 * k + 1]));
+            scene->wf_ms[ev_kind[k]] += ms;
+        }
+        return BF_OK;
+    };
+    for (uint32_t it = 0; it < bfd::kWfMaxIter; ++it) {
+        unsigned blocks = (n_cur + bfd::kBlock - 1) / bfd::kBlock;
+        HIP_TRY(tic(1));
+        HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev,
+                             std::max(1u, std::min(grid_shade, blocks)), lds_shade, stream));
+        HIP_TRY(toc());
+        HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_q + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync((void *) &hq[2], wf.counters + bfd::CTR_NEXT_PATH, sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(scene->wf_event, stream));
+        // rays of this bounce: at most one shadow + one closest ray per live slot
+        HIP_TRY(tic(0));
+        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, std::max(1u, std::min(grid_trace, 2 * blocks)), stream));
+        HIP_TRY(toc());
+        HIP_TRY(hipEventSynchronize(scene->wf_event));
+        uint32_t n_next = hq[0];
+        unsigned long long next_path = ((unsigned long long) hq[3] << 32) | hq[2];
+        if (n_next == 0) return finish(it + 1, it + 1);
+        if (next_path >= lp.n_paths && n_next <= tail_max) {
+            HIP_TRY(tic(2));
+            HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, it + 1, n_next, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail,
+                                    stream));
+            HIP_TRY(toc());
+            return finish(it + 1, it + 1);
+        }
+        n_cur = n_next;
+    }
+    return fail(BF_ERR_UNSUPPORTED, "path depth exceeded the wavefront iteration limit (%u bounces)", bfd::kWfMaxIter);
+}
+
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
                            void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
@@ -376,8 +536,14 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     if (launch->n_paths) {
-        HIP_TRY(bfk_launch_render(&scene->d, &lp, hist_dev, records_dev, scene->counters,
-                                  (launch->flags & BF_FLAG_STATS) ? 1 : 0, grid, lds, stream));
+        if (launch->flags & BF_FLAG_MEGAKERNEL) {
+            HIP_TRY(bfk_launch_render(&scene->d, &lp, hist_dev, records_dev, scene->counters,
+                                      (launch->flags & BF_FLAG_STATS) ? 1 : 0, grid, lds, stream));
+        } else {
+            bf_status wst = wf_render(scene, lp, hist_dev, records_dev, stream, (launch->flags & BF_FLAG_STATS) != 0,
+                                      stats_out != nullptr);
+            if (wst != BF_OK) return wst;
+        }
     }
     if (stats_out) {
         HIP_TRY(hipEventRecord(ev1, stream));
@@ -395,6 +561,13 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         stats_out->kernel_ms = ms;
+        if (!(launch->flags & BF_FLAG_MEGAKERNEL) && launch->n_paths) {
+            stats_out->trace_ms = scene->wf_ms[0];
+            stats_out->shade_ms = scene->wf_ms[1];
+            stats_out->tail_ms = scene->wf_ms[2];
+            stats_out->n_launches_trace = scene->wf_trace_launches;
+            stats_out->n_bounce_iters = scene->wf_iters;
+        }
         (void) hipEventDestroy(ev0);
         (void) hipEventDestroy(ev1);
     }

@@ -1,0 +1,533 @@
+// Device functions shared by the megakernel (bf_kernels.hip) and the wavefront
+// kernels (bf_wavefront.hip): BVH traversal, surface interaction, BSDFs,
+// emitters, sensors.  Reference semantics (file:line) are cited at each
+// function; the oracle (oracle/bf_oracle.cpp) restates the same functions
+// independently on the CPU.
+#pragma once
+#include "bf_device.h"
+#include "bf_device_math.h"
+
+namespace bfd {
+
+struct Hit {
+    float t, u, v;
+    uint32_t prim;      // global primitive index (tie rule)
+    int32_t slot;       // triangle slot in leaf order, or -(rect+1)
+};
+
+// Mesh::ray_intersect_triangle — include/mitsuba/render/mesh.h:190-224
+BF_DEV bool tri_intersect(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, float maxt, float &t, float &u, float &v) {
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    V3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    t = dot(e2, qvec) * inv_det;
+    return active && t >= mint && t <= maxt;
+}
+
+// Rectangle::ray_intersect_preliminary — src/shapes/rectangle.cpp:229-249
+BF_DEV bool rect_intersect(const DRect &rc, V3 o, V3 d, float mint, float maxt, float &t, float &lx, float &ly) {
+    V3 oo = xf_point(rc.to_object, o);
+    V3 dd = xf_vector(rc.to_object, d);
+    float d_rcp_z = rcp(dd.z);
+    t = -oo.z * d_rcp_z;
+    V3 local = fmadd3(dd, t, oo);
+    lx = local.x;
+    ly = local.y;
+    return t >= mint && t <= maxt && __builtin_fabsf(local.x) <= 1.f && __builtin_fabsf(local.y) <= 1.f;
+}
+
+// Closest-hit tie rule: the reference shrinks ray.maxt and accepts t <= maxt
+// (kdtree.h:2139-2156; Scene::ray_intersect_naive), so among equal t the
+// primitive tested later — the larger global index in the naive order — wins.
+// Fixing that rule makes the result independent of traversal order.
+BF_DEV void consider(Hit &best, float t, float u, float v, uint32_t prim, int32_t slot) {
+    if (t < best.t || (t == best.t && prim > best.prim)) {
+        best.t = t;
+        best.u = u;
+        best.v = v;
+        best.prim = prim;
+        best.slot = slot;
+    }
+}
+
+BF_DEV bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 id, float mint, float tmax,
+                 float &tn) {
+    float t0x = (lox - o.x) * id.x, t1x = (hix - o.x) * id.x;
+    float t0y = (loy - o.y) * id.y, t1y = (hiy - o.y) * id.y;
+    float t0z = (loz - o.z) * id.z, t1z = (hiz - o.z) * id.z;
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                         __builtin_fmaxf(__builtin_fminf(t0z, t1z), mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                               __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
+    return tn <= tf * 1.0000004f;
+}
+
+// Scene::ray_intersect / ray_test — src/librender/scene.cpp:129-178.
+// `stack` points at this lane's column of the workgroup's LDS stack
+// (entry k at stack[k * kBlock]).
+template <bool ANY, bool STATS>
+BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
+                     uint32_t &n_tris) {
+    best.t = BF_INF;
+    best.u = best.v = 0.f;
+    best.prim = 0;
+    best.slot = 0;
+    // analytic rectangles (antennas, target plate, ground): a handful per scene
+    for (uint32_t i = 0; i < sc.n_rects; ++i) {
+        const DRect &rc = sc.rects[i];
+        float t, lx, ly;
+        if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
+            if (ANY) return true;
+            consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
+        }
+    }
+    if (sc.n_tris == 0) return best.t != BF_INF;
+
+    V3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    int node = sc.root;
+    int sp = 0;
+    while (true) {
+        if (node >= 0) {
+            const float4 *np = sc.nodes + 4 * (size_t) node;
+            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (STATS) ++n_nodes;
+            float tmax = ANY ? maxt : __builtin_fminf(maxt, best.t);
+            float tn0, tn1;
+            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
+            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                if (tn1 < tn0) {
+                    int tmp = c0;
+                    c0 = c1;
+                    c1 = tmp;
+                }
+                stack[sp * kBlock] = c1;
+                ++sp;
+                node = c0;
+                continue;
+            } else if (h0) {
+                node = c0;
+                continue;
+            } else if (h1) {
+                node = c1;
+                continue;
+            }
+        } else {
+            uint32_t enc = ~(uint32_t) node;
+            uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4 *tp = sc.tris + 3 * (size_t) (first + i);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) ++n_tris;
+                float t, u, v;
+                if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
+                    if (ANY) return true;
+                    consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = stack[sp * kBlock];
+    }
+    return best.t != BF_INF;
+}
+
+// ---------------------------------------------------------------------------
+// surface interaction: PreliminaryIntersection::compute_surface_interaction
+// (interaction.h:613-644), Mesh::compute_surface_interaction
+// (mesh.cpp:452-548), Rectangle::compute_surface_interaction
+// (rectangle.cpp:265-298), initialize_sh_frame (interaction.h:159-162)
+// ---------------------------------------------------------------------------
+struct SI {
+    float t;
+    V3 p, wi;
+    Frame sh;
+    uint32_t shape;
+};
+
+BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
+    si.t = h.t;
+    V3 dp_du;
+    if (h.slot < 0) {
+        const DRect &rc = sc.rects[-h.slot - 1];
+        si.shape = rc.shape;
+        si.p = fmadd3(d, h.t, o);
+        si.sh.n = mk(rc.n[0], rc.n[1], rc.n[2]);
+        dp_du = mk(rc.s[0], rc.s[1], rc.s[2]);
+    } else {
+        const float4 *tp = sc.tris + 3 * (size_t) h.slot;
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
+        si.shape = __float_as_uint(b.w);
+        float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
+        V3 dp0 = p1 - p0, dp1 = p2 - p0;
+        si.p = p0 * b0 + p1 * b1 + p2 * b2;
+        V3 n = normalize(cross(dp0, dp1));
+        V3 dp_dv;
+        coordinate_system(n, dp_du, dp_dv);
+        if (__float_as_uint(c.w) != 0u) {
+            const float4 *nq = sc.normals + 3 * (size_t) h.slot;
+            float4 na = nq[0], nb = nq[1], nc = nq[2];
+            si.sh.n = normalize(mk(na.x, na.y, na.z) * b0 + mk(nb.x, nb.y, nb.z) * b1 + mk(nc.x, nc.y, nc.z) * b2);
+        } else {
+            si.sh.n = n;
+        }
+    }
+    float dd = dot(si.sh.n, dp_du);
+    si.sh.s = normalize(mk(fnmadd(si.sh.n.x, dd, dp_du.x), fnmadd(si.sh.n.y, dd, dp_du.y), fnmadd(si.sh.n.z, dd, dp_du.z)));
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = to_local(si.sh, -d);
+}
+
+// ---------------------------------------------------------------------------
+// BSDFs: diffuse.cpp:78-135, roughconductor.cpp:196-392 (+ microfacet.h,
+// fresnel.h:92-116), twosided.cpp:94-180
+// ---------------------------------------------------------------------------
+struct Microfacet {
+    uint32_t type;
+    float au, av;
+    bool sample_visible;
+};
+BF_DEV Microfacet mf_make(const bf_material &m) {
+    Microfacet d;
+    d.type = m.distribution;
+    d.au = __builtin_fmaxf(m.alpha_u, 1e-4f);
+    d.av = __builtin_fmaxf(m.alpha_v, 1e-4f);
+    d.sample_visible = m.sample_visible != 0;
+    return d;
+}
+BF_DEV float mf_eval(const Microfacet &d, V3 m) {
+    float alpha_uv = d.au * d.av, cos_theta = m.z, cos_theta_2 = sqr(cos_theta), result;
+    if (d.type == BF_MF_BECKMANN)
+        result = exp_cr(-(sqr(m.x / d.au) + sqr(m.y / d.av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
+    else
+        result = rcp(kPi * alpha_uv * sqr(sqr(m.x / d.au) + sqr(m.y / d.av) + sqr(m.z)));
+    return (result * cos_theta > 1e-20f) ? result : 0.f;
+}
+BF_DEV float mf_smith_g1(const Microfacet &d, V3 v, V3 m) {
+    float xy_alpha_2 = sqr(d.au * v.x) + sqr(d.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z), result;
+    if (d.type == BF_MF_BECKMANN) {
+        float a = 1.f / __builtin_sqrtf(tan_theta_alpha_2), a_sqr = sqr(a);
+        result = (a >= 1.6f) ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else {
+        result = 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
+    }
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+BF_DEV float mf_G(const Microfacet &d, V3 wi, V3 wo, V3 m) { return mf_smith_g1(d, wi, m) * mf_smith_g1(d, wo, m); }
+BF_DEV void mf_sample_visible_11(const Microfacet &d, float cos_theta_i, float sx, float sy, float &ox, float &oy) {
+    if (d.type == BF_MF_BECKMANN) {
+        float tan_theta_i = safe_sqrt(fnmadd(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i;
+        float cot_theta_i = rcp(tan_theta_i);
+        float maxval = erf_cr(cot_theta_i);
+        sx = __builtin_fmaxf(__builtin_fminf(sx, 1.f - 1e-6f), 1e-6f);
+        sy = __builtin_fmaxf(__builtin_fminf(sy, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * erf_cr(__builtin_sqrtf(-log_cr(sx)));
+        sx *= 1.f + maxval + kInvSqrtPi * tan_theta_i * exp_cr(-sqr(cot_theta_i));
+#pragma nounroll
+        for (int i = 0; i < 3; ++i) {
+            float slope = erfinv_giles(x);
+            float value = 1.f + x + kInvSqrtPi * tan_theta_i * exp_cr(-sqr(slope)) - sx;
+            float derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        ox = erfinv_giles(x);
+        oy = erfinv_giles(fmsub(2.f, sy, 1.f));
+    } else {
+        float px, py;
+        square_to_uniform_disk_concentric(sx, sy, px, py);
+        float s = .5f * (1.f + cos_theta_i);
+        float a = safe_sqrt(1.f - sqr(px));
+        py = fmadd(py, s, fnmadd(a, s, a));
+        float x = px, y = py, z = safe_sqrt(1.f - fmadd(py, py, px * px));
+        float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+        float nrm = rcp(fmadd(sin_theta_i, y, cos_theta_i * z));
+        ox = fmsub(cos_theta_i, y, sin_theta_i * z) * nrm;
+        oy = x * nrm;
+    }
+}
+BF_DEV void mf_sample(const Microfacet &d, V3 wi, float sx, float sy, V3 &m, float &pdf) {
+    if (!d.sample_visible) {
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+        if (d.au == d.av) {
+            float ang = (2.f * kPi) * sy;
+            sin_phi = sin_cr(ang);
+            cos_phi = cos_cr(ang);
+            alpha_2 = d.au * d.au;
+        } else {
+            float ratio = d.av / d.au, tmp = ratio * tan_cr((2.f * kPi) * sy);
+            cos_phi = 1.f / __builtin_sqrtf(fmadd(tmp, tmp, 1.f));
+            cos_phi = mulsign(cos_phi, __builtin_fabsf(sy - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = rcp(sqr(cos_phi / d.au) + sqr(sin_phi / d.av));
+        }
+        if (d.type == BF_MF_BECKMANN) {
+            cos_theta = 1.f / __builtin_sqrtf(fnmadd(alpha_2, log_cr(1.f - sx), 1.f));
+            cos_theta_2 = sqr(cos_theta);
+            float cos_theta_3 = __builtin_fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.f - sx) / (kPi * d.au * d.av * cos_theta_3);
+        } else {
+            float tan_theta_m_2 = alpha_2 * sx / (1.f - sx);
+            cos_theta = 1.f / __builtin_sqrtf(1.f + tan_theta_m_2);
+            cos_theta_2 = sqr(cos_theta);
+            float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = __builtin_fmaxf(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = rcp(kPi * d.au * d.av * cos_theta_3 * sqr(temp));
+        }
+        float sin_theta = __builtin_sqrtf(1.f - cos_theta_2);
+        m = mk(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    } else {
+        V3 wi_p = normalize(mk(d.au * wi.x, d.av * wi.y, wi.z));
+        float sin_theta_2 = fmadd(wi_p.x, wi_p.x, sqr(wi_p.y));
+        float inv_sin_theta = 1.f / __builtin_sqrtf(sin_theta_2);
+        float sin_phi, cos_phi;
+        if (__builtin_fabsf(sin_theta_2) <= 4.f * kEpsilon) {
+            sin_phi = 0.f;
+            cos_phi = 1.f;
+        } else {
+            sin_phi = __builtin_fminf(__builtin_fmaxf(wi_p.y * inv_sin_theta, -1.f), 1.f);
+            cos_phi = __builtin_fminf(__builtin_fmaxf(wi_p.x * inv_sin_theta, -1.f), 1.f);
+        }
+        float slx, sly;
+        mf_sample_visible_11(d, wi_p.z, sx, sy, slx, sly);
+        float rx = fmsub(cos_phi, slx, sin_phi * sly) * d.au;
+        float ry = fmadd(sin_phi, slx, cos_phi * sly) * d.av;
+        m = normalize(mk(-rx, -ry, 1.f));
+        pdf = mf_eval(d, m) * mf_smith_g1(d, wi, m) * __builtin_fabsf(dot(wi, m)) / wi.z;
+    }
+}
+BF_DEV float mf_pdf(const Microfacet &d, V3 wi, V3 m) {
+    float result = mf_eval(d, m);
+    if (d.sample_visible)
+        result *= mf_smith_g1(d, wi, m) * __builtin_fabsf(dot(wi, m)) / wi.z;
+    else
+        result *= m.z;
+    return result;
+}
+BF_DEV float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2,
+          sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+          a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return .5f * (r_s + r_p);
+}
+BF_DEV V3 reflect(V3 wi, V3 m) {
+    float d2 = 2.f * dot(wi, m);
+    return mk(fmsub(m.x, d2, wi.x), fmsub(m.y, d2, wi.y), fmsub(m.z, d2, wi.z));
+}
+
+struct BSDFSample {
+    V3 wo;
+    float pdf, eta;
+};
+
+BF_DEV float bsdf_sample_1(const bf_material &mat, V3 wi, float s2x, float s2y, BSDFSample &bs) {
+    bs.wo = mk(0.f, 0.f, 0.f);
+    bs.pdf = 0.f;
+    bs.eta = 1.f;
+    float cos_theta_i = wi.z;
+    if (!(cos_theta_i > 0.f)) return 0.f;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+        bs.pdf = kInvPi * bs.wo.z;
+        return (bs.pdf > 0.f) ? mat.reflectance : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        Microfacet distr = mf_make(mat);
+        V3 m;
+        mf_sample(distr, wi, s2x, s2y, m, bs.pdf);
+        bs.wo = reflect(wi, m);
+        bool active = bs.pdf != 0.f && bs.wo.z > 0.f;
+        float weight;
+        if (distr.sample_visible)
+            weight = mf_smith_g1(distr, bs.wo, m);
+        else
+            weight = mf_G(distr, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
+        bs.pdf /= 4.f * dot(bs.wo, m);
+        float F = fresnel_conductor(dot(wi, m), mat.eta, mat.k);
+        if (mat.has_specular_reflectance) weight *= mat.reflectance;
+        return active ? F * weight : 0.f;
+    }
+    return 0.f;
+}
+BF_DEV float bsdf_eval_1(const bf_material &mat, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        float value = mat.reflectance * kInvPi * cos_theta_o;
+        return active ? value : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        if (!active) return 0.f;
+        V3 H = normalize(wo + wi);
+        Microfacet distr = mf_make(mat);
+        float D = mf_eval(distr, H);
+        active = active && D != 0.f;
+        float G = mf_G(distr, wi, wo, H);
+        float result = D * G / (4.f * wi.z);
+        float F = fresnel_conductor(dot(wi, H), mat.eta, mat.k);
+        if (mat.has_specular_reflectance) result *= mat.reflectance;
+        return active ? F * result : 0.f;
+    }
+    return 0.f;
+}
+BF_DEV float bsdf_pdf_1(const bf_material &mat, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (mat.type == BF_BSDF_DIFFUSE) {
+        float pdf = kInvPi * wo.z;
+        return (cos_theta_i > 0.f && cos_theta_o > 0.f) ? pdf : 0.f;
+    } else if (mat.type == BF_BSDF_ROUGHCONDUCTOR) {
+        V3 m = normalize(wo + wi);
+        bool active = cos_theta_i > 0.f && cos_theta_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
+        if (!active) return 0.f;
+        Microfacet distr = mf_make(mat);
+        if (distr.sample_visible) return mf_eval(distr, m) * mf_smith_g1(distr, wi, m) / (4.f * cos_theta_i);
+        return mf_pdf(distr, wi, m) / (4.f * dot(wo, m));
+    }
+    return 0.f;
+}
+// TwoSidedBRDF with one nested BSDF on both sides: flip wi.z / wo.z
+BF_DEV float bsdf_sample(const bf_material &mat, V3 wi, float s2x, float s2y, BSDFSample &bs) {
+    bool flip = mat.twosided && wi.z < 0.f;
+    if (mat.twosided && wi.z == 0.f) {
+        bs.wo = mk(0.f, 0.f, 0.f);
+        bs.pdf = 0.f;
+        bs.eta = 1.f;
+        return 0.f;
+    }
+    if (flip) wi.z *= -1.f;
+    float r = bsdf_sample_1(mat, wi, s2x, s2y, bs);
+    if (flip) bs.wo.z *= -1.f;
+    return r;
+}
+BF_DEV void bsdf_eval_pdf(const bf_material &mat, V3 wi, V3 wo, float &ev, float &pdf) {
+    if (mat.twosided) {
+        if (wi.z == 0.f) {
+            ev = pdf = 0.f;
+            return;
+        }
+        if (wi.z < 0.f) {
+            wi.z *= -1.f;
+            wo.z *= -1.f;
+        }
+    }
+    ev = bsdf_eval_1(mat, wi, wo);
+    pdf = bsdf_pdf_1(mat, wi, wo);
+}
+BF_DEV bool bsdf_smooth(const bf_material &mat) {
+    return mat.type == BF_BSDF_DIFFUSE || mat.type == BF_BSDF_ROUGHCONDUCTOR;
+}
+
+// ---------------------------------------------------------------------------
+// emitters: spot.cpp:97-164, area.cpp:66-186, shape.cpp:323-356,
+// rectangle.cpp:111-125; scene.cpp:180-247
+// ---------------------------------------------------------------------------
+struct DirSample {
+    V3 d;
+    float pdf, dist;
+    bool delta;
+};
+
+BF_DEV float spot_falloff(const DEmitter &e, V3 d) {
+    float result = e.radiance;
+    V3 local_dir = normalize(d);
+    float cos_theta = local_dir.z;
+    float beam_res = (cos_theta >= e.cos_beam) ? result : result * ((e.cutoff - acos_cr(cos_theta)) * e.inv_transition);
+    return (cos_theta <= e.cos_cutoff) ? 0.f : beam_res;
+}
+
+BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
+    if (e.type == BF_EMITTER_SPOT) {
+        V3 p = mk(e.to_world[3], e.to_world[7], e.to_world[11]);
+        ds.pdf = 1.f;
+        ds.delta = true;
+        ds.d = p - ref_p;
+        ds.dist = norm(ds.d);
+        float inv_dist = rcp(ds.dist);
+        ds.d = ds.d * inv_dist;
+        V3 local_d = xf_vector(e.to_object, -ds.d);
+        return spot_falloff(e, local_d) * (inv_dist * inv_dist);
+    } else {
+        const DRect &rc = sc.rects[e.rect];
+        V3 p = xf_point(rc.to_world, mk(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
+        V3 n = mk(rc.n[0], rc.n[1], rc.n[2]);
+        ds.pdf = rc.inv_area;
+        ds.delta = false;
+        ds.d = p - ref_p;
+        float dist_squared = squared_norm(ds.d);
+        ds.dist = __builtin_sqrtf(dist_squared);
+        ds.d = ds.d / ds.dist;
+        float dp = __builtin_fabsf(dot(ds.d, n));
+        ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        bool active = dot(ds.d, n) < 0.f && ds.pdf != 0.f;
+        float spec = e.radiance / ds.pdf;
+        return active ? spec : 0.f;
+    }
+}
+
+// pdf_emitter_direction for the hit `p_hit` (normal n_hit) seen from `p_ref`
+BF_DEV float emitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
+    if (e.type == BF_EMITTER_SPOT) return 0.f;
+    const DRect &rc = sc.rects[e.rect];
+    V3 d = p_hit - p_ref;
+    float dist = norm(d);
+    d = d / dist;
+    float dp = dot(d, n_hit);
+    float pdf = rc.inv_area, adp = __builtin_fabsf(dot(d, n_hit));
+    pdf *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
+    return (dp < 0.f) ? pdf : 0.f;
+}
+
+BF_DEV float mis_weight(float pdf_a, float pdf_b) {   // path.cpp:222-226
+    pdf_a *= pdf_a;
+    pdf_b *= pdf_b;
+    return pdf_a > 0.f ? pdf_a / (pdf_a + pdf_b) : 0.f;
+}
+
+// spectrum.h:281-287 applied to a grey colour: M * (l,l,l)
+BF_DEV void srgb_to_xyz_grey(float l, float &X, float &Y, float &Z) {
+    X = fmadd(0.180423f, l, fmadd(0.357580f, l, 0.412453f * l));
+    Y = fmadd(0.072169f, l, fmadd(0.715160f, l, 0.212671f * l));
+    Z = fmadd(0.950227f, l, fmadd(0.119193f, l, 0.019334f * l));
+}
+
+// sensor rays: fluxmeter.cpp:63-85, perspective.cpp:172-199
+BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, float ay, V3 &o, V3 &d, float &mint,
+                               float &maxt) {
+    const DSensor &s = sc.sensor;
+    if (s.type == BF_SENSOR_FLUXMETER) {
+        const DRect &rc = sc.rects[s.rect];
+        o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
+        V3 local = square_to_cosine_hemisphere(ax, ay);
+        Frame f;
+        f.n = mk(rc.n[0], rc.n[1], rc.n[2]);
+        coordinate_system(f.n, f.s, f.t);
+        d = to_world(f, local);
+        mint = kRayEpsilon;
+        maxt = BF_INF;
+        return 1.f * kPi;
+    } else {
+        V3 near_p = xf_point_proj(s.sample_to_camera, mk(px, py, 0.f));
+        V3 dl = normalize(near_p);
+        float inv_z = rcp(dl.z);
+        mint = s.near_clip * inv_z;
+        maxt = s.far_clip * inv_z;
+        o = xf_point(s.to_world, mk(0.f, 0.f, 0.f));
+        d = xf_vector(s.to_world, dl);
+        return 1.f;
+    }
+}
+
+}  // namespace bfd

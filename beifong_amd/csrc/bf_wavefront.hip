@@ -1,0 +1,558 @@
+// Wavefront path tracer for gfx950: the radar hot path split into two
+// persistent kernels per bounce, with the path state streamed through HBM.
+//
+//   wf_shade : one lane per live path slot.  Reads the slot's state + closest
+//              hit (coalesced, queue order), runs the integrator's vertex logic
+//              (emitter hit, Russian roulette, next-event estimation, BSDF
+//              sampling — path.cpp:121-209 and the pathlength / pathtime
+//              variants), bins finished paths into the LDS-privatised range
+//              histogram, REGENERATES finished slots with fresh paths from the
+//              global path counter, and writes survivors compacted
+//              (__ballot/__popcll prefix + one atomic per wave) into the next
+//              queue together with their next ray; shadow rays go to a second
+//              compacted queue carrying the NEE contribution they gate.
+//   wf_trace : persistent waves pull batches of 64 rays (shadow rays first,
+//              then closest-hit rays) from the queues and traverse the BVH with
+//              per-lane LDS stacks; closest hits are written in queue order,
+//              unoccluded shadow rays add their contribution to the path.
+//
+// The fat shading code (fp64 transcendentals, > 256 registers) and the lean
+// traversal code (58 VGPRs) no longer share one register allocation, so the
+// latency-bound traversal runs at 5 waves/SIMD instead of 1, and every lane
+// of a trace wave holds a ray.  Results are bit-identical per path to the
+// megakernel (bf_kernels.hip) and to the oracle: same draws, same arithmetic.
+#include "bf_device_core.h"
+#include "bf_wavefront.h"
+#include "bf_wf_state.h"
+
+namespace bfd {
+
+BF_DEV void wf_hist_add(float *s_hist, float *g_hist, bool lds, uint32_t idx, float v) {
+    if (lds)
+        atomicAdd(&s_hist[idx], v);     // ds_add_f32
+    else
+        atomicAdd(&g_hist[idx], v);     // global_atomic_add_f32
+}
+
+struct FilmAcc {
+    float X, Y, Z, A, W;
+    uint32_t invalid;
+};
+
+// render_sample tail (integrator.cpp:286-307) + range/time AOVs
+// (range.cpp:141-161, time.cpp:134-153) + ImageBlock::put box branch
+BF_DEV void film_put(const DLaunch &lp, const PathState &s, float sensor_w, float *s_hist, float *g_hist, bool lds_hist,
+                     FilmAcc &acc, bf_path_record *records) {
+    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+    float L = sensor_w * s.result;
+    float X, Y, Z;
+    if (lp.color_mode == BF_COLOR_RGB)
+        srgb_to_xyz_grey(L, X, Y, Z);
+    else
+        X = Y = Z = L;
+    float a0 = s.result, a1 = s.result, a2 = s.result;      // AOVs see the unweighted radiance
+    if (is_time && lp.color_mode == BF_COLOR_RGB) srgb_to_xyz_grey(s.result, a0, a1, a2);
+    bool ok = (s.flags & kFlagFilmOk) && __builtin_isfinite(X) && __builtin_isfinite(Y) && __builtin_isfinite(Z);
+    if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
+    if (ok) {
+        acc.X += X;
+        acc.Y += Y;
+        acc.Z += Z;
+        acc.A += (s.flags & kFlagValid) ? 1.f : 0.f;
+        acc.W += 1.f;
+        if (is_range || is_time) {
+            float w = lp.bin_width;
+            int k = (int) __builtin_floorf(s.aux / w);
+            for (int i = k - 1; i <= k + 1; ++i) {
+                if (i < 0 || i >= (int) lp.bins) continue;
+                float lo = (float) i * w, hi = (float) i * w + w;
+                if (s.aux >= lo && s.aux < hi) {
+                    if (is_range) {
+                        if (a0 != 0.f) wf_hist_add(s_hist, g_hist, lds_hist, 5u + (uint32_t) i, a0);
+                    } else if (a0 != 0.f || a1 != 0.f || a2 != 0.f) {
+                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 0u, a0);
+                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 1u, a1);
+                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 2u, a2);
+                    }
+                }
+            }
+        }
+    } else {
+        ++acc.invalid;
+    }
+    if (records) {
+        bf_path_record r;
+        r.L = L;
+        r.aux = s.aux;
+        r.valid = (s.flags & kFlagValid) ? 1u : 0u;
+        r.n_rays = s.n_rays;
+        records[s.path_i] = r;
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
+                                                   bf_path_record *__restrict__ records) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    float *s_hist = reinterpret_cast<float *>(s_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool lds_hist = lp.lds_hist != 0;
+    if (lds_hist) {
+        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) s_hist[i] = 0.f;
+        __syncthreads();
+    }
+    const int cur = it & 1, nxt = cur ^ 1;
+    const uint32_t n_cur = wf.n_q[it];
+    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+    const uint32_t n_emit = sc.n_emitters;
+    const bool aperture = sc.sensor.type != BF_SENSOR_PERSPECTIVE;
+    const float sensor_w = sc.sensor.type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
+
+    FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
+    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0;
+
+    // static wave-granular partition of the queue: a device-wide queue head
+    // saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"),
+    // which throttled 64-ray batches; batches are plentiful per wave, so a
+    // grid-stride walk balances well without any atomic.
+    const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
+    for (uint32_t base = wave_id * 64u; base < n_cur; base += n_waves * 64u) {
+        const uint32_t i = base + lane;
+        const bool has = i < n_cur;
+
+        PathState s;
+        bool need_gen = false, cont = false, want_shadow = false;
+        V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 1);
+        float sh_mint = 0.f, sh_maxt = 0.f, sh_c = 0.f;
+
+        if (has) {
+            if (FIRST) {
+                need_gen = true;
+            } else {
+                load_state(wf, cur, i, s);
+                if (s.flags & kFlagTermPending) {
+                    // terminated after last bounce's BSDF sample; its NEE shadow ray has resolved by now
+                    film_put(lp, s, sensor_w, s_hist, g_hist, lds_hist, acc, records);
+                    need_gen = true;
+                } else {
+                    float4 hq = wf.hit[i];
+                    Hit hit;
+                    hit.t = hq.x;
+                    hit.u = hq.y;
+                    hit.v = hq.z;
+                    hit.slot = __float_as_int(hq.w);
+                    hit.prim = 0;
+                    SI si;
+                    const bool si_valid = hit.t != BF_INF;
+                    int emitter = -1;
+                    if (si_valid) {
+                        make_si(sc, s.ro, s.rd, hit, si);
+                        emitter = sc.shapes[si.shape].emitter;
+                    }
+                    uint32_t depth = s.flags & kDepthMask;
+                    if (depth == 0) {
+                        // first intersection — path.cpp:115-117, pathlength.cpp:138-146, pathtime.cpp:136-140
+                        if (si_valid) s.flags |= kFlagValid;
+                        if (is_range) s.aux += si_valid ? si.t : 0.f;
+                        if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
+                        depth = 1;
+                    } else {
+                        // tail of the previous iteration — path.cpp:184-209
+                        if (emitter >= 0) {
+                            const DEmitter &e = sc.emitters[emitter];
+                            float emitter_pdf = emitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n);
+                            if (n_emit != 1) emitter_pdf *= 1.f / (float) n_emit;
+                            s.emission_weight = mis_weight(s.bs_pdf, emitter_pdf);
+                        }
+                        if (is_range) s.aux += si_valid ? si.t : 0.f;
+                        if (is_time) s.aux += si_valid ? si.t / lp.time_c : 0.f;
+                        ++depth;
+                    }
+                    s.flags = (s.flags & ~kDepthMask) | (depth & kDepthMask);
+                    // head of iteration `depth` — path.cpp:121-145
+                    if (emitter >= 0) {
+                        const DEmitter &e = sc.emitters[emitter];
+                        float ev = (e.type == BF_EMITTER_SPOT) ? 0.f : ((si.wi.z > 0.f) ? e.radiance : 0.f);
+                        s.result += s.emission_weight * s.throughput * ev;
+                        if (is_range) s.aux += si_valid ? si.t : 0.f;       // pathlength.cpp:161
+                    }
+                    bool active = si_valid;
+                    if ((int) depth > lp.rr_depth) {
+                        float q = __builtin_fminf(s.throughput * sqr(s.eta), .95f);
+                        active = (next_1d(s.rng) < q) && active;
+                        s.throughput *= rcp(q);
+                    }
+                    if (depth >= (uint32_t) lp.max_depth || !active) {
+                        film_put(lp, s, sensor_w, s_hist, g_hist, lds_hist, acc, records);
+                        need_gen = true;
+                    } else {
+                        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+                        ++c_bounces;
+                        if (bsdf_smooth(mat)) {
+                            // Scene::sample_emitter_direction — scene.cpp:180-230
+                            float sx = next_1d(s.rng), sy = next_1d(s.rng);
+                            DirSample ds;
+                            ds.d = mk(0, 0, 1);
+                            ds.pdf = 0.f;
+                            ds.dist = 0.f;
+                            ds.delta = false;
+                            float emitter_val = 0.f;
+                            if (n_emit == 1) {
+                                emitter_val = emitter_sample_direction(sc, sc.emitters[0], si.p, sx, sy, ds);
+                            } else if (n_emit > 1) {
+                                float emitter_pdf = 1.f / (float) n_emit;
+                                uint32_t index = min((uint32_t) (sx * (float) n_emit), n_emit - 1u);
+                                sx = (sx - index * emitter_pdf) * (float) n_emit;
+                                emitter_val = emitter_sample_direction(sc, sc.emitters[index], si.p, sx, sy, ds);
+                                ds.pdf *= emitter_pdf;
+                                emitter_val *= rcp(emitter_pdf);
+                            }
+                            if (ds.pdf != 0.f) {
+                                // the shadow ray gates this contribution (scene.cpp:220-224)
+                                V3 wo = to_local(si.sh, ds.d);
+                                float bsdf_val, bsdf_pdf;
+                                bsdf_eval_pdf(mat, si.wi, wo, bsdf_val, bsdf_pdf);
+                                float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf);
+                                sh_c = mis * s.throughput * bsdf_val * emitter_val;
+                                sh_o = si.p;
+                                sh_d = ds.d;
+                                sh_mint = kRayEpsilon * (1.f + hmax_abs(si.p));
+                                sh_maxt = ds.dist * (1.f - kShadowEpsilon);
+                                want_shadow = true;
+                                ++s.n_rays;
+                                ++c_shadow;
+                            }
+                            if (is_range) s.aux += si.t;                    // pathlength.cpp:209
+                        }
+                        (void) next_1d(s.rng);                              // sample1 (unused by these BSDFs)
+                        float s2x = next_1d(s.rng), s2y = next_1d(s.rng);
+                        BSDFSample bs;
+                        float bsdf_val = bsdf_sample(mat, si.wi, s2x, s2y, bs);
+                        s.throughput = s.throughput * bsdf_val;
+                        cont = true;
+                        if (s.throughput == 0.f) {
+                            // path.cpp:171-173 break; the film write waits for the shadow ray
+                            s.flags |= kFlagTermPending;
+                            s.rmint = BF_INF;      // no closest-hit query for this slot
+                            s.rmaxt = 0.f;
+                        } else {
+                            s.eta *= bs.eta;
+                            // si.spawn_ray — interaction.h:61-64
+                            s.ro = si.p;
+                            s.rd = to_world(si.sh, bs.wo);
+                            s.rmint = (1.f + hmax_abs(si.p)) * kRayEpsilon;
+                            s.rmaxt = BF_INF;
+                            s.prev_p = si.p;
+                            s.bs_pdf = bs.pdf;
+                            ++s.n_rays;
+                            ++c_closest;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- regeneration: finished slots pull fresh paths -------------------
+        unsigned long long gmask = __ballot(need_gen);
+        if (gmask) {
+            unsigned long long pbase = 0;
+            if (lane == 0) pbase = atomicAdd(&wf.counters[CTR_NEXT_PATH], (unsigned long long) __popcll(gmask));
+            pbase = __shfl(pbase, 0);
+            if (need_gen) {
+                uint64_t path_i = pbase + __popcll(gmask & ((1ull << lane) - 1ull));
+                if (path_i < lp.n_paths) {
+                    // SamplingIntegrator::render_sample — integrator.cpp:259-283;
+                    // per-path stream seed(base_seed + path) (sampler.cpp:83-96)
+                    s.path_i = path_i;
+                    pcg_seed(s.rng, lp.seed + lp.path_offset + path_i);
+                    float fx = next_1d(s.rng), fy = next_1d(s.rng);
+                    float ax = .5f, ay = .5f;
+                    if (aperture) {
+                        ax = next_1d(s.rng);
+                        ay = next_1d(s.rng);
+                    }
+                    if (sc.sensor.shutter_open_time > 0.f) (void) next_1d(s.rng);
+                    (void) next_1d(s.rng);   // wavelength sample (consumed in RGB mode too)
+                    (void) sensor_sample_ray(sc, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
+                    // ImageBlock::put box branch: lo = ceil(pos - .5 - .5) must be 0
+                    bool film_ok = __builtin_ceilf((fx - .5f) - .5f) == 0.f && __builtin_ceilf((fy - .5f) - .5f) == 0.f;
+                    s.throughput = 1.f;
+                    s.eta = 1.f;
+                    s.emission_weight = 1.f;
+                    s.result = 0.f;
+                    s.aux = 0.f;
+                    s.bs_pdf = 0.f;
+                    s.prev_p = mk(0, 0, 0);
+                    s.flags = film_ok ? kFlagFilmOk : 0u;
+                    s.n_rays = 1;
+                    ++c_closest;
+                    cont = true;
+                }
+            }
+        }
+
+        // ---- compaction: survivors -> next queue, shadow rays -> shadow queue --
+        unsigned long long cmask = __ballot(cont);
+        uint32_t j = 0;
+        if (cmask) {
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&wf.n_q[it + 1], (uint32_t) __popcll(cmask));
+            qb = __shfl(qb, 0);
+            j = qb + __popcll(cmask & ((1ull << lane) - 1ull));
+            if (cont) store_state(wf, nxt, j, s);
+        }
+        unsigned long long smask = __ballot(want_shadow);
+        if (smask) {
+            uint32_t sb = 0;
+            if (lane == 0) sb = atomicAdd(&wf.n_sh[it], (uint32_t) __popcll(smask));
+            sb = __shfl(sb, 0);
+            if (want_shadow) {
+                uint32_t k = sb + __popcll(smask & ((1ull << lane) - 1ull));
+                wf.sh0[k] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_mint);
+                wf.sh1[k] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_maxt);
+                wf.sh2[k] = make_uint2(j, __float_as_uint(sh_c));
+            }
+        }
+    }
+
+    // ---- epilogue: wave-reduce the base channels, flush the histogram ------
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.X += __shfl_down(acc.X, off);
+        acc.Y += __shfl_down(acc.Y, off);
+        acc.Z += __shfl_down(acc.Z, off);
+        acc.A += __shfl_down(acc.A, off);
+        acc.W += __shfl_down(acc.W, off);
+    }
+    if (lane == 0 && acc.W != 0.f) {
+        wf_hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
+        wf_hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
+        wf_hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);
+        wf_hist_add(s_hist, g_hist, lds_hist, 3, acc.A);
+        wf_hist_add(s_hist, g_hist, lds_hist, 4, acc.W);
+    }
+    if (lds_hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
+            float v = s_hist[i];
+            if (v != 0.f) atomicAdd(&g_hist[i], v);
+        }
+    }
+    unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v_closest += __shfl_down(v_closest, off);
+        v_shadow += __shfl_down(v_shadow, off);
+        v_invalid += __shfl_down(v_invalid, off);
+        v_bounces += __shfl_down(v_bounces, off);
+    }
+    if (lane == 0) {
+        if (v_closest) atomicAdd(&wf.counters[CTR_CLOSEST], v_closest);
+        if (v_shadow) atomicAdd(&wf.counters[CTR_SHADOW], v_shadow);
+        if (v_invalid) atomicAdd(&wf.counters[CTR_INVALID], v_invalid);
+        if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
+    }
+}
+
+// Persistent-wave traversal with dynamic ray replacement: each wave owns a
+// contiguous segment of the job list (shadow rays first, then closest-hit
+// rays); a lane whose ray has finished takes the next job of the segment as
+// soon as the wave's occupancy drops below kRefill lanes (__ballot/__popcll
+// prefix, no atomics), so the wave's cost tracks the SUM of its rays'
+// traversal steps instead of 64 x the longest one.
+constexpr int kRefill = 44;
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void wf_trace(DScene sc, WF wf, uint32_t it) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int *stack = s_stack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int nxt = (it & 1) ^ 1;
+    const uint32_t n_sh = wf.n_sh[it], n_ext = wf.n_q[it + 1];
+    const uint32_t total = n_sh + n_ext;
+    uint32_t c_nodes = 0, c_tris = 0;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    // segment per wave, multiple of 64 so that the first fetch of each wave is a coalesced 1 KiB read
+    uint32_t seg = (uint32_t) (((uint64_t) total + n_waves - 1) / n_waves);
+    seg = (seg + 63u) & ~63u;
+    uint64_t sb64 = (uint64_t) wave_id * seg;
+    uint32_t next = (uint32_t) (sb64 < total ? sb64 : total);
+    const uint32_t seg_end = (uint32_t) ((sb64 + seg) < total ? (sb64 + seg) : total);
+
+    bool has = false, any = false;
+    uint32_t job = 0;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), id = mk(0, 0, 0);
+    float mint = 0.f, maxt = 0.f;
+    Hit best;
+    best.t = BF_INF;
+    best.u = best.v = 0.f;
+    best.prim = 0;
+    best.slot = 0;
+    int node = 0, sp = 0;
+    bool found = false;      // any-hit result
+
+    while (true) {
+        // ---- refill idle lanes from the wave's segment -------------------------
+        unsigned long long idle = __ballot(!has);
+        if (idle && next < seg_end) {
+            uint32_t k = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+            next += (uint32_t) __popcll(idle);
+            if (!has && k < seg_end) {
+                job = k;
+                float4 r0, r1;
+                if (k < n_sh) {
+                    r0 = wf.sh0[k];
+                    r1 = wf.sh1[k];
+                    any = true;
+                } else {
+                    r0 = wf.ray0[nxt][k - n_sh];
+                    r1 = wf.ray1[nxt][k - n_sh];
+                    any = false;
+                }
+                o = mk(r0.x, r0.y, r0.z);
+                d = mk(r1.x, r1.y, r1.z);
+                mint = r0.w;
+                maxt = r1.w;
+                best.t = BF_INF;
+                best.u = best.v = 0.f;
+                best.prim = 0;
+                best.slot = 0;
+                found = false;
+                has = true;
+                bool live = mint <= maxt;       // TERM_PENDING slots carry an empty interval
+                if (live) {
+                    for (uint32_t i = 0; i < sc.n_rects; ++i) {
+                        const DRect &rc = sc.rects[i];
+                        float t, lx, ly;
+                        if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
+                            if (any)
+                                found = true;
+                            else
+                                consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
+                        }
+                    }
+                }
+                id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                node = sc.root;
+                sp = 0;
+                if (!live || sc.n_tris == 0 || (any && found)) node = INT32_MIN;   // nothing to traverse
+            }
+        }
+        if (__ballot(has) == 0ull) break;
+
+        // ---- traversal steps until the wave thins out ----------------------------
+        while (true) {
+            if (has) {
+                bool finished = false;
+                if (node == INT32_MIN) {
+                    finished = true;
+                } else {
+                    if (node >= 0) {
+                        const float4 *np = sc.nodes + 4 * (size_t) node;
+                        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                        if (STATS) ++c_nodes;
+                        float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
+                        float tn0, tn1;
+                        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
+                        bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
+                        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                        if (h0 && h1) {
+                            if (tn1 < tn0) {
+                                int tmp = c0;
+                                c0 = c1;
+                                c1 = tmp;
+                            }
+                            stack[sp * kBlock] = c1;
+                            ++sp;
+                            node = c0;
+                        } else if (h0) {
+                            node = c0;
+                        } else if (h1) {
+                            node = c1;
+                        } else if (sp == 0) {
+                            finished = true;
+                        } else {
+                            --sp;
+                            node = stack[sp * kBlock];
+                        }
+                    } else {
+                        uint32_t enc = ~(uint32_t) node;
+                        uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            const float4 *tp = sc.tris + 3 * (size_t) (first + i);
+                            float4 a = tp[0], b = tp[1], c = tp[2];
+                            if (STATS) ++c_tris;
+                            float t, u, v;
+                            if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u,
+                                              v)) {
+                                if (any) {
+                                    found = true;
+                                    break;
+                                }
+                                consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
+                            }
+                        }
+                        if ((any && found) || sp == 0) {
+                            finished = true;
+                        } else {
+                            --sp;
+                            node = stack[sp * kBlock];
+                        }
+                    }
+                }
+                if (finished) {
+                    if (any) {
+                        // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
+                        if (!found) {
+                            uint2 e = wf.sh2[job];
+                            float4 a = wf.sa[nxt][e.x];
+                            a.w += __uint_as_float(e.y);
+                            wf.sa[nxt][e.x] = a;
+                        }
+                    } else {
+                        wf.hit[job - n_sh] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
+                    }
+                    has = false;
+                }
+            }
+            unsigned long long act = __ballot(has);
+            if (act == 0ull) break;
+            if (next < seg_end && __popcll(act) <= kRefill) break;
+        }
+    }
+    if (STATS) {
+        unsigned long long v_nodes = c_nodes, v_tris = c_tris;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v_nodes += __shfl_down(v_nodes, off);
+            v_tris += __shfl_down(v_tris, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&wf.counters[CTR_NODES], v_nodes);
+            atomicAdd(&wf.counters[CTR_TRIS], v_tris);
+        }
+    }
+}
+
+}  // namespace bfd
+
+extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
+                                   float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
+                                   hipStream_t stream) {
+    if (first)
+        hipLaunchKernelGGL(bfd::wf_shade<true>, dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist,
+                           records);
+    else
+        hipLaunchKernelGGL(bfd::wf_shade<false>, dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist,
+                           records);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
+                                   hipStream_t stream) {
+    if (stats)
+        hipLaunchKernelGGL(bfd::wf_trace<true>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);
+    else
+        hipLaunchKernelGGL(bfd::wf_trace<false>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);
+    return hipGetLastError();
+}

@@ -11,7 +11,7 @@ the RCCL all-reduce of the per-GPU range histograms.  Weak scaling: per-GPU
 work is fixed; GPU g renders global path indices [g*P, (g+1)*P) via
 bf_launch.path_offset, so the union is one sample set.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: bf_render_kernel)
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: wf_trace)
 and `cpu_baseline` (the CPU oracle, a port of the reference's scalar path,
 timed on this box's host cores on a bounded sample of the same workload).
 """
@@ -99,11 +99,17 @@ def main():
     rays = 0
     paths = 0
     kernel_ms = 0.0
+    trace_ms = shade_ms = tail_ms = 0.0
+    trace_launches = 0
     for i in range(args.steps):
         st = step(i)
         rays += st.n_rays_closest + st.n_rays_shadow
         paths += st.n_paths
         kernel_ms += st.kernel_ms
+        trace_ms += st.trace_ms
+        shade_ms += st.shade_ms
+        tail_ms += st.tail_ms
+        trace_launches += st.n_launches_trace
     sync()
     dt = time.perf_counter() - t0
 
@@ -121,9 +127,11 @@ def main():
     out = None
     if rank == 0:
         mrays = rays_all / dt / 1e6
-        avg_kernel_s = kernel_ms / args.steps / 1e3
-        rays_per_launch = rays / args.steps
-        achieved = b_ray * rays_per_launch / avg_kernel_s / 1e9
+        # dominant kernel = wf_trace (BVH traversal): HIP events bracket every one
+        # of its launches on the launch stream; a step issues one launch per bounce
+        avg_launch_s = trace_ms / max(trace_launches, 1) / 1e3
+        rays_per_launch = rays / max(trace_launches, 1)
+        achieved = b_ray * rays_per_launch / avg_launch_s / 1e9
         out = {
             "metric": "Mrays/s (closest + any-hit BVH queries), Bus.obj-class radar scene",
             "value": round(mrays, 2),
@@ -152,7 +160,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "bf_render_kernel",
+                "kernel": "wf_trace",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -162,7 +170,11 @@ def main():
                 "nodes_per_ray": round(v_n, 2),
                 "tris_per_ray": round(v_t, 2),
                 "rays_per_launch": int(rays_per_launch),
-                "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "launches_per_step": round(trace_launches / args.steps, 2),
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "per_step_ms": {"wf_trace": round(trace_ms / args.steps, 3), "wf_shade": round(shade_ms / args.steps, 3),
+                                "tail": round(tail_ms / args.steps, 3), "all_kernels": round(kernel_ms / args.steps, 3)},
+                "whole_pipeline_frac": round(b_ray * rays / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
             },
         }
         if not args.no_cpu:

@@ -177,7 +177,9 @@ typedef struct bf_launch {
 
 enum {
     BF_FLAG_STATS = 1u,       /* count BVH nodes visited / triangles tested   */
-    BF_FLAG_GLOBAL_ATOMICS = 2u /* skip LDS privatisation (debug / ablation)  */
+    BF_FLAG_GLOBAL_ATOMICS = 2u, /* skip LDS privatisation (debug / ablation) */
+    BF_FLAG_MEGAKERNEL = 4u    /* single persistent megakernel instead of the
+                                  wavefront pipeline (ablation; same results) */
 };
 
 /* per-path record for exact parity tests (optional output) */
@@ -196,7 +198,12 @@ typedef struct bf_stats {
     uint64_t n_tris_tested;    /* only with BF_FLAG_STATS                     */
     uint64_t n_invalid;        /* samples dropped by ImageBlock::put's checks */
     uint64_t n_bounces;        /* path vertices shaded                        */
-    float    kernel_ms;        /* HIP-event time of the render kernels        */
+    float    kernel_ms;        /* HIP-event time of the whole render (all kernels) */
+    float    trace_ms;         /* sum of the BVH traversal kernel launches (wf_trace) */
+    float    shade_ms;         /* sum of the shading kernel launches (wf_shade)     */
+    float    tail_ms;          /* tail kernel                                       */
+    uint32_t n_launches_trace; /* wf_trace launches in this render                  */
+    uint32_t n_bounce_iters;   /* wavefront iterations executed                     */
 } bf_stats;
 
 typedef struct bf_scene_info {

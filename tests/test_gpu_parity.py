@@ -97,10 +97,21 @@ def test_trace_mixed_rect_and_mesh_scene(hiplib):
 
 
 def _render_compare(sd, lp, hist_rtol=2e-5):
-    g = capi.Scene(sd)
+    """Both device pipelines (wavefront = default, megakernel = ablation flag)
+    against the oracle."""
     o = OracleScene(sd)
+    oracle_out = o.render(lp, records=True, threads=8)
+    g = capi.Scene(sd)
+    flags0 = lp.flags
+    lp.flags = flags0 | capi.BF_FLAG_MEGAKERNEL
+    _render_compare_one(g, lp, oracle_out, hist_rtol)
+    lp.flags = flags0
+    return _render_compare_one(g, lp, oracle_out, hist_rtol)
+
+
+def _render_compare_one(g, lp, oracle_out, hist_rtol):
     hg, rg, sg = g.render(lp, records=True)
-    ho, ro, so = o.render(lp, records=True, threads=8)
+    ho, ro, so = oracle_out
     # integer counters and per-path results: exact
     assert np.array_equal(rg["n_rays"], ro["n_rays"])
     assert np.array_equal(rg["valid"], ro["valid"])
