@@ -558,6 +558,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         stats_out->n_tris_tested = c[bfd::CTR_TRIS];
         stats_out->n_invalid = c[bfd::CTR_INVALID];
         stats_out->n_bounces = c[bfd::CTR_BOUNCES];
+        stats_out->n_rays_tail = c[bfd::CTR_TAIL_RAYS];
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         stats_out->kernel_ms = ms;

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(kBlock) void bf_render_kernel(DScene sc, DLaunch lp
     if (lane == 0) {
         atomicAdd(&counters[CTR_CLOSEST], v_closest);
         atomicAdd(&counters[CTR_SHADOW], v_shadow);
+        if (RESUME) atomicAdd(&counters[CTR_TAIL_RAYS], v_closest + v_shadow);
         if (STATS) {
             atomicAdd(&counters[CTR_NODES], v_nodes);
             atomicAdd(&counters[CTR_TRIS], v_tris);

@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--paths", type=int, default=1 << 24, help="paths per GPU per step")
     ap.add_argument("--tris", type=int, default=200_000)
-    ap.add_argument("--cpu-paths", type=int, default=1 << 21, help="bounded sample for the CPU baseline")
+    ap.add_argument("--cpu-paths", type=int, default=1 << 26, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -101,6 +101,7 @@ def main():
     kernel_ms = 0.0
     trace_ms = shade_ms = tail_ms = 0.0
     trace_launches = 0
+    rays_trace = 0
     for i in range(args.steps):
         st = step(i)
         rays += st.n_rays_closest + st.n_rays_shadow
@@ -110,6 +111,7 @@ def main():
         shade_ms += st.shade_ms
         tail_ms += st.tail_ms
         trace_launches += st.n_launches_trace
+        rays_trace += st.n_rays_closest + st.n_rays_shadow - st.n_rays_tail
     sync()
     dt = time.perf_counter() - t0
 
@@ -130,7 +132,7 @@ def main():
         # dominant kernel = wf_trace (BVH traversal): HIP events bracket every one
         # of its launches on the launch stream; a step issues one launch per bounce
         avg_launch_s = trace_ms / max(trace_launches, 1) / 1e3
-        rays_per_launch = rays / max(trace_launches, 1)
+        rays_per_launch = rays_trace / max(trace_launches, 1)
         achieved = b_ray * rays_per_launch / avg_launch_s / 1e9
         out = {
             "metric": "Mrays/s (closest + any-hit BVH queries), Bus.obj-class radar scene",

@@ -204,6 +204,7 @@ typedef struct bf_stats {
     float    tail_ms;          /* tail kernel                                       */
     uint32_t n_launches_trace; /* wf_trace launches in this render                  */
     uint32_t n_bounce_iters;   /* wavefront iterations executed                     */
+    uint64_t n_rays_tail;      /* rays traced by the tail kernel (not by wf_trace)   */
 } bf_stats;
 
 typedef struct bf_scene_info {
