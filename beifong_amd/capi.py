@@ -55,7 +55,7 @@ class bf_sensor(C.Structure):
                 ("adc_sampling_start", C.c_float), ("adc_sampling_time", C.c_float),
                 ("t_bins", C.c_uint32), ("f_bins", C.c_uint32),
                 ("t_bandwidth", C.c_float), ("f_bandwidth", C.c_float),
-                ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float)]
+                ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32)]
 
 
 class bf_physics(C.Structure):
@@ -72,7 +72,7 @@ class bf_scene_desc(C.Structure):
 class bf_launch(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("color_mode", C.c_uint32), ("n_paths", C.c_uint64),
                 ("path_offset", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_int32),
-                ("rr_depth", C.c_int32), ("bins", C.c_uint32), ("bin_width", C.c_float),
+                ("rr_depth", C.c_int32), ("bins", C.c_uint32), ("bins_y", C.c_uint32), ("bin_width", C.c_float),
                 ("time_c", C.c_float), ("flags", C.c_uint32)]
 
 
@@ -155,10 +155,11 @@ def _ptr(a):
 
 
 def make_launch(mode, n_paths, seed=0, path_offset=0, bins=0, bin_width=0.0, color_mode=BF_COLOR_RGB,
-                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0):
+                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0, bins_y=0):
     lp = bf_launch()
     lp.mode, lp.color_mode, lp.n_paths, lp.path_offset, lp.seed = mode, color_mode, n_paths, path_offset, seed
     lp.max_depth, lp.rr_depth, lp.bins, lp.bin_width, lp.time_c, lp.flags = max_depth, rr_depth, bins, bin_width, time_c, flags
+    lp.bins_y = bins_y
     return lp
 
 

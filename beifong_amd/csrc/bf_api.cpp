@@ -94,6 +94,7 @@ struct bf_scene {
     bf_scene_info info;
     int device = 0;
     int n_cus = 256;
+    std::vector<uint32_t> emitter_types;
     // per-scene scratch for bf_render_device (counters), allocated once
     unsigned long long *counters = nullptr;
     // wavefront workspace, allocated on first use (mutable: lazily grown cache)
@@ -128,7 +129,7 @@ uint32_t bf_launch_channels(const bf_launch *lp) {
         case BF_MODE_PATH: return 5;
         case BF_MODE_RANGE: return 5 + lp->bins;
         case BF_MODE_TIME: return 5 + 3 * lp->bins;
-        case BF_MODE_RECEIVE_RAW: return 3;
+        case BF_MODE_RECEIVE_RAW: return 3 * lp->bins * lp->bins_y;
     }
     return 0;
 }
@@ -190,6 +191,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             float area = std::sqrt(dot(c, c));
             if (!(area > 0.f) || !std::isfinite(area)) return fail(BF_ERR_INVALID, "shape %u: degenerate rectangle", i);
             rc.inv_area = 1.f / area;
+            rc.area = area;
             rc.shape = i;
             rc.prim = prim;
             ds.rect = (int32_t) rects.size();
@@ -241,10 +243,21 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             de.inv_transition = 1.0f / (de.cutoff - de.beam);
             de.cos_cutoff = (float) std::cos((double) de.cutoff);
             de.cos_beam = (float) std::cos((double) de.beam);
-        } else if (e.type == BF_EMITTER_AREA) {
+        } else if (e.type == BF_EMITTER_AREA || e.type == BF_TRANSMITTER_AREA || e.type == BF_TRANSMITTER_WIGNER) {
             if (e.shape < 0 || e.shape >= (int32_t) desc->n_shapes || desc->shapes[e.shape].type != BF_SHAPE_RECTANGLE)
-                return fail(BF_ERR_UNSUPPORTED, "emitter %u: area emitters must sit on a rectangle", i);
+                return fail(BF_ERR_UNSUPPORTED, "emitter %u: area emitters / transmitters must sit on a rectangle", i);
             de.rect = shapes[e.shape].rect;
+            if (e.type == BF_TRANSMITTER_WIGNER) {
+                if (e.resample_freq) return fail(BF_ERR_UNSUPPORTED, "emitter %u: resample_freq=true is not supported", i);
+                if (e.signal_type > BF_SIGNAL_LINFMCW) return fail(BF_ERR_INVALID, "emitter %u: unknown signal type", i);
+                de.signal_type = e.signal_type;
+                de.amplitude = e.amplitude;
+                de.freq_centre = e.freq_centre;
+                de.freq_ext = e.freq_ext;
+                de.pulse_len = e.pulse_len;
+                de.prf = e.prf;
+                de.gain = e.gain;
+            }
         } else {
             return fail(BF_ERR_UNSUPPORTED, "emitter %u: type %u not supported by this build", i, e.type);
         }
@@ -259,13 +272,24 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     bfd::DSensor &sen = sc->d.sensor;
     sen.type = desc->sensor.type;
     sen.rect = -1;
-    if (desc->sensor.type == BF_SENSOR_FLUXMETER) {
+    if (desc->sensor.type == BF_SENSOR_FLUXMETER || desc->sensor.type == BF_RECEIVER_OMNI ||
+        desc->sensor.type == BF_RECEIVER_WIGNER) {
         int32_t sh = desc->sensor.shape;
         if (sh < 0 || sh >= (int32_t) desc->n_shapes || desc->shapes[sh].type != BF_SHAPE_RECTANGLE) {
             delete sc;
-            return fail(BF_ERR_UNSUPPORTED, "fluxmeter must sit on a rectangle");
+            return fail(BF_ERR_UNSUPPORTED, "fluxmeter / receiver must sit on a rectangle");
         }
         sen.rect = shapes[sh].rect;
+        sen.adc_sampling_start = desc->sensor.adc_sampling_start;
+        sen.adc_sampling_time = desc->sensor.adc_sampling_time;
+        sen.t_bins = desc->sensor.t_bins;
+        sen.f_bins = desc->sensor.f_bins;
+        sen.t_bandwidth = desc->sensor.t_bandwidth;
+        sen.f_bandwidth = desc->sensor.f_bandwidth;
+        sen.freq_centre = desc->sensor.freq_centre;
+        sen.freq_ext = desc->sensor.freq_ext;
+        sen.gain = desc->sensor.gain;
+        sen.rx_sig_is_delta = desc->sensor.rx_sig_is_delta;
     } else if (desc->sensor.type == BF_SENSOR_PERSPECTIVE) {
         m34(desc->sensor.to_world, sen.to_world);
         std::memcpy(sen.sample_to_camera, desc->sensor.sample_to_camera, 16 * sizeof(float));
@@ -327,8 +351,12 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->d.n_tris = (uint32_t) btris.size();
     sc->d.n_rects = (uint32_t) rects.size();
     sc->d.n_emitters = (uint32_t) emitters.size();
+    for (const auto &e : emitters) sc->emitter_types.push_back(e.type);
     sc->d.n_nodes = (uint32_t) bvh.nodes.size();
     sc->d.root = bvh.root_child;
+    sc->d.c = desc->physics.c;
+    sc->d.lambda_min = desc->physics.lambda_min_nm;
+    sc->d.lambda_max = desc->physics.lambda_max_nm;
 
     hipError_t e = hipMalloc((void **) &sc->counters, sizeof(unsigned long long) * bfd::CTR_COUNT);
     if (e != hipSuccess) {
@@ -391,6 +419,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
         HIP_TRY(alloc((void **) &wf.sb[b], n * 16));
         HIP_TRY(alloc((void **) &wf.sc[b], n * 16));
         HIP_TRY(alloc((void **) &wf.sd[b], n * 16));
+        HIP_TRY(alloc((void **) &wf.se[b], n * 16));
     }
     HIP_TRY(alloc((void **) &wf.hit, n * 16));
     HIP_TRY(alloc((void **) &wf.sh0, n * 16));
@@ -501,7 +530,21 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
                            void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
-    if (launch->mode == BF_MODE_RECEIVE_RAW) return fail(BF_ERR_UNSUPPORTED, "receive mode is not built yet");
+    const bool is_rx = scene->d.sensor.type == BF_RECEIVER_OMNI || scene->d.sensor.type == BF_RECEIVER_WIGNER;
+    if (launch->mode == BF_MODE_RECEIVE_RAW) {
+        if (!is_rx) return fail(BF_ERR_INVALID, "receive mode needs a receiver (omnidirectional / wigner)");
+        if (launch->bins != scene->d.sensor.t_bins || launch->bins_y != scene->d.sensor.f_bins)
+            return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size (%u x %u)", launch->bins,
+                        launch->bins_y, scene->d.sensor.t_bins, scene->d.sensor.f_bins);
+        for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
+            if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER)
+                return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);
+    } else {
+        if (is_rx) return fail(BF_ERR_INVALID, "render modes need a sensor (fluxmeter / perspective), not a receiver");
+        for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
+            if (scene->emitter_types[i] != BF_EMITTER_SPOT && scene->emitter_types[i] != BF_EMITTER_AREA)
+                return fail(BF_ERR_INVALID, "render modes: emitter %u is a transmitter (use receive mode)", i);
+    }
     if (launch->mode > BF_MODE_RECEIVE_RAW) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);
     if ((launch->mode == BF_MODE_RANGE || launch->mode == BF_MODE_TIME) && (launch->bins == 0 || !(launch->bin_width > 0.f)))
         return fail(BF_ERR_INVALID, "range/time mode needs bins > 0 and bin_width > 0");
@@ -516,6 +559,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     lp.max_depth = launch->max_depth;
     lp.rr_depth = launch->rr_depth;
     lp.bins = launch->bins;
+    lp.bins_y = launch->bins_y;
     lp.bin_width = launch->bin_width;
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);

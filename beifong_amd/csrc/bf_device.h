@@ -26,6 +26,7 @@ struct DRect {
     float to_object[12];
     float s[3], t[3], n[3];   // Rectangle::update frame (dp_du, dp_dv, normal)
     float inv_area;
+    float area;           // Rectangle::surface_area()
     uint32_t shape;
     uint32_t prim;        // global primitive index
 };
@@ -41,6 +42,9 @@ struct DEmitter {
     int32_t rect;         // area types: rectangle index
     float to_world[12], to_object[12];
     float radiance, cutoff, beam, inv_transition, cos_cutoff, cos_beam;
+    // wigner transmitter signal model (wignertransmitter.cpp:53-110)
+    uint32_t signal_type;
+    float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
 };
 
 struct DSensor {
@@ -49,6 +53,12 @@ struct DSensor {
     float to_world[12];
     float sample_to_camera[16];
     float near_clip, far_clip, shutter_open, shutter_open_time;
+    // receiver + ADC (receiver.cpp:16-62, adc.cpp:18-46, wignerreceiver.cpp)
+    float adc_sampling_start, adc_sampling_time;
+    uint32_t t_bins, f_bins;
+    float t_bandwidth, f_bandwidth;
+    float freq_centre, freq_ext, gain;
+    uint32_t rx_sig_is_delta;
 };
 
 struct DScene {
@@ -61,6 +71,7 @@ struct DScene {
     const DEmitter *emitters;
     uint32_t n_tris, n_rects, n_emitters, n_nodes;
     int32_t root;             // child reference of the BVH root
+    float c, lambda_min, lambda_max;   // MTS_C, MTS_WAVELENGTH_MIN/MAX as run-time physics
     DSensor sensor;
 };
 
@@ -68,7 +79,7 @@ struct DLaunch {
     uint32_t mode, color_mode;
     uint64_t n_paths, path_offset, seed;
     int32_t max_depth, rr_depth;
-    uint32_t bins;
+    uint32_t bins, bins_y;
     float bin_width, time_c;
     uint32_t n_chan;
     uint32_t lds_hist;        // 1: histogram privatised in LDS

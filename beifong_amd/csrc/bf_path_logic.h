@@ -1,0 +1,522 @@
+// The integrator's per-path logic, shared verbatim by the wavefront shade
+// kernel (bf_wavefront.hip) and the megakernel / tail kernel (bf_kernels.hip):
+//
+//   generate_path : SamplingIntegrator::render_sample / receive_sample head
+//                   (integrator.cpp:259-283, 1538-1572) — sampler draws and the
+//                   sensor / receiver ray
+//   shade_vertex  : one iteration of PathIntegrator::sample (path.cpp:121-209),
+//                   PathLengthIntegrator (pathlength.cpp), PathTimeIntegrator
+//                   (pathtime.cpp) or PathTimeFrequencyIntegrator
+//                   (pathtimefrequency.cpp:154-447), given the closest hit of the
+//                   path's current ray
+//   film_put      : render_sample / receive_sample tail + range/time AOVs +
+//                   ImageBlock::put / SignalBlock::put (box filter)
+//
+// The NEE contribution is computed BEFORE its shadow ray is traced and handed
+// to the caller (ShadowReq), which adds it to PathState::result iff the ray is
+// unoccluded — the same value the reference adds (scene.cpp:220-224 zeroes the
+// emitter value of an occluded sample).
+#pragma once
+#include "bf_device_core.h"
+#include "bf_wavefront.h"
+
+namespace bfd {
+
+constexpr uint32_t kFlagValid = 1u << 24, kFlagFilmOk = 1u << 25, kFlagTermPending = 1u << 26, kDepthMask = 0xffffffu;
+
+struct PathState {
+    V3 ro, rd;
+    float rmint, rmaxt;
+    float throughput, eta, emission_weight, result;
+    float aux, bs_pdf;
+    V3 prev_p;
+    uint32_t flags;      // depth | kFlag*
+    uint32_t n_rays;
+    Rng rng;
+    uint64_t path_i;
+    // gen-3 (receive) only
+    float time;          // ray.time: retarded time carried along the path (ray.h:89-93)
+    float t_rx;          // sampled receive time (integrator.cpp:1556-1561)
+    float lambda0;       // ray.wavelengths[0] in nm
+};
+
+BF_DEV void load_state(const WF &wf, int b, uint32_t i, bool receive, PathState &s) {
+    float4 r0 = wf.ray0[b][i], r1 = wf.ray1[b][i], a = wf.sa[b][i], bb = wf.sb[b][i];
+    uint4 c = wf.sc[b][i], d = wf.sd[b][i];
+    s.ro = mk(r0.x, r0.y, r0.z);
+    s.rmint = r0.w;
+    s.rd = mk(r1.x, r1.y, r1.z);
+    s.rmaxt = r1.w;
+    s.throughput = a.x;
+    s.eta = a.y;
+    s.emission_weight = a.z;
+    s.result = a.w;
+    s.aux = bb.x;
+    s.bs_pdf = bb.y;
+    s.prev_p = mk(bb.z, bb.w, __uint_as_float(c.x));
+    s.flags = c.y;
+    s.n_rays = c.z;
+    s.rng.state = ((uint64_t) d.y << 32) | d.x;
+    s.path_i = ((uint64_t) d.w << 32) | d.z;
+    s.time = s.t_rx = s.lambda0 = 0.f;
+    if (receive) {
+        float4 e = wf.se[b][i];
+        s.time = e.x;
+        s.t_rx = e.y;
+        s.lambda0 = e.z;
+    }
+}
+BF_DEV void store_state(const WF &wf, int b, uint32_t j, bool receive, const PathState &s) {
+    wf.ray0[b][j] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
+    wf.ray1[b][j] = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
+    wf.sa[b][j] = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
+    wf.sb[b][j] = make_float4(s.aux, s.bs_pdf, s.prev_p.x, s.prev_p.y);
+    wf.sc[b][j] = make_uint4(__float_as_uint(s.prev_p.z), s.flags, s.n_rays, 0u);
+    wf.sd[b][j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
+                             (uint32_t) (s.path_i >> 32));
+    if (receive) wf.se[b][j] = make_float4(s.time, s.t_rx, s.lambda0, 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// gen-3 building blocks: "Jacob functions" (math.h:62-131), the rectangular
+// aperture Wigner gain (rectangle.cpp:132-220), the transmitter signal model
+// (wignertransmitter.cpp:111-146).  A literal `1e-9` is a double in the
+// reference, so those products run in double here too.
+// ---------------------------------------------------------------------------
+BF_DEV float jabs(float x) { return x >= 0.f ? x : -x; }
+BF_DEV float sinc_j(float x) { return jabs(x) > kEpsilon ? sin_cr(x) / x : 1.f; }
+BF_DEV float tri_j(float x) { return jabs(x) < 0.5f ? 1.f - 2.f * jabs(x) : 0.f; }
+BF_DEV float rect_j(float x) { return jabs(x) < 0.5f ? 1.f : 0.f; }
+BF_DEV float fmodulo_j(float a, float b) {
+    float result = jabs(a);
+    int guard = 0;
+    while (result - jabs(b) >= kEpsilon && guard++ < (1 << 22)) result -= jabs(b);
+    result = (a < 0.f) ? jabs(b) - result : result;
+    result += (b < 0.f) ? b : 0.f;
+    return result;
+}
+BF_DEV float wchirp_j(float t, float f, float w, float a) {
+    return 2 * a * a * w * tri_j(t / w) * sinc_j(6.28318530717958647692f * f * w * tri_j(t / w));
+}
+BF_DEV float rect_sample_wigner(const DRect &rc, V3 p, V3 d, float lambda_nm) {
+    const float kTwoPi = 6.28318530717958647692f;
+    V3 fs = mk(rc.s[0], rc.s[1], rc.s[2]), ft = mk(rc.t[0], rc.t[1], rc.t[2]), fn = mk(rc.n[0], rc.n[1], rc.n[2]);
+    float wid_x = norm(fs), wid_y = norm(ft);
+    V3 r_hat = xf_point(rc.to_object, p) / 2.f;
+    V3 ns = normalize(fs), nt = normalize(ft);
+    (void) fn;
+    float lx = dot(ns, d), ly = dot(nt, d);
+    double inv = 1.0 / ((double) lambda_nm * 1e-9);
+    float nu_x = (float) ((double) lx * inv), nu_y = (float) ((double) ly * inv);
+    return 4 * tri_j(r_hat.x) * tri_j(r_hat.y) * sinc_j(kTwoPi * nu_x * wid_x * tri_j(r_hat.x)) *
+           sinc_j(kTwoPi * nu_y * wid_y * tri_j(r_hat.y));
+}
+BF_DEV float tx_eval_signal(const DEmitter &e, float time, float frequency) {
+    if (e.signal_type == BF_SIGNAL_LINFMCW) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        float fi = e.freq_centre + (e.freq_ext / e.pulse_len) * (t - ti);
+        return rect_j((t - ti) / e.pulse_len) > 0.f ? wchirp_j(t - ti, frequency - fi, e.pulse_len, e.amplitude) : 0.f;
+    } else if (e.signal_type == BF_SIGNAL_PULSE) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        float fi = e.freq_centre;
+        return rect_j((t - ti) / e.pulse_len) > 0.f ? wchirp_j(t - ti, frequency - fi, e.pulse_len, e.amplitude) : 0.f;
+    }
+    return e.amplitude * e.amplitude;
+}
+BF_DEV float freq_of(float c, float lambda_nm) { return (float) ((double) c * (1.0 / ((double) lambda_nm * 1e-9))); }
+
+// Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
+BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si, float si_time, float lambda0) {
+    const DRect &rc = sc.rects[e.rect];
+    if (e.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.radiance * rc.area : 0.f;
+    float signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
+    float ws = rect_sample_wigner(rc, si.p, mk(0.f, 0.f, 0.f), lambda0);   // Q5: ds.d never initialised -> 0
+    return (si.wi.z > 0.f) ? signal_power * e.gain * (1.f * ws) * 6.28318530717958647692f : 0.f;
+}
+// Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
+BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float ref_time, float lambda0,
+                                          float sx, float sy, DirSample &ds) {
+    const DRect &rc = sc.rects[e.rect];
+    V3 p = xf_point(rc.to_world, mk(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
+    V3 n = mk(rc.n[0], rc.n[1], rc.n[2]);
+    ds.pdf = rc.inv_area;
+    ds.delta = false;
+    ds.d = p - ref_p;
+    float dist_squared = squared_norm(ds.d);
+    ds.dist = __builtin_sqrtf(dist_squared);
+    ds.d = ds.d / ds.dist;
+    float dp = __builtin_fabsf(dot(ds.d, n));
+    ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+    bool active = dot(ds.d, n) < 0.f && ds.pdf != 0.f;
+    if (e.type == BF_TRANSMITTER_AREA) {
+        float spec = e.radiance / ds.pdf;
+        return active ? spec : 0.f;
+    }
+    float geom_gain = 1.f / ds.pdf;
+    float t = ref_time;
+    if ((double) ds.dist > 5e-7) t += -ds.dist / sc.c;                      // retarded time :422-425
+    float signal_power = tx_eval_signal(e, t, freq_of(sc.c, lambda0));
+    float ws = rect_sample_wigner(rc, p, -ds.d, lambda0);
+    geom_gain *= ws;
+    ds.pdf *= ws;
+    float extents = rcp(rc.area) * 6.28318530717958647692f;
+    return active ? signal_power * e.gain * geom_gain * extents : 0.f;
+}
+// Transmitter::pdf_direction — areatransmitter.cpp:167-186, wignertransmitter.cpp:540-577
+BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit, float lambda0) {
+    const DRect &rc = sc.rects[e.rect];
+    V3 d = p_hit - p_ref;
+    float dist = norm(d);
+    d = d / dist;
+    float dp = dot(d, n_hit);
+    float value = rc.inv_area, adp = __builtin_fabsf(dot(d, n_hit));
+    value *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
+    if (e.type == BF_TRANSMITTER_WIGNER) value *= rect_sample_wigner(rc, p_hit, -d, lambda0);
+    return (dp < 0.f) ? value : 0.f;
+}
+
+// Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
+BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
+                                 float &mint, float &maxt, float &lambda0) {
+    const DSensor &s = sc.sensor;
+    const DRect &rc = sc.rects[s.rect];
+    o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
+    V3 local = square_to_cosine_hemisphere(ax, ay);
+    Frame f;
+    f.n = mk(rc.n[0], rc.n[1], rc.n[2]);
+    coordinate_system(f.n, f.s, f.t);
+    d = to_world(f, local);
+    mint = kRayEpsilon;
+    maxt = BF_INF;
+    if (s.type == BF_RECEIVER_OMNI) {
+        float lo = sc.lambda_min, hi = sc.lambda_max;
+        lambda0 = wl_sample * (hi - lo) + lo;            // sample_uniform_spectrum (spectrum.h:312-316), lane 0
+        return (hi - lo) * rc.area;
+    }
+    float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    lambda0 = (float) ((double) (sc.c * rcp(freq)) * 1e9);
+    float ws = rect_sample_wigner(rc, o, local, lambda0);   // ds.d is the LOCAL cosine direction (:249-252)
+    float geom_gain = ws * rc.inv_area;
+    float extents = rc.area * kPi;
+    if (!s.rx_sig_is_delta) extents = (float) ((double) (extents * (sc.c * rcp(s.freq_ext))) * 1e9);
+    return 1.f * s.gain * geom_gain * extents;
+}
+
+// ---------------------------------------------------------------------------
+// path generation
+// ---------------------------------------------------------------------------
+BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, PathState &s) {
+    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+    s.path_i = path_i;
+    // per-path stream: sampler->seed(base_seed + path) (sampler.cpp:83-96)
+    pcg_seed(s.rng, lp.seed + lp.path_offset + path_i);
+    float fx = next_1d(s.rng), fy = next_1d(s.rng);
+    float ax = .5f, ay = .5f;
+    s.time = s.t_rx = s.lambda0 = 0.f;
+    bool film_ok = true;
+    if (receive) {
+        // receive_sample — integrator.cpp:1544-1572
+        ax = next_1d(s.rng);
+        ay = next_1d(s.rng);
+        float time = sc.sensor.adc_sampling_start;
+        if (sc.sensor.adc_sampling_time > 0.f)
+            time += next_1d(s.rng) * sc.sensor.adc_sampling_time;
+        else
+            time = 0.f;
+        float wl = next_1d(s.rng);
+        s.t_rx = time;
+        s.time = time;
+        float w = receiver_sample_ray(sc, wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
+        s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
+    } else {
+        // render_sample — integrator.cpp:263-283
+        if (sc.sensor.type != BF_SENSOR_PERSPECTIVE) {   // endpoint.h:241, perspective.cpp:130
+            ax = next_1d(s.rng);
+            ay = next_1d(s.rng);
+        }
+        if (sc.sensor.shutter_open_time > 0.f) (void) next_1d(s.rng);
+        (void) next_1d(s.rng);     // wavelength sample (consumed in RGB mode too)
+        (void) sensor_sample_ray(sc, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
+        // ImageBlock::put box branch: lo = ceil(pos - .5 - .5) must be 0 for the 1x1 film
+        film_ok = __builtin_ceilf((fx - .5f) - .5f) == 0.f && __builtin_ceilf((fy - .5f) - .5f) == 0.f;
+        s.aux = 0.f;
+    }
+    s.throughput = 1.f;
+    s.eta = 1.f;
+    s.emission_weight = 1.f;
+    s.result = 0.f;
+    s.bs_pdf = 0.f;
+    s.prev_p = mk(0, 0, 0);
+    s.flags = film_ok ? kFlagFilmOk : 0u;
+    s.n_rays = 1;
+}
+
+// ---------------------------------------------------------------------------
+// one integrator iteration
+// ---------------------------------------------------------------------------
+struct ShadowReq {
+    bool want;
+    V3 o, d;
+    float mint, maxt;
+    float c;             // NEE contribution released by an unoccluded shadow ray
+};
+
+// Returns true if the path continues with a new closest-hit ray (s.ro/rd/...),
+// false if it ended at the head of the iteration (film_put is due now).  When
+// the BSDF sample kills the path (path.cpp:171-173) the function returns true
+// with kFlagTermPending set and an empty ray interval: the film write has to
+// wait for the shadow ray of this very iteration.
+BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
+                         uint32_t &c_bounces) {
+    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+    const uint32_t n_emit = sc.n_emitters;
+    sh.want = false;
+    SI si;
+    const bool si_valid = hit.t != BF_INF;
+    int emitter = -1;
+    if (si_valid) {
+        make_si(sc, s.ro, s.rd, hit, si);
+        emitter = sc.shapes[si.shape].emitter;
+    }
+    uint32_t depth = s.flags & kDepthMask;
+    if (depth == 0) {
+        // first intersection — path.cpp:115-117, pathlength.cpp:138-146,
+        // pathtime.cpp:136-140, pathtimefrequency.cpp:131-153
+        if (si_valid) s.flags |= kFlagValid;
+        if (is_range) s.aux += si_valid ? si.t : 0.f;
+        if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
+        if (receive && si_valid) s.time += -si.t / sc.c;          // ray.update_state(-si.t); si.time = ray.time
+        depth = 1;
+    } else {
+        // tail of the previous iteration — path.cpp:184-209, pathtimefrequency.cpp:363-399
+        if (receive) s.time += -hit.t / sc.c;                      // :368-371, also for a miss (Q3)
+        if (emitter >= 0) {
+            const DEmitter &e = sc.emitters[emitter];
+            float emitter_pdf = receive ? transmitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
+                                        : emitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n);
+            if (n_emit != 1) emitter_pdf *= 1.f / (float) n_emit;
+            s.emission_weight = mis_weight(s.bs_pdf, emitter_pdf);
+        }
+        if (is_range) s.aux += si_valid ? si.t : 0.f;
+        if (is_time) s.aux += si_valid ? si.t / lp.time_c : 0.f;
+        ++depth;
+    }
+    s.flags = (s.flags & ~kDepthMask) | (depth & kDepthMask);
+    // head of iteration `depth` — path.cpp:121-145
+    if (emitter >= 0) {
+        const DEmitter &e = sc.emitters[emitter];
+        float ev;
+        if (receive)
+            ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
+        else
+            ev = (e.type == BF_EMITTER_SPOT) ? 0.f : ((si.wi.z > 0.f) ? e.radiance : 0.f);
+        s.result += s.emission_weight * s.throughput * ev;
+        if (is_range) s.aux += si_valid ? si.t : 0.f;              // pathlength.cpp:161
+    }
+    bool active = si_valid;
+    if ((int) depth > lp.rr_depth) {
+        float q = __builtin_fminf(s.throughput * sqr(s.eta), .95f);
+        active = (next_1d(s.rng) < q) && active;
+        s.throughput *= rcp(q);
+    }
+    if (depth >= (uint32_t) lp.max_depth || !active) return false;
+
+    const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+    ++c_bounces;
+    if (bsdf_smooth(mat)) {
+        // Scene::sample_emitter_direction / sample_transmitter_direction — scene.cpp:180-230, 249-299
+        float sx = next_1d(s.rng), sy = next_1d(s.rng);
+        DirSample ds;
+        ds.d = mk(0, 0, 1);
+        ds.pdf = 0.f;
+        ds.dist = 0.f;
+        ds.delta = false;
+        float emitter_val = 0.f;
+        if (n_emit >= 1) {
+            uint32_t index = 0;
+            float emitter_pdf = 1.f;
+            if (n_emit > 1) {
+                emitter_pdf = 1.f / (float) n_emit;
+                index = min((uint32_t) (sx * (float) n_emit), n_emit - 1u);
+                sx = (sx - index * emitter_pdf) * (float) n_emit;
+            }
+            const DEmitter &e = sc.emitters[index];
+            if (receive)
+                emitter_val = transmitter_sample_direction(sc, e, si.p, s.time, s.lambda0, sx, sy, ds);
+            else
+                emitter_val = emitter_sample_direction(sc, e, si.p, sx, sy, ds);
+            if (n_emit > 1) {
+                ds.pdf *= emitter_pdf;
+                emitter_val *= rcp(emitter_pdf);
+            }
+        }
+        if (ds.pdf != 0.f) {
+            V3 wo = to_local(si.sh, ds.d);
+            float bsdf_val, bsdf_pdf;
+            bsdf_eval_pdf(mat, si.wi, wo, bsdf_val, bsdf_pdf);
+            float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf);
+            sh.c = mis * s.throughput * bsdf_val * emitter_val;
+            sh.o = si.p;
+            sh.d = ds.d;
+            sh.mint = kRayEpsilon * (1.f + hmax_abs(si.p));
+            sh.maxt = ds.dist * (1.f - kShadowEpsilon);
+            sh.want = true;
+            ++s.n_rays;
+        }
+        if (is_range) s.aux += si.t;                                // pathlength.cpp:209
+    }
+    (void) next_1d(s.rng);                                          // sample1 (unused by these BSDFs)
+    float s2x = next_1d(s.rng), s2y = next_1d(s.rng);
+    BSDFSample bs;
+    float bsdf_val = bsdf_sample(mat, si.wi, s2x, s2y, bs);
+    s.throughput = s.throughput * bsdf_val;
+    if (s.throughput == 0.f) {
+        s.flags |= kFlagTermPending;
+        s.rmint = BF_INF;      // empty interval: no closest-hit query for this slot
+        s.rmaxt = 0.f;
+        return true;
+    }
+    s.eta *= bs.eta;
+    // si.spawn_ray — interaction.h:61-64
+    s.ro = si.p;
+    s.rd = to_world(si.sh, bs.wo);
+    s.rmint = (1.f + hmax_abs(si.p)) * kRayEpsilon;
+    s.rmaxt = BF_INF;
+    s.prev_p = si.p;
+    s.bs_pdf = bs.pdf;
+    ++s.n_rays;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// film / ADC
+// ---------------------------------------------------------------------------
+BF_DEV void hist_add(float *s_hist, float *g_hist, bool lds, uint32_t idx, float v) {
+    if (lds)
+        atomicAdd(&s_hist[idx], v);     // ds_add_f32
+    else
+        atomicAdd(&g_hist[idx], v);     // global_atomic_add_f32
+}
+
+struct FilmAcc {
+    float X, Y, Z, A, W;    // base channels of the 1x1 film (render modes)
+    uint32_t invalid;
+};
+
+BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
+                     FilmAcc &acc, bf_path_record *records) {
+    const bool valid = (s.flags & kFlagValid) != 0;
+    float rec_L, rec_aux;
+    if (lp.mode == BF_MODE_RECEIVE_RAW) {
+        // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
+        const DSensor &se = sc.sensor;
+        float tf0 = s.t_rx - se.adc_sampling_start;
+        float tf1 = freq_of(sc.c, s.lambda0);
+        tf0 *= (float) se.t_bins / se.t_bandwidth;
+        tf1 *= (float) se.f_bins / se.f_bandwidth;
+        float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode
+        float a0 = valid ? 4.f * L : 0.f;                     // hsum over 4 identical spectral lanes
+        float a1 = valid ? 1.f : 0.f;
+        bool ok = __builtin_isfinite(a0);
+        float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
+        ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
+        if (ok) {
+            uint32_t off = 3u * ((uint32_t) ly * lp.bins + (uint32_t) lx);
+            if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 0u, a0);
+            if (a1 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 1u, a1);
+            hist_add(s_hist, g_hist, lds_hist, off + 2u, 1.f);
+            acc.W += 1.f;
+        } else {
+            ++acc.invalid;
+        }
+        rec_L = a0;
+        rec_aux = s.t_rx - se.adc_sampling_start;
+    } else {
+        const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+        const float sensor_w = sc.sensor.type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
+        float L = sensor_w * s.result;                        // integrator.cpp:286
+        float X, Y, Z;
+        if (lp.color_mode == BF_COLOR_RGB)
+            srgb_to_xyz_grey(L, X, Y, Z);
+        else
+            X = Y = Z = L;
+        float a0 = s.result, a1 = s.result, a2 = s.result;    // AOVs see the unweighted radiance
+        if (is_time && lp.color_mode == BF_COLOR_RGB) srgb_to_xyz_grey(s.result, a0, a1, a2);
+        bool ok = (s.flags & kFlagFilmOk) && __builtin_isfinite(X) && __builtin_isfinite(Y) && __builtin_isfinite(Z);
+        if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
+        if (ok) {
+            acc.X += X;
+            acc.Y += Y;
+            acc.Z += Z;
+            acc.A += valid ? 1.f : 0.f;
+            acc.W += 1.f;
+            if (is_range || is_time) {
+                // range.cpp:141-161 / time.cpp:134-153: bin i takes the sample iff
+                // (float)i*w <= aux < (float)i*w + w, evaluated exactly as written
+                // there for the (at most three) candidate bins
+                float w = lp.bin_width;
+                int k = (int) __builtin_floorf(s.aux / w);
+                for (int i = k - 1; i <= k + 1; ++i) {
+                    if (i < 0 || i >= (int) lp.bins) continue;
+                    float lo = (float) i * w, hi = (float) i * w + w;
+                    if (s.aux >= lo && s.aux < hi) {
+                        if (is_range) {
+                            if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, 5u + (uint32_t) i, a0);
+                        } else if (a0 != 0.f || a1 != 0.f || a2 != 0.f) {
+                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 0u, a0);
+                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 1u, a1);
+                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 2u, a2);
+                        }
+                    }
+                }
+            }
+        } else {
+            ++acc.invalid;
+        }
+        rec_L = L;
+        rec_aux = s.aux;
+    }
+    if (records) {
+        bf_path_record r;
+        r.L = rec_L;
+        r.aux = rec_aux;
+        r.valid = valid ? 1u : 0u;
+        r.n_rays = s.n_rays;
+        records[s.path_i] = r;
+    }
+}
+
+// wave-reduce the base channels into the histogram (render modes only) and
+// flush the LDS-privatised histogram: one global atomic per non-empty bin
+BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_hist, bool lds_hist, int tid) {
+    const int lane = tid & 63;
+    if (lp.mode != BF_MODE_RECEIVE_RAW) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.X += __shfl_down(acc.X, off);
+            acc.Y += __shfl_down(acc.Y, off);
+            acc.Z += __shfl_down(acc.Z, off);
+            acc.A += __shfl_down(acc.A, off);
+            acc.W += __shfl_down(acc.W, off);
+        }
+        if (lane == 0 && acc.W != 0.f) {
+            hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
+            hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
+            hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);
+            hist_add(s_hist, g_hist, lds_hist, 3, acc.A);
+            hist_add(s_hist, g_hist, lds_hist, 4, acc.W);
+        }
+    }
+    if (lds_hist) {
+        __syncthreads();
+        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
+            float v = s_hist[i];
+            if (v != 0.f) atomicAdd(&g_hist[i], v);
+        }
+    }
+}
+
+}  // namespace bfd

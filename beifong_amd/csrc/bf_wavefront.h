@@ -19,6 +19,7 @@ struct WF {
     float4 *sb[2];      // aux, bs_pdf, prev_p.x, prev_p.y
     uint4 *sc[2];       // prev_p.z, depth|flags, n_rays, -
     uint4 *sd[2];       // rng state lo/hi, path index lo/hi
+    float4 *se[2];      // receive mode only: ray.time, t_rx, lambda0, -
     float4 *hit;        // t, u, v, slot      [capacity]
     // shadow-ray queue [capacity]
     float4 *sh0;        // o.xyz, mint

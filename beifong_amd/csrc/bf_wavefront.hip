@@ -21,74 +21,9 @@
 // latency-bound traversal runs at 5 waves/SIMD instead of 1, and every lane
 // of a trace wave holds a ray.  Results are bit-identical per path to the
 // megakernel (bf_kernels.hip) and to the oracle: same draws, same arithmetic.
-#include "bf_device_core.h"
-#include "bf_wavefront.h"
-#include "bf_wf_state.h"
+#include "bf_path_logic.h"
 
 namespace bfd {
-
-BF_DEV void wf_hist_add(float *s_hist, float *g_hist, bool lds, uint32_t idx, float v) {
-    if (lds)
-        atomicAdd(&s_hist[idx], v);     // ds_add_f32
-    else
-        atomicAdd(&g_hist[idx], v);     // global_atomic_add_f32
-}
-
-struct FilmAcc {
-    float X, Y, Z, A, W;
-    uint32_t invalid;
-};
-
-// render_sample tail (integrator.cpp:286-307) + range/time AOVs
-// (range.cpp:141-161, time.cpp:134-153) + ImageBlock::put box branch
-BF_DEV void film_put(const DLaunch &lp, const PathState &s, float sensor_w, float *s_hist, float *g_hist, bool lds_hist,
-                     FilmAcc &acc, bf_path_record *records) {
-    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
-    float L = sensor_w * s.result;
-    float X, Y, Z;
-    if (lp.color_mode == BF_COLOR_RGB)
-        srgb_to_xyz_grey(L, X, Y, Z);
-    else
-        X = Y = Z = L;
-    float a0 = s.result, a1 = s.result, a2 = s.result;      // AOVs see the unweighted radiance
-    if (is_time && lp.color_mode == BF_COLOR_RGB) srgb_to_xyz_grey(s.result, a0, a1, a2);
-    bool ok = (s.flags & kFlagFilmOk) && __builtin_isfinite(X) && __builtin_isfinite(Y) && __builtin_isfinite(Z);
-    if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
-    if (ok) {
-        acc.X += X;
-        acc.Y += Y;
-        acc.Z += Z;
-        acc.A += (s.flags & kFlagValid) ? 1.f : 0.f;
-        acc.W += 1.f;
-        if (is_range || is_time) {
-            float w = lp.bin_width;
-            int k = (int) __builtin_floorf(s.aux / w);
-            for (int i = k - 1; i <= k + 1; ++i) {
-                if (i < 0 || i >= (int) lp.bins) continue;
-                float lo = (float) i * w, hi = (float) i * w + w;
-                if (s.aux >= lo && s.aux < hi) {
-                    if (is_range) {
-                        if (a0 != 0.f) wf_hist_add(s_hist, g_hist, lds_hist, 5u + (uint32_t) i, a0);
-                    } else if (a0 != 0.f || a1 != 0.f || a2 != 0.f) {
-                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 0u, a0);
-                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 1u, a1);
-                        wf_hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 2u, a2);
-                    }
-                }
-            }
-        }
-    } else {
-        ++acc.invalid;
-    }
-    if (records) {
-        bf_path_record r;
-        r.L = L;
-        r.aux = s.aux;
-        r.valid = (s.flags & kFlagValid) ? 1u : 0u;
-        r.n_rays = s.n_rays;
-        records[s.path_i] = r;
-    }
-}
 
 template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
@@ -103,17 +38,14 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
     }
     const int cur = it & 1, nxt = cur ^ 1;
     const uint32_t n_cur = wf.n_q[it];
-    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
-    const uint32_t n_emit = sc.n_emitters;
-    const bool aperture = sc.sensor.type != BF_SENSOR_PERSPECTIVE;
-    const float sensor_w = sc.sensor.type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
+    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
     uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0;
 
     // static wave-granular partition of the queue: a device-wide queue head
     // saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"),
-    // which throttled 64-ray batches; batches are plentiful per wave, so a
+    // which throttled 64-slot batches; batches are plentiful per wave, so a
     // grid-stride walk balances well without any atomic.
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
     for (uint32_t base = wave_id * 64u; base < n_cur; base += n_waves * 64u) {
@@ -121,18 +53,18 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
         const bool has = i < n_cur;
 
         PathState s;
-        bool need_gen = false, cont = false, want_shadow = false;
-        V3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 1);
-        float sh_mint = 0.f, sh_maxt = 0.f, sh_c = 0.f;
+        ShadowReq sh;
+        sh.want = false;
+        bool need_gen = false, cont = false;
 
         if (has) {
             if (FIRST) {
                 need_gen = true;
             } else {
-                load_state(wf, cur, i, s);
+                load_state(wf, cur, i, receive, s);
                 if (s.flags & kFlagTermPending) {
-                    // terminated after last bounce's BSDF sample; its NEE shadow ray has resolved by now
-                    film_put(lp, s, sensor_w, s_hist, g_hist, lds_hist, acc, records);
+                    // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
+                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else {
                     float4 hq = wf.hit[i];
@@ -142,112 +74,14 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
                     hit.v = hq.z;
                     hit.slot = __float_as_int(hq.w);
                     hit.prim = 0;
-                    SI si;
-                    const bool si_valid = hit.t != BF_INF;
-                    int emitter = -1;
-                    if (si_valid) {
-                        make_si(sc, s.ro, s.rd, hit, si);
-                        emitter = sc.shapes[si.shape].emitter;
-                    }
-                    uint32_t depth = s.flags & kDepthMask;
-                    if (depth == 0) {
-                        // first intersection — path.cpp:115-117, pathlength.cpp:138-146, pathtime.cpp:136-140
-                        if (si_valid) s.flags |= kFlagValid;
-                        if (is_range) s.aux += si_valid ? si.t : 0.f;
-                        if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
-                        depth = 1;
-                    } else {
-                        // tail of the previous iteration — path.cpp:184-209
-                        if (emitter >= 0) {
-                            const DEmitter &e = sc.emitters[emitter];
-                            float emitter_pdf = emitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n);
-                            if (n_emit != 1) emitter_pdf *= 1.f / (float) n_emit;
-                            s.emission_weight = mis_weight(s.bs_pdf, emitter_pdf);
-                        }
-                        if (is_range) s.aux += si_valid ? si.t : 0.f;
-                        if (is_time) s.aux += si_valid ? si.t / lp.time_c : 0.f;
-                        ++depth;
-                    }
-                    s.flags = (s.flags & ~kDepthMask) | (depth & kDepthMask);
-                    // head of iteration `depth` — path.cpp:121-145
-                    if (emitter >= 0) {
-                        const DEmitter &e = sc.emitters[emitter];
-                        float ev = (e.type == BF_EMITTER_SPOT) ? 0.f : ((si.wi.z > 0.f) ? e.radiance : 0.f);
-                        s.result += s.emission_weight * s.throughput * ev;
-                        if (is_range) s.aux += si_valid ? si.t : 0.f;       // pathlength.cpp:161
-                    }
-                    bool active = si_valid;
-                    if ((int) depth > lp.rr_depth) {
-                        float q = __builtin_fminf(s.throughput * sqr(s.eta), .95f);
-                        active = (next_1d(s.rng) < q) && active;
-                        s.throughput *= rcp(q);
-                    }
-                    if (depth >= (uint32_t) lp.max_depth || !active) {
-                        film_put(lp, s, sensor_w, s_hist, g_hist, lds_hist, acc, records);
+                    cont = shade_vertex(sc, lp, s, hit, sh, c_bounces);
+                    if (!cont) {
+                        film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                         need_gen = true;
-                    } else {
-                        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
-                        ++c_bounces;
-                        if (bsdf_smooth(mat)) {
-                            // Scene::sample_emitter_direction — scene.cpp:180-230
-                            float sx = next_1d(s.rng), sy = next_1d(s.rng);
-                            DirSample ds;
-                            ds.d = mk(0, 0, 1);
-                            ds.pdf = 0.f;
-                            ds.dist = 0.f;
-                            ds.delta = false;
-                            float emitter_val = 0.f;
-                            if (n_emit == 1) {
-                                emitter_val = emitter_sample_direction(sc, sc.emitters[0], si.p, sx, sy, ds);
-                            } else if (n_emit > 1) {
-                                float emitter_pdf = 1.f / (float) n_emit;
-                                uint32_t index = min((uint32_t) (sx * (float) n_emit), n_emit - 1u);
-                                sx = (sx - index * emitter_pdf) * (float) n_emit;
-                                emitter_val = emitter_sample_direction(sc, sc.emitters[index], si.p, sx, sy, ds);
-                                ds.pdf *= emitter_pdf;
-                                emitter_val *= rcp(emitter_pdf);
-                            }
-                            if (ds.pdf != 0.f) {
-                                // the shadow ray gates this contribution (scene.cpp:220-224)
-                                V3 wo = to_local(si.sh, ds.d);
-                                float bsdf_val, bsdf_pdf;
-                                bsdf_eval_pdf(mat, si.wi, wo, bsdf_val, bsdf_pdf);
-                                float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf);
-                                sh_c = mis * s.throughput * bsdf_val * emitter_val;
-                                sh_o = si.p;
-                                sh_d = ds.d;
-                                sh_mint = kRayEpsilon * (1.f + hmax_abs(si.p));
-                                sh_maxt = ds.dist * (1.f - kShadowEpsilon);
-                                want_shadow = true;
-                                ++s.n_rays;
-                                ++c_shadow;
-                            }
-                            if (is_range) s.aux += si.t;                    // pathlength.cpp:209
-                        }
-                        (void) next_1d(s.rng);                              // sample1 (unused by these BSDFs)
-                        float s2x = next_1d(s.rng), s2y = next_1d(s.rng);
-                        BSDFSample bs;
-                        float bsdf_val = bsdf_sample(mat, si.wi, s2x, s2y, bs);
-                        s.throughput = s.throughput * bsdf_val;
-                        cont = true;
-                        if (s.throughput == 0.f) {
-                            // path.cpp:171-173 break; the film write waits for the shadow ray
-                            s.flags |= kFlagTermPending;
-                            s.rmint = BF_INF;      // no closest-hit query for this slot
-                            s.rmaxt = 0.f;
-                        } else {
-                            s.eta *= bs.eta;
-                            // si.spawn_ray — interaction.h:61-64
-                            s.ro = si.p;
-                            s.rd = to_world(si.sh, bs.wo);
-                            s.rmint = (1.f + hmax_abs(si.p)) * kRayEpsilon;
-                            s.rmaxt = BF_INF;
-                            s.prev_p = si.p;
-                            s.bs_pdf = bs.pdf;
-                            ++s.n_rays;
-                            ++c_closest;
-                        }
+                    } else if (!(s.flags & kFlagTermPending)) {
+                        ++c_closest;
                     }
+                    if (sh.want) ++c_shadow;
                 }
             }
         }
@@ -261,30 +95,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
             if (need_gen) {
                 uint64_t path_i = pbase + __popcll(gmask & ((1ull << lane) - 1ull));
                 if (path_i < lp.n_paths) {
-                    // SamplingIntegrator::render_sample — integrator.cpp:259-283;
-                    // per-path stream seed(base_seed + path) (sampler.cpp:83-96)
-                    s.path_i = path_i;
-                    pcg_seed(s.rng, lp.seed + lp.path_offset + path_i);
-                    float fx = next_1d(s.rng), fy = next_1d(s.rng);
-                    float ax = .5f, ay = .5f;
-                    if (aperture) {
-                        ax = next_1d(s.rng);
-                        ay = next_1d(s.rng);
-                    }
-                    if (sc.sensor.shutter_open_time > 0.f) (void) next_1d(s.rng);
-                    (void) next_1d(s.rng);   // wavelength sample (consumed in RGB mode too)
-                    (void) sensor_sample_ray(sc, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
-                    // ImageBlock::put box branch: lo = ceil(pos - .5 - .5) must be 0
-                    bool film_ok = __builtin_ceilf((fx - .5f) - .5f) == 0.f && __builtin_ceilf((fy - .5f) - .5f) == 0.f;
-                    s.throughput = 1.f;
-                    s.eta = 1.f;
-                    s.emission_weight = 1.f;
-                    s.result = 0.f;
-                    s.aux = 0.f;
-                    s.bs_pdf = 0.f;
-                    s.prev_p = mk(0, 0, 0);
-                    s.flags = film_ok ? kFlagFilmOk : 0u;
-                    s.n_rays = 1;
+                    generate_path(sc, lp, path_i, s);
                     ++c_closest;
                     cont = true;
                 }
@@ -299,45 +110,23 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
             if (lane == 0) qb = atomicAdd(&wf.n_q[it + 1], (uint32_t) __popcll(cmask));
             qb = __shfl(qb, 0);
             j = qb + __popcll(cmask & ((1ull << lane) - 1ull));
-            if (cont) store_state(wf, nxt, j, s);
+            if (cont) store_state(wf, nxt, j, receive, s);
         }
-        unsigned long long smask = __ballot(want_shadow);
+        unsigned long long smask = __ballot(sh.want);
         if (smask) {
             uint32_t sb = 0;
             if (lane == 0) sb = atomicAdd(&wf.n_sh[it], (uint32_t) __popcll(smask));
             sb = __shfl(sb, 0);
-            if (want_shadow) {
+            if (sh.want) {
                 uint32_t k = sb + __popcll(smask & ((1ull << lane) - 1ull));
-                wf.sh0[k] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_mint);
-                wf.sh1[k] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_maxt);
-                wf.sh2[k] = make_uint2(j, __float_as_uint(sh_c));
+                wf.sh0[k] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
+                wf.sh1[k] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
+                wf.sh2[k] = make_uint2(j, __float_as_uint(sh.c));
             }
         }
     }
 
-    // ---- epilogue: wave-reduce the base channels, flush the histogram ------
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        acc.X += __shfl_down(acc.X, off);
-        acc.Y += __shfl_down(acc.Y, off);
-        acc.Z += __shfl_down(acc.Z, off);
-        acc.A += __shfl_down(acc.A, off);
-        acc.W += __shfl_down(acc.W, off);
-    }
-    if (lane == 0 && acc.W != 0.f) {
-        wf_hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
-        wf_hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
-        wf_hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);
-        wf_hist_add(s_hist, g_hist, lds_hist, 3, acc.A);
-        wf_hist_add(s_hist, g_hist, lds_hist, 4, acc.W);
-    }
-    if (lds_hist) {
-        __syncthreads();
-        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
-            float v = s_hist[i];
-            if (v != 0.f) atomicAdd(&g_hist[i], v);
-        }
-    }
+    film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

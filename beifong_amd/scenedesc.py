@@ -208,6 +208,42 @@ class SceneDesc:
         self.shapes[shape].emitter = idx
         return idx
 
+    # ---- transmitters (gen-3) ----
+    def add_area_transmitter(self, shape, radiance=1.0):
+        e = capi.bf_emitter()
+        e.type, e.shape, e.radiance = capi.BF_TRANSMITTER_AREA, shape, radiance
+        e.to_world, e.to_object = _m16(np.eye(4)), _m16(np.eye(4))
+        self.emitters.append(e)
+        self.shapes[shape].emitter = len(self.emitters) - 1
+        return len(self.emitters) - 1
+
+    def add_wigner_transmitter(self, shape, signaltype="pulse", amplitude=1.0, freq_centre=1.0, freq_ext=1.0,
+                               pulse_len=1.0, prf=1.0, gain=1.0):
+        """wignertransmitter.cpp:53-110; chirp_len/crf/freq_sweep of "linfmcw" map onto pulse_len/prf/freq_ext."""
+        e = capi.bf_emitter()
+        e.type, e.shape, e.radiance = capi.BF_TRANSMITTER_WIGNER, shape, 1.0
+        e.to_world, e.to_object = _m16(np.eye(4)), _m16(np.eye(4))
+        e.signal_type = {"cw": capi.BF_SIGNAL_CW, "pulse": capi.BF_SIGNAL_PULSE, "linfmcw": capi.BF_SIGNAL_LINFMCW}[signaltype]
+        e.amplitude, e.freq_centre, e.freq_ext, e.pulse_len, e.prf, e.gain = amplitude, freq_centre, freq_ext, pulse_len, prf, gain
+        e.resample_freq = 0
+        self.emitters.append(e)
+        self.shapes[shape].emitter = len(self.emitters) - 1
+        return len(self.emitters) - 1
+
+    # ---- receivers + ADC (gen-3) ----
+    def set_receiver(self, shape, kind="omnidirectional", adc_sampling_start=0.0, adc_sampling_end=0.0, t_bins=1024,
+                     f_bins=1024, t_bandwidth=3.81e-6, f_bandwidth=250e6, freq_centre=1.0, freq_ext=1.0, gain=1.0,
+                     sig_is_delta=False):
+        """receiver.cpp:16-62 + adc.cpp:18-46 (box rfilter, full window)."""
+        s = self.sensor
+        s.type = capi.BF_RECEIVER_OMNI if kind == "omnidirectional" else capi.BF_RECEIVER_WIGNER
+        s.shape = shape
+        self.shapes[shape].is_sensor = 1
+        s.adc_sampling_start = adc_sampling_start
+        s.adc_sampling_time = f32(adc_sampling_end) - f32(adc_sampling_start)
+        s.t_bins, s.f_bins, s.t_bandwidth, s.f_bandwidth = t_bins, f_bins, t_bandwidth, f_bandwidth
+        s.freq_centre, s.freq_ext, s.gain, s.rx_sig_is_delta = freq_centre, freq_ext, gain, int(sig_is_delta)
+
     # ---- sensors ----
     def set_fluxmeter(self, shape):
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_FLUXMETER, shape

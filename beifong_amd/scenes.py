@@ -97,6 +97,40 @@ def multi_mesh_radar(n_paths=4096 << 10, bins=4096, dr=0.01, seed=3, scale=1.0):
     return sd, launch
 
 
+def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmitter="wigner", receiver="omnidirectional",
+                signaltype="pulse"):
+    """C2-recv: C2 geometry through gen-3 receive():
+    wignertransmitter (pulse tau = 2 dr / c, prf = 1/T) on the TX aperture,
+    omnidirectional receiver on a coincident RX aperture, ADC t_bins x 1 with
+    t_bandwidth = T = t_bins * tau, f_bandwidth = 2 c / lambda_min (one frequency row)."""
+    sd = SceneDesc()
+    c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
+    aperture = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
+    tx_mat = sd.add_diffuse(0.0)        # transmitter shape: rho = 0 (shape.cpp:89-98)
+    rx_mat = sd.add_diffuse(0.5)
+    txa = sd.add_rectangle(aperture, tx_mat)
+    rxa = sd.add_rectangle(aperture, rx_mat)
+    tau = 2.0 * dr / c
+    t_total = t_bins * tau
+    f_c = c / (0.5 * (lmin + lmax) * 1e-9)
+    if transmitter == "wigner":
+        sd.add_wigner_transmitter(txa, signaltype=signaltype, amplitude=1.0, freq_centre=f_c, freq_ext=1.0 / tau,
+                                  pulse_len=tau, prf=1.0 / t_total, gain=1.0)
+    else:
+        sd.add_area_transmitter(txa, 1.0)
+    sd.set_receiver(rxa, kind=receiver, adc_sampling_start=0.0, adc_sampling_end=t_total, t_bins=t_bins, f_bins=1,
+                    t_bandwidth=t_total, f_bandwidth=2.0 * c / (lmin * 1e-9), freq_centre=f_c,
+                    freq_ext=c / (lmin * 1e-9) - c / (lmax * 1e-9))
+    _ground(sd)
+    car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
+    v, f = meshgen.bus(n_tris, seed=1)
+    sd.add_mesh(meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7)), f, car)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, n_paths, seed=seed, bins=t_bins, bins_y=1)
+    return sd, launch
+
+
 def single_mesh(v, f, normals=None):
     """Bare mesh scene for Scene::ray_intersect tests (test_kdtrees.py style)."""
     sd = SceneDesc()

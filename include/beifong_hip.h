@@ -133,6 +133,8 @@ typedef struct bf_sensor {
     uint32_t t_bins, f_bins;
     float t_bandwidth, f_bandwidth;
     float freq_centre, freq_ext, gain;     /* wigner receiver                */
+    uint32_t rx_sig_is_delta;  /* wignerreceiver.cpp:258 reads an uninitialised
+                                  m_sig_is_delta in raw mode; made explicit  */
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */
@@ -169,7 +171,8 @@ typedef struct bf_launch {
     uint64_t seed;            /* sampler base seed (sampler.cpp:83-96)        */
     int32_t  max_depth;       /* -1 = infinite (integrator.cpp:1713-1728)     */
     int32_t  rr_depth;        /* default 5                                    */
-    uint32_t bins;            /* range/time bins                              */
+    uint32_t bins;            /* range/time bins; receive: ADC t_bins         */
+    uint32_t bins_y;          /* receive: ADC f_bins (else ignored)           */
     float    bin_width;       /* dr [m] (range) or dt [s] (time)              */
     float    time_c;          /* gen-1 divides by (Float)3.0e8 (pathtime.cpp:140) */
     uint32_t flags;           /* BF_FLAG_*                                    */
@@ -224,7 +227,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out);
 bf_status bf_scene_destroy(bf_scene *scene);
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info);
 
-/* number of float channels per pixel the given launch produces */
+/* number of floats the given launch accumulates into: 5 (+bins | +3*bins) for
+ * the 1x1 film modes, f_bins*t_bins*3 ([y=f][x=t][Y,A,W]) for receive */
 uint32_t bf_launch_channels(const bf_launch *launch);
 
 /* Render into a DEVICE buffer hist_dev[film_h*film_w*channels] (accumulates;

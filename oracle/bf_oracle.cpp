@@ -269,6 +269,7 @@ struct Rect {
     M4 to_world, to_object;
     Frame frame;              // rectangle.cpp:83-92 (s = dp_du, t = dp_dv, n)
     float inv_area;
+    float area;               // Rectangle::surface_area()
 };
 struct Tri {
     V3 p0, p1, p2;
@@ -1083,6 +1084,250 @@ static PathResult path_sample(const OScene &sc, const bf_launch &lp, Sampler &sm
     return r;
 }
 
+// ===========================================================================
+// gen-3: Integrator::receive — Transmitter / Receiver / ADC
+// ===========================================================================
+// "Jacob functions" — include/mitsuba/core/math.h:62-131
+inline float jabs(float x) { return x >= 0.f ? x : -x; }
+inline float sinc_j(float x) { return jabs(x) > kEpsilon ? sinf_cr(x) / x : 1.f; }
+inline float tri_j(float x) { return jabs(x) < 0.5f ? 1.f - 2.f * jabs(x) : 0.f; }
+inline float rect_j(float x) { return jabs(x) < 0.5f ? 1.f : 0.f; }
+inline float fmodulo_j(float a, float b) {          // math.h:108-123 (subtract loop, literal)
+    float result = jabs(a);
+    int guard = 0;
+    while (result - jabs(b) >= kEpsilon && guard++ < (1 << 22)) result -= jabs(b);
+    result = (a < 0.f) ? jabs(b) - result : result;
+    result += (b < 0.f) ? b : 0.f;
+    return result;
+}
+inline float wchirp_j(float t, float f, float w, float a) {   // math.h:126-130
+    return 2 * a * a * w * tri_j(t / w) * sinc_j(kTwoPi * f * w * tri_j(t / w));
+}
+
+// Rectangle::sample_wigner — src/shapes/rectangle.cpp:132-220.  `p` and `d` are
+// the DirectionSample's p and d as the caller left them; lambda_nm = wavelength[0].
+// Literal `1e-9` is a double in the reference, so that product runs in double.
+static float rect_sample_wigner(const Rect &rc, V3 p, V3 d, float lambda_nm) {
+    float wid_x = norm(rc.frame.s), wid_y = norm(rc.frame.t);
+    // m_to_object * ds.p / 2 : projective point transform, then / 2
+    V3 q = xf_point(rc.to_object, p);      // affine matrices: w == 1
+    V3 r_hat = q / 2.f;
+    Frame f;
+    f.s = normalize(rc.frame.s);
+    f.t = normalize(rc.frame.t);
+    f.n = normalize(rc.frame.n);
+    V3 loc = {dot(f.s, d), dot(f.t, d), dot(f.n, d)};     // from_frame rows s,t,n (transform.h:286-295)
+    double inv = 1.0 / ((double) lambda_nm * 1e-9);
+    float nu_x = (float) ((double) loc.x * inv), nu_y = (float) ((double) loc.y * inv);
+    float gain = 4 * tri_j(r_hat.x) * tri_j(r_hat.y) * sinc_j(kTwoPi * nu_x * wid_x * tri_j(r_hat.x)) *
+                 sinc_j(kTwoPi * nu_y * wid_y * tri_j(r_hat.y));
+    return gain;
+}
+
+// WignerTransmitter::eval_signal — src/transmitters/wignertransmitter.cpp:111-146
+static float tx_eval_signal(const bf_emitter &e, float time, float frequency) {
+    if (e.signal_type == BF_SIGNAL_LINFMCW) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        float fi = e.freq_centre + (e.freq_ext / e.pulse_len) * (t - ti);
+        return rect_j((t - ti) / e.pulse_len) > 0.f ? wchirp_j(t - ti, frequency - fi, e.pulse_len, e.amplitude) : 0.f;
+    } else if (e.signal_type == BF_SIGNAL_PULSE) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        float fi = e.freq_centre;
+        return rect_j((t - ti) / e.pulse_len) > 0.f ? wchirp_j(t - ti, frequency - fi, e.pulse_len, e.amplitude) : 0.f;
+    }
+    return e.amplitude * e.amplitude;      // cw
+}
+inline float freq_of(const OScene &sc, float lambda_nm) {
+    // MTS_C * rcp(wavelengths * 1e-9): float * rcp(double) -> rounded to Float at the call
+    return (float) ((double) sc.physics.c * (1.0 / ((double) lambda_nm * 1e-9)));
+}
+
+struct RxCtx {
+    float lambda0;     // ray.wavelengths[0] (nm)
+};
+
+// Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
+static float transmitter_eval(const OScene &sc, const Emitter &e, const SI &si, const RxCtx &cx) {
+    const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
+    if (e.d.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.d.radiance * (rc.area) : 0.f;
+    float signal_power = tx_eval_signal(e.d, si.time, freq_of(sc, cx.lambda0));
+    // DirectionSample3f ds(si); ds.d *= -1  — d is never initialised there (Q5): defined as 0
+    float ws = rect_sample_wigner(rc, si.p, V3{0.f, 0.f, 0.f}, cx.lambda0);
+    float geom_gain = 1.f * ws;
+    return (si.wi.z > 0.f) ? signal_power * e.d.gain * geom_gain * kTwoPi : 0.f;
+}
+
+// Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
+static float transmitter_sample_direction(const OScene &sc, const Emitter &e, const SI &ref, float sx, float sy,
+                                          const RxCtx &cx, DirectionSample &ds) {
+    const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
+    ds = rect_sample_direction(rc, ref.p, ref.time, sx, sy);
+    bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+    if (e.d.type == BF_TRANSMITTER_AREA) {
+        float spec = e.d.radiance / ds.pdf;
+        return active ? spec : 0.f;
+    }
+    float geom_gain = 1.f / ds.pdf;
+    if ((double) ds.dist > 5e-7) ds.time += -ds.dist / sc.physics.c;       // retarded time :422-425
+    float signal_power = tx_eval_signal(e.d, ds.time, freq_of(sc, cx.lambda0));
+    float ws = rect_sample_wigner(rc, ds.p, -ds.d, cx.lambda0);
+    geom_gain *= ws;
+    ds.pdf *= ws;
+    float extents = rcp(rc.area) * kTwoPi;
+    return active ? signal_power * e.d.gain * geom_gain * extents : 0.f;
+}
+
+// Transmitter::pdf_direction — areatransmitter.cpp:167-186, wignertransmitter.cpp:540-577
+static float transmitter_pdf_direction(const OScene &sc, const Emitter &e, const DirectionSample &ds, const RxCtx &cx) {
+    const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
+    float dp = dot(ds.d, ds.n);
+    bool active = dp < 0.f;
+    float value = rc.inv_area, adp = std::fabs(dot(ds.d, ds.n));
+    value *= (adp != 0.f) ? (ds.dist * ds.dist) / adp : 0.f;
+    if (e.d.type == BF_TRANSMITTER_WIGNER) value *= rect_sample_wigner(rc, ds.p, -ds.d, cx.lambda0);
+    return active ? value : 0.f;
+}
+
+// Scene::sample_transmitter_direction — src/librender/scene.cpp:249-299
+static float scene_sample_transmitter_direction(const OScene &sc, const SI &ref, float sx, float sy, const RxCtx &cx,
+                                                DirectionSample &ds, uint32_t &n_shadow) {
+    float spec;
+    size_t k = sc.emitters.size();
+    if (k == 0) {
+        ds = DirectionSample();
+        return 0.f;
+    }
+    if (k == 1) {
+        spec = transmitter_sample_direction(sc, sc.emitters[0], ref, sx, sy, cx, ds);
+    } else {
+        float pdf = 1.f / (float) k;
+        uint32_t index = std::min((uint32_t) (sx * (float) k), (uint32_t) k - 1);
+        sx = (sx - index * pdf) * (float) k;
+        spec = transmitter_sample_direction(sc, sc.emitters[index], ref, sx, sy, cx, ds);
+        ds.pdf *= pdf;
+        spec *= rcp(pdf);
+    }
+    if (ds.pdf != 0.f) {
+        Ray ray;
+        ray.o = ref.p;
+        ray.d = ds.d;
+        ray.mint = kRayEpsilon * (1.f + hmax_abs(ref.p));
+        ray.maxt = ds.dist * (1.f - kShadowEpsilon);
+        ray.time = ref.time;
+        ++n_shadow;
+        if (ray_test(sc, ray)) spec = 0.f;
+    }
+    return spec;
+}
+
+// PathTimeFrequencyIntegrator::sample — src/integrators/pathtimefrequency.cpp:103-460
+static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, const RxCtx &cx) {
+    PathResult r;
+    float eta = 1.f, emission_weight = 1.f, throughput = 1.f, result = 0.f;
+    bool active = true;
+    const float c = sc.physics.c;
+    SI si = ray_intersect(sc, ray);
+    ++r.n_closest;
+    bool valid_ray = si.valid();
+    int tx = si.valid() ? sc.shapes[si.shape].emitter : -1;
+    if (si.valid()) {                    // :149-153 ray.update_state(-si.t)
+        ray.time += -si.t / c;
+        si.time = ray.time;
+    }
+    for (int depth = 1;; ++depth) {
+        if (tx >= 0 && active) result += emission_weight * throughput * transmitter_eval(sc, sc.emitters[tx], si, cx);
+        active = active && si.valid();
+        if (depth > lp.rr_depth) {
+            float q = std::min(throughput * sqr(eta), .95f);
+            active = (smp.next_1d() < q) && active;
+            throughput *= rcp(q);
+        }
+        if ((uint32_t) depth >= (uint32_t) lp.max_depth || !active) break;
+        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+        ++r.n_bounces;
+        if (bsdf_smooth(mat)) {
+            float sx, sy;
+            smp.next_2d(sx, sy);
+            DirectionSample ds;
+            float tv = scene_sample_transmitter_direction(sc, si, sx, sy, cx, ds, r.n_shadow);
+            bool active_e = ds.pdf != 0.f;
+            V3 wo = si.sh.to_local(ds.d);
+            float bsdf_val = bsdf_eval(mat, si.wi, wo);
+            float bsdf_pdf_ = bsdf_pdf(mat, si.wi, wo);
+            float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf_);
+            if (active_e) result += mis * throughput * bsdf_val * tv;
+        }
+        float s1 = smp.next_1d(), s2x, s2y;
+        smp.next_2d(s2x, s2y);
+        BSDFSample bs;
+        float bsdf_val = bsdf_sample(mat, si.wi, s1, s2x, s2y, bs);
+        throughput = throughput * bsdf_val;
+        active = active && (throughput != 0.f);
+        if (!active) break;
+        eta *= bs.eta;
+        Ray nray;
+        nray.o = si.p;
+        nray.d = si.sh.to_world(bs.wo);
+        nray.mint = (1.f + hmax_abs(si.p)) * kRayEpsilon;
+        nray.maxt = kInf;
+        nray.time = si.time;
+        SI si_bsdf = ray_intersect(sc, nray);
+        ++r.n_closest;
+        // :368-371 — executed even when si_bsdf.t is +inf (Q3)
+        nray.time += -si_bsdf.t / c;
+        si_bsdf.time = nray.time;
+        tx = si_bsdf.valid() ? sc.shapes[si_bsdf.shape].emitter : -1;
+        if (tx >= 0) {
+            DirectionSample ds;
+            ds.p = si_bsdf.p;
+            ds.n = si_bsdf.sh.n;
+            ds.d = si_bsdf.p - si.p;
+            ds.dist = norm(ds.d);
+            ds.d = ds.d / ds.dist;
+            float tpdf = transmitter_pdf_direction(sc, sc.emitters[tx], ds, cx);
+            if (sc.emitters.size() != 1) tpdf *= 1.f / (float) sc.emitters.size();
+            emission_weight = mis_weight(bs.pdf, tpdf);
+        }
+        si = si_bsdf;
+    }
+    r.L = result;
+    r.valid = valid_ray;
+    return r;
+}
+
+// Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
+static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, float px, float py, float ax, float ay,
+                                 Ray &ray, RxCtx &cx) {
+    const bf_sensor &s = sc.sensor;
+    const Rect &rc = sc.rects[sc.shapes[s.shape].rect];
+    V3 p = xf_point(rc.to_world, V3{px * 2.f - 1.f, py * 2.f - 1.f, 0.f});
+    V3 local = square_to_cosine_hemisphere(ax, ay);
+    Frame f = frame_from_normal(rc.frame.n);
+    ray.o = p;
+    ray.d = f.to_world(local);
+    ray.mint = kRayEpsilon;
+    ray.maxt = kInf;
+    ray.time = time;
+    float area = rc.area;
+    if (s.type == BF_RECEIVER_OMNI) {
+        // sample_wavelength (spectrum.h:365-376) -> sample_uniform_spectrum: lane 0 of sample_shifted is the sample itself
+        float lo = sc.physics.lambda_min_nm, hi = sc.physics.lambda_max_nm;
+        cx.lambda0 = wl_sample * (hi - lo) + lo;
+        return (hi - lo) * area;
+    }
+    // wigner receiver, receive_type raw: frequency uniform in [fc - B/2, fc + B/2]
+    float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    // Wavelength wavelength = MTS_C*rcp(frequencies)*1e9  (float * float, then * double literal)
+    cx.lambda0 = (float) ((double) (sc.physics.c * rcp(freq)) * 1e9);
+    float ws = rect_sample_wigner(rc, p, local, cx.lambda0);     // ds.d is the LOCAL cosine direction (:249-252)
+    float geom_gain = ws * rc.inv_area;
+    float extents = area * kPi;
+    if (!s.rx_sig_is_delta) extents = (float) ((double) (extents * (sc.physics.c * rcp(s.freq_ext))) * 1e9);
+    return 1.f * s.gain * geom_gain * extents;
+}
+
 // ---------------------------------------------------------------------------
 // film: SamplingIntegrator::render_sample (integrator.cpp:259-310) +
 // RangeIntegrator / TimeIntegrator AOV fill (range.cpp:141-161,
@@ -1106,7 +1351,7 @@ static uint32_t launch_channels(const bf_launch &lp) {
         case BF_MODE_PATH: return 5;
         case BF_MODE_RANGE: return 5 + lp.bins;
         case BF_MODE_TIME: return 5 + 3 * lp.bins;
-        case BF_MODE_RECEIVE_RAW: return 3;
+        case BF_MODE_RECEIVE_RAW: return 3 * lp.bins * lp.bins_y;
     }
     return 0;
 }
@@ -1172,6 +1417,49 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     return out;
 }
 
+// SamplingIntegrator::receive_sample — src/librender/integrator.cpp:1538-1667
+// (receive_type "raw") + SignalBlock::put box branch (signalblock.cpp:162-169).
+// The reference runs in scalar_spectral (Q9): four wavelength lanes that carry
+// identical values for uniform spectra, so hsum() is 4 x the lane value.
+static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, double *hist) {
+    SampleOut out;
+    const bf_sensor &s = sc.sensor;
+    float fx, fy, ax = .5f, ay = .5f;
+    smp.next_2d(fx, fy);                                    // :1544
+    smp.next_2d(ax, ay);                                    // :1549-1552 (needs_sample_3 defaults to true)
+    float time = s.adc_sampling_start;                      // :1556-1561
+    if (s.adc_sampling_time > 0.f)
+        time += smp.next_1d() * s.adc_sampling_time;
+    else
+        time = 0.f;
+    float wl = smp.next_1d();                               // :1565
+    Ray ray;
+    RxCtx cx;
+    float w = receiver_sample_ray(sc, time, wl, fx, fy, ax, ay, ray, cx);
+    out.pr = ptf_sample(sc, lp, smp, ray, cx);
+    float tf0 = time - s.adc_sampling_start;                // :1625-1626
+    float tf1 = freq_of(sc, cx.lambda0);
+    tf0 *= (float) s.t_bins / s.t_bandwidth;                // :1639
+    tf1 *= (float) s.f_bins / s.f_bandwidth;
+    float L = std::fabs(w) * out.pr.L;                      // :1643
+    float a0 = out.pr.valid ? 4.f * L : 0.f;                // hsum over the 4 identical spectral lanes :1661
+    float a1 = out.pr.valid ? 1.f : 0.f, a2 = 1.f;
+    out.L = a0;
+    out.pr.aux = time - s.adc_sampling_start;
+    bool ok = std::isfinite(a0);
+    // pos = tf - (offset - border + .5); lo = ceil(pos - .5)
+    float lx = std::ceil((tf0 - .5f) - .5f), ly = std::ceil((tf1 - .5f) - .5f);
+    ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
+    out.put = ok;
+    if (ok) {
+        size_t off = 3 * ((size_t) ly * lp.bins + (size_t) lx);
+        hist[off + 0] += (double) a0;
+        hist[off + 1] += (double) a1;
+        hist[off + 2] += (double) a2;
+    }
+    return out;
+}
+
 static thread_local std::string g_err;
 
 }  // namespace
@@ -1219,7 +1507,8 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
             rc.frame.t = xf_vector(rc.to_world, V3{0.f, 2.f, 0.f});
             // Transform * Normal uses the inverse transpose: row 2 of to_object
             rc.frame.n = normalize(V3{rc.to_object.m[8], rc.to_object.m[9], rc.to_object.m[10]});
-            rc.inv_area = rcp(norm(cross(rc.frame.s, rc.frame.t)));
+            rc.area = norm(cross(rc.frame.s, rc.frame.t));
+            rc.inv_area = rcp(rc.area);
             sh.rect = (int32_t) sc.rects.size();
             sh.prim_count = 1;
             sc.rects.push_back(rc);
@@ -1299,9 +1588,10 @@ uint32_t bfo_launch_channels(const bf_launch *lp) { return launch_channels(*lp);
 bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int n_threads, float *hist_out,
                      bf_path_record *records_out, bf_stats *stats_out) {
     if (!s || !lp || !hist_out) return BF_ERR_INVALID;
-    if (lp->mode == BF_MODE_RECEIVE_RAW) {
-        g_err = "receive mode: use bfo_receive";
-        return BF_ERR_UNSUPPORTED;
+    const bool is_receive = lp->mode == BF_MODE_RECEIVE_RAW;
+    if (is_receive && (s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.type != BF_RECEIVER_WIGNER)) {
+        g_err = "receive mode needs a receiver";
+        return BF_ERR_INVALID;
     }
     const OScene &sc = s->sc;
     const uint32_t nchan = launch_channels(*lp);
@@ -1319,7 +1609,8 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
         if (rng_mode == 1) smp.rng.seed(lp->seed + 0);
         for (uint64_t i = lo; i < hi; ++i) {
             if (rng_mode == 0) smp.rng.seed(lp->seed + lp->path_offset + i);
-            SampleOut o = render_sample(sc, *lp, smp, th_hist[tid].data());
+            SampleOut o = is_receive ? receive_sample(sc, *lp, smp, th_hist[tid].data())
+                                     : render_sample(sc, *lp, smp, th_hist[tid].data());
             bf_stats &st = th_stats[tid];
             st.n_paths++;
             st.n_rays_closest += o.pr.n_closest;
@@ -1480,6 +1771,6 @@ float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x
     return w;
 }
 float bfo_erfinv(float x) { return erfinv_giles(x); }
-float bfo_rect_area(const bfo_scene *s, uint32_t rect) { return 1.f / s->sc.rects[rect].inv_area; }
+float bfo_rect_area(const bfo_scene *s, uint32_t rect) { return s->sc.rects[rect].area; }
 
 }  // extern "C"
