@@ -1,0 +1,99 @@
+// bfrender — command line front end with the reference CLI's flags
+// (src/mitsuba/mitsuba.cpp:173-183): -m variant, -D name=value, -o output,
+// -r (call receive() instead of render()), -v verbose.  Writes the raw
+// film / ADC storage as a little-endian float32 .npy (EXR output is out of scope).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "render.h"
+
+using namespace bfh;
+
+static void save_npy(const std::string &path, const float *data, unsigned rows, unsigned cols, unsigned ch) {
+    std::ofstream f(path, std::ios::binary);
+    std::string hdr = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(rows) + ", " +
+                      std::to_string(cols) + ", " + std::to_string(ch) + "), }";
+    size_t total = 10 + hdr.size() + 1;
+    hdr.append((64 - total % 64) % 64, ' ');
+    hdr.push_back('\n');
+    unsigned short hl = (unsigned short) hdr.size();
+    f.write("\x93NUMPY\x01\x00", 8);
+    f.write((const char *) &hl, 2);
+    f.write(hdr.data(), (std::streamsize) hdr.size());
+    f.write((const char *) data, (std::streamsize) ((size_t) rows * cols * ch * 4));
+}
+
+int main(int argc, char **argv) {
+    std::string variant_name = "scalar_rgb", output, scene_file;
+    bool do_receive = false;
+    xml::ParameterList params;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-m" && i + 1 < argc) variant_name = argv[++i];
+        else if (a == "-o" && i + 1 < argc) output = argv[++i];
+        else if (a == "-r") do_receive = true;
+        else if (a == "-v") set_log_level(Debug);
+        else if (a == "-t" && i + 1 < argc) ++i;    // thread count: the work runs on the GPU
+        else if (a.rfind("-D", 0) == 0) {
+            std::string kv = a.size() > 2 ? a.substr(2) : (i + 1 < argc ? argv[++i] : "");
+            size_t k = kv.find('=');
+            if (k == std::string::npos) {
+                fprintf(stderr, "-D expects name=value\n");
+                return 2;
+            }
+            params.emplace_back(kv.substr(0, k), kv.substr(k + 1));
+        } else if (a == "-h" || a == "--help") {
+            printf("usage: bfrender [-m variant] [-D name=value]... [-r] [-o out.npy] [-v] scene.xml\n");
+            return 0;
+        } else {
+            scene_file = a;
+        }
+    }
+    if (scene_file.empty()) {
+        fprintf(stderr, "bfrender: no scene file given (try --help)\n");
+        return 2;
+    }
+    try {
+        set_variant(variant_name);
+        ref<Object> obj = xml::load_file(scene_file, params);
+        auto *scene = dynamic_cast<Scene *>(obj.get());
+        if (!scene) Throw("top-level object is not a scene");
+        Integrator *in = scene->integrator();
+        const float *data;
+        unsigned rows, cols, ch;
+        const bf_stats *st;
+        if (do_receive) {
+            if (scene->receivers().empty()) Throw("-r given but the scene has no receiver");
+            Receiver *r = scene->receivers()[0].get();
+            in->receive(scene, r);
+            data = r->adc()->bitmap().data();
+            rows = r->adc()->f_bins();
+            cols = r->adc()->t_bins();
+            ch = (unsigned) r->adc()->channels().size();
+        } else {
+            if (scene->sensors().empty()) Throw("the scene has no sensor");
+            Sensor *s = scene->sensors()[0].get();
+            in->render(scene, s);
+            data = s->film()->bitmap().data();
+            rows = s->film()->height();
+            cols = s->film()->width();
+            ch = (unsigned) s->film()->channels().size();
+        }
+        st = &in->last_stats().stats;
+        printf("rendered %llu paths, %llu rays in %.3f ms (kernels %.3f ms) -> [%u, %u, %u]\n",
+               (unsigned long long) st->n_paths, (unsigned long long) (st->n_rays_closest + st->n_rays_shadow),
+               in->last_stats().wall_ms, st->kernel_ms, rows, cols, ch);
+        if (output.empty()) {
+            size_t k = scene_file.find_last_of('.');
+            output = (k == std::string::npos ? scene_file : scene_file.substr(0, k)) + ".npy";
+        }
+        save_npy(output, data, rows, cols, ch);
+        printf("wrote %s\n", output.c_str());
+    } catch (const std::exception &e) {
+        fprintf(stderr, "bfrender: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,175 @@
+// C API over the host layer, bound by beifong_amd/mitsuba_compat.py (ctypes) the
+// way the reference binds its C++ through pybind11 (src/librender/python/
+// integrator_v.cpp: render / receive with the GIL released, film / adc bitmap).
+// Errors never cross as exceptions: status + bfh_last_error().
+#include <cstring>
+#include <string>
+
+#include "render.h"
+
+using namespace bfh;
+
+static thread_local std::string g_err;
+#define BFH_TRY(body)                   \
+    try {                               \
+        body;                           \
+        return 0;                       \
+    } catch (const std::exception &e) { \
+        g_err = e.what();               \
+        return 1;                       \
+    }
+
+extern "C" {
+
+const char *bfh_last_error(void) { return g_err.c_str(); }
+int bfh_set_variant(const char *v) { BFH_TRY(set_variant(v)) }
+const char *bfh_variant(void) { return variant().c_str(); }
+int bfh_set_log_level(int level) { BFH_TRY(set_log_level((LogLevel) level)) }
+
+static xml::ParameterList make_params(int n, const char **keys, const char **values) {
+    xml::ParameterList p;
+    for (int i = 0; i < n; ++i) p.emplace_back(keys[i], values[i]);
+    return p;
+}
+static int hold(ref<Object> o, void **out) {
+    o->inc_ref();    // the handle owns one reference until bfh_release
+    *out = o.get();
+    return 0;
+}
+int bfh_load_file(const char *path, int n, const char **keys, const char **values, void **out) {
+    BFH_TRY(hold(xml::load_file(path, make_params(n, keys, values)), out))
+}
+int bfh_load_string(const char *text, const char *base_dir, int n, const char **keys, const char **values, void **out) {
+    BFH_TRY(hold(xml::load_string(text, make_params(n, keys, values), base_dir ? base_dir : "."), out))
+}
+void bfh_release(void *obj) {
+    if (obj) ((Object *) obj)->dec_ref();
+}
+const char *bfh_class_name(void *obj) { return ((Object *) obj)->class_()->name().c_str(); }
+
+static Scene *as_scene(void *o) {
+    auto *s = dynamic_cast<Scene *>((Object *) o);
+    if (!s) Throw("object is not a Scene");
+    return s;
+}
+int bfh_scene_counts(void *scene, int *n_shapes, int *n_sensors, int *n_receivers, int *n_emitters, int *n_transmitters) {
+    BFH_TRY({
+        Scene *s = as_scene(scene);
+        *n_shapes = (int) s->shapes().size();
+        *n_sensors = (int) s->sensors().size();
+        *n_receivers = (int) s->receivers().size();
+        *n_emitters = (int) s->emitters().size();
+        *n_transmitters = (int) s->transmitters().size();
+    })
+}
+void *bfh_scene_integrator(void *scene) { return as_scene(scene)->integrator(); }
+void *bfh_scene_sensor(void *scene, int i) { return as_scene(scene)->sensors().at(i).get(); }
+void *bfh_scene_receiver(void *scene, int i) { return as_scene(scene)->receivers().at(i).get(); }
+void *bfh_scene_shape(void *scene, int i) { return as_scene(scene)->shapes().at(i).get(); }
+int bfh_shape_info(void *shape, unsigned *prims, float *area) {
+    BFH_TRY({
+        auto *s = dynamic_cast<Shape *>((Object *) shape);
+        if (!s) Throw("object is not a Shape");
+        *prims = s->primitive_count();
+        *area = s->surface_area();
+    })
+}
+/// flattened description the integrator hands to bf_scene_create (for tests: the
+/// same pointer can be given to the CPU oracle)
+const bf_scene_desc *bfh_scene_flat_desc(void *scene, void *endpoint) {
+    try {
+        return as_scene(scene)->flat_desc(dynamic_cast<Endpoint *>((Object *) endpoint));
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+/// the bf_launch the integrator would issue for this endpoint
+int bfh_integrator_launch(void *integrator, void *endpoint, bf_launch *out) {
+    BFH_TRY({
+        auto *in = dynamic_cast<SamplingIntegrator *>((Object *) integrator);
+        if (!in) Throw("object is not a SamplingIntegrator");
+        std::memset(out, 0, sizeof(*out));
+        out->color_mode = variant() == "scalar_rgb" ? BF_COLOR_RGB : BF_COLOR_MONO;
+        out->max_depth = -1;
+        out->rr_depth = 5;
+        out->time_c = 3.0e8f;
+        in->configure(*out);
+        if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) {
+            out->n_paths = se->sampler()->sample_count();
+            out->seed = se->sampler()->base_seed();
+        } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
+            out->n_paths = re->sampler()->sample_count();
+            out->seed = re->sampler()->base_seed();
+            out->bins = re->adc()->t_bins();
+            out->bins_y = re->adc()->f_bins();
+            out->color_mode = BF_COLOR_MONO;
+        }
+    })
+}
+int bfh_integrator_render(void *integrator, void *scene, void *sensor) {
+    BFH_TRY({
+        auto *in = dynamic_cast<Integrator *>((Object *) integrator);
+        auto *se = dynamic_cast<Sensor *>((Object *) sensor);
+        if (!in || !se) Throw("render(): expected (Integrator, Scene, Sensor)");
+        in->render(as_scene(scene), se);
+    })
+}
+int bfh_integrator_receive(void *integrator, void *scene, void *receiver) {
+    BFH_TRY({
+        auto *in = dynamic_cast<Integrator *>((Object *) integrator);
+        auto *re = dynamic_cast<Receiver *>((Object *) receiver);
+        if (!in || !re) Throw("receive(): expected (Integrator, Scene, Receiver)");
+        in->receive(as_scene(scene), re);
+    })
+}
+int bfh_integrator_stats(void *integrator, bf_stats *out, double *wall_ms) {
+    BFH_TRY({
+        auto *in = dynamic_cast<Integrator *>((Object *) integrator);
+        if (!in) Throw("object is not an Integrator");
+        *out = in->last_stats().stats;
+        *wall_ms = in->last_stats().wall_ms;
+    })
+}
+int bfh_sensor_sample_count(void *endpoint, unsigned long long *n) {
+    BFH_TRY({
+        if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) *n = se->sampler()->sample_count();
+        else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) *n = re->sampler()->sample_count();
+        else Throw("object is neither a Sensor nor a Receiver");
+    })
+}
+/// film.bitmap(raw=True) / adc.bitmap(raw=True): float32 [rows][cols][channels]
+int bfh_bitmap(void *endpoint, const float **data, unsigned *rows, unsigned *cols, unsigned *channels) {
+    BFH_TRY({
+        if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) {
+            Film *f = se->film();
+            *data = f->bitmap().data();
+            *rows = f->height();
+            *cols = f->width();
+            *channels = (unsigned) f->channels().size();
+        } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
+            ADC *a = re->adc();
+            *data = a->bitmap().data();
+            *rows = a->f_bins();
+            *cols = a->t_bins();
+            *channels = (unsigned) a->channels().size();
+        } else {
+            Throw("object is neither a Sensor nor a Receiver");
+        }
+        if (*channels == 0) Throw("bitmap(): nothing has been rendered yet");
+    })
+}
+const char *bfh_channel_name(void *endpoint, unsigned i) {
+    if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) return se->film()->channels().at(i).c_str();
+    if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) return re->adc()->channels().at(i).c_str();
+    return "";
+}
+int bfh_loaded_plugins(char *buf, int cap) {
+    std::string s;
+    for (auto &p : PluginManager::instance()->loaded_plugins()) s += p + ",";
+    std::strncpy(buf, s.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+    return (int) s.size();
+}
+
+}  // extern "C"

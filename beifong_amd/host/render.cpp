@@ -1,0 +1,479 @@
+// beifong_amd host layer — render classes (see render.h).
+#include "render.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace bfh {
+
+// ---- class registry (class.h:195-211; aliases are the XML tags, xml.cpp:153-161)
+static Class c_texture("Texture", "Object", "", nullptr, "texture");
+static Class c_rfilter("ReconstructionFilter", "Object", "", nullptr, "rfilter");
+static Class c_sampler("Sampler", "Object", "", nullptr, "sampler");
+static Class c_bsdf("BSDF", "Object", "", nullptr, "bsdf");
+static Class c_film("Film", "Object", "", nullptr, "film");
+static Class c_adc("ADC", "Object", "", nullptr, "adc");
+static Class c_endpoint("Endpoint", "Object", "", nullptr);
+static Class c_emitter("Emitter", "Endpoint", "", nullptr, "emitter");
+static Class c_transmitter("Transmitter", "Endpoint", "", nullptr, "transmitter");
+static Class c_sensor("Sensor", "Endpoint", "", nullptr, "sensor");
+static Class c_receiver("Receiver", "Endpoint", "", nullptr, "receiver");
+static Class c_shape("Shape", "Object", "", nullptr, "shape");
+static Class c_mesh("Mesh", "Shape", "", nullptr);
+static Class c_integrator("Integrator", "Object", "", nullptr, "integrator");
+static Class c_sampling_integrator("SamplingIntegrator", "Integrator", "", nullptr);
+static Object *construct_scene(const Properties &p) { return new Scene(p); }
+static Class c_scene("Scene", "Object", "", construct_scene, "scene");
+
+const Class *Texture::class_() const { return &c_texture; }
+const Class *ReconstructionFilter::class_() const { return &c_rfilter; }
+const Class *Sampler::class_() const { return &c_sampler; }
+const Class *BSDF::class_() const { return &c_bsdf; }
+const Class *Film::class_() const { return &c_film; }
+const Class *ADC::class_() const { return &c_adc; }
+const Class *Endpoint::class_() const { return &c_endpoint; }
+const Class *Emitter::class_() const { return &c_emitter; }
+const Class *Transmitter::class_() const { return &c_transmitter; }
+const Class *Sensor::class_() const { return &c_sensor; }
+const Class *Receiver::class_() const { return &c_receiver; }
+const Class *Shape::class_() const { return &c_shape; }
+const Class *Mesh::class_() const { return &c_mesh; }
+const Class *Integrator::class_() const { return &c_integrator; }
+const Class *SamplingIntegrator::class_() const { return &c_sampling_integrator; }
+const Class *Scene::class_() const { return &c_scene; }
+
+float Properties::texture_value(const std::string &n, float def) const {
+    auto it = m_entries.find(n);
+    if (it == m_entries.end()) return def;
+    const Entry &e = it->second;
+    e.queried = true;
+    if (e.type == Type::Float) return (float) e.f;
+    if (e.type == Type::Long) return (float) e.l;
+    if (e.type == Type::Object) {
+        auto *t = dynamic_cast<Texture *>(e.o.get());
+        if (t) return t->value();
+    }
+    Throw("The property \"%s\" must be a float or a (uniform) spectrum.", n.c_str());
+}
+
+// ---- small objects ----------------------------------------------------------
+Sampler::Sampler(const Properties &props) {
+    m_sample_count = (size_t) props.int_("sample_count", 4);    // sampler.cpp:11-16
+    m_base_seed = (uint64_t) props.int_("seed", 0);
+}
+
+static ref<ReconstructionFilter> find_filter(const Properties &props, const char *def_plugin) {
+    for (auto &kv : props.objects(false)) {
+        auto *f = dynamic_cast<ReconstructionFilter *>(kv.second.get());
+        if (f) {
+            props.mark_queried(kv.first);
+            return f;
+        }
+    }
+    ref<Object> o = PluginManager::instance()->create_object(Properties(def_plugin), "ReconstructionFilter");
+    return dynamic_cast<ReconstructionFilter *>(o.get());
+}
+
+Film::Film(const Properties &props) {
+    m_width = (uint32_t) props.int_("width", 768);              // film.cpp
+    m_height = (uint32_t) props.int_("height", 576);
+    m_filter = find_filter(props, "gaussian");
+}
+void Film::prepare(const std::vector<std::string> &channels) {
+    m_channels = channels;
+    m_storage.assign((size_t) m_width * m_height * channels.size(), 0.f);
+}
+void Film::put(const float *data, size_t n) {
+    if (n != m_storage.size()) Throw("Film::put(): mismatched block size");
+    for (size_t i = 0; i < n; ++i) m_storage[i] += data[i];
+}
+
+ADC::ADC(const Properties &props) {
+    m_t_bins = (uint32_t) props.int_("t_bins", 1024);           // adc.cpp:9-13
+    m_f_bins = (uint32_t) props.int_("f_bins", 1024);
+    if (props.int_("window_t_bins", m_t_bins) != (int64_t) m_t_bins || props.int_("window_f_bins", m_f_bins) != (int64_t) m_f_bins ||
+        props.int_("window_offset_t", 0) != 0 || props.int_("window_offset_f", 0) != 0)
+        Throw("ADC: crop windows are not supported");
+    m_t_bandwidth = props.float_("t_bandwidth", 3.81e-6f);      // adc.cpp:27-29
+    m_f_bandwidth = props.float_("f_bandwidth", 250e6f);
+    (void) props.bool_("high_quality_edges", false);
+    m_filter = find_filter(props, "gaussian");                  // adc.cpp:70-75 default
+}
+void ADC::prepare(const std::vector<std::string> &channels) {
+    m_channels = channels;
+    m_storage.assign((size_t) m_t_bins * m_f_bins * channels.size(), 0.f);
+}
+void ADC::put(const float *data, size_t n) {
+    if (n != m_storage.size()) Throw("ADC::put(): mismatched block size");
+    for (size_t i = 0; i < n; ++i) m_storage[i] += data[i];
+}
+
+Endpoint::Endpoint(const Properties &props) { m_to_world = props.transform("to_world", Transform4f()); }
+
+template <typename T> static ref<T> find_child(const Properties &props, const char *what, bool unique = true) {
+    ref<T> r;
+    for (auto &kv : props.objects(false)) {
+        auto *p = dynamic_cast<T *>(kv.second.get());
+        if (p) {
+            if (r && unique) Throw("Only one %s can be specified per object.", what);
+            r = p;
+            props.mark_queried(kv.first);
+        }
+    }
+    return r;
+}
+
+Sensor::Sensor(const Properties &props) : Endpoint(props) {
+    m_shutter_open = props.float_("shutter_open", 0.f);         // sensor.cpp
+    m_shutter_open_time = props.float_("shutter_close", 0.f) - m_shutter_open;
+    if (m_shutter_open_time < 0) Throw("Shutter opening time must be less than or equal to the shutter closing time!");
+    m_film = find_child<Film>(props, "film");
+    m_sampler = find_child<Sampler>(props, "sampler");
+    auto pm = PluginManager::instance();
+    if (!m_film) m_film = dynamic_cast<Film *>(pm->create_object(Properties("hdrfilm"), "Film").get());
+    if (!m_sampler) {
+        Properties ps("independent");
+        ps.set_long("sample_count", 4);
+        m_sampler = dynamic_cast<Sampler *>(pm->create_object(ps, "Sampler").get());
+    }
+}
+
+Receiver::Receiver(const Properties &props) : Endpoint(props) {
+    m_adc_sampling_start = props.float_("adc_sampling_start", 0.f);        // receiver.cpp:16-24
+    m_adc_sampling_time = props.float_("adc_sampling_end", 0.f) - m_adc_sampling_start;
+    m_receive_type = props.string("receive_type", "raw");
+    if (m_adc_sampling_time < 0) Throw("ADC sampling time must be less than or equal to the adc sampling end time!");
+    m_adc = find_child<ADC>(props, "adc");
+    m_sampler = find_child<Sampler>(props, "sampler");
+    auto pm = PluginManager::instance();
+    if (!m_adc) m_adc = dynamic_cast<ADC *>(pm->create_object(Properties("hdradc"), "ADC").get());
+    if (!m_sampler) {
+        Properties ps("independent");
+        ps.set_long("sample_count", 4);
+        m_sampler = dynamic_cast<Sampler *>(pm->create_object(ps, "Sampler").get());
+    }
+}
+
+Shape::Shape(const Properties &props) {
+    m_to_world = props.transform("to_world", Transform4f());
+    // shape.cpp:38-98
+    for (auto &kv : props.objects(false)) {
+        Object *o = kv.second.get();
+        bool used = true;
+        if (auto *e = dynamic_cast<Emitter *>(o)) {
+            if (m_emitter) Throw("Only a single Emitter child object can be specified per shape.");
+            m_emitter = e;
+        } else if (auto *t = dynamic_cast<Transmitter *>(o)) {
+            if (m_transmitter) Throw("Only a single Transmitter child object can be specified per shape.");
+            m_transmitter = t;
+        } else if (auto *s = dynamic_cast<Sensor *>(o)) {
+            if (m_sensor) Throw("Only a single Sensor child object can be specified per shape.");
+            m_sensor = s;
+        } else if (auto *r = dynamic_cast<Receiver *>(o)) {
+            if (m_receiver) Throw("Only a single Receiver child object can be specified per shape.");
+            m_receiver = r;
+        } else if (auto *b = dynamic_cast<BSDF *>(o)) {
+            if (m_bsdf) Throw("Only a single BSDF child object can be specified per shape.");
+            m_bsdf = b;
+        } else {
+            used = false;
+        }
+        if (used) props.mark_queried(kv.first);
+    }
+    if (!m_bsdf) {
+        // shape.cpp:89-98: default diffuse; black if the shape emits / transmits
+        Properties pb("diffuse");
+        if (m_emitter || m_transmitter) pb.set_float("reflectance", 0.0);
+        m_bsdf = dynamic_cast<BSDF *>(PluginManager::instance()->create_object(pb, "BSDF").get());
+    }
+    if (m_emitter) m_emitter->set_shape(this);
+    if (m_transmitter) m_transmitter->set_shape(this);
+    if (m_sensor) m_sensor->set_shape(this);
+    if (m_receiver) m_receiver->set_shape(this);
+}
+
+float Mesh::surface_area() const {
+    double a = 0;
+    for (size_t f = 0; f < m_faces.size() / 3; ++f) {
+        const float *p0 = &m_positions[3 * m_faces[3 * f]], *p1 = &m_positions[3 * m_faces[3 * f + 1]],
+                    *p2 = &m_positions[3 * m_faces[3 * f + 2]];
+        double e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+        double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        a += 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    }
+    return (float) a;
+}
+
+void Mesh::recompute_vertex_normals() {
+    // mesh.cpp:201-249: angle-weighted (Thuermer & Wuethrich), fp32 accumulate
+    size_t nv = vertex_count(), nf = primitive_count();
+    std::vector<float> nrm(3 * nv, 0.f);
+    size_t invalid = 0;
+    auto V = [&](uint32_t i, double *o) {
+        o[0] = m_positions[3 * i];
+        o[1] = m_positions[3 * i + 1];
+        o[2] = m_positions[3 * i + 2];
+    };
+    for (size_t f = 0; f < nf; ++f) {
+        uint32_t fi[3] = {m_faces[3 * f], m_faces[3 * f + 1], m_faces[3 * f + 2]};
+        double v[3][3];
+        for (int k = 0; k < 3; ++k) V(fi[k], v[k]);
+        double s0[3], s1[3], n[3];
+        for (int k = 0; k < 3; ++k) {
+            s0[k] = v[1][k] - v[0][k];
+            s1[k] = v[2][k] - v[0][k];
+        }
+        n[0] = s0[1] * s1[2] - s0[2] * s1[1];
+        n[1] = s0[2] * s1[0] - s0[0] * s1[2];
+        n[2] = s0[0] * s1[1] - s0[1] * s1[0];
+        double l2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        if (!(l2 > 0)) continue;
+        double il = 1.0 / std::sqrt(l2);
+        for (int k = 0; k < 3; ++k) n[k] *= il;
+        for (int j = 0; j < 3; ++j) {
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) {
+                a[k] = v[(j + 1) % 3][k] - v[j][k];
+                b[k] = v[(j + 2) % 3][k] - v[j][k];
+            }
+            double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+            double c = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) / (la * lb);
+            double ang = std::acos(std::max(-1.0, std::min(1.0, c)));
+            for (int k = 0; k < 3; ++k) nrm[3 * fi[j] + k] += (float) (n[k] * ang);
+        }
+    }
+    for (size_t i = 0; i < nv; ++i) {
+        float *n = &nrm[3 * i];
+        float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (len != 0.f) {
+            n[0] /= len; n[1] /= len; n[2] /= len;
+        } else {
+            n[0] = 1; n[1] = 0; n[2] = 0;
+            ++invalid;
+        }
+    }
+    if (invalid) Log(Warn, "computed vertex normals (%zu invalid vertices!)", invalid);
+    m_normals.swap(nrm);
+}
+
+// ---- scene --------------------------------------------------------------------
+struct Scene::Flat {
+    const Endpoint *endpoint = nullptr;
+    std::vector<bf_shape> shapes;
+    std::vector<bf_material> materials;
+    std::vector<bf_emitter> emitters;
+    bf_scene_desc desc;
+    bf_scene *device = nullptr;
+};
+
+Scene::Scene(const Properties &props) {
+    // scene.cpp:22-71
+    for (auto &kv : props.objects()) {
+        Object *o = kv.second.get();
+        if (auto *s = dynamic_cast<Shape *>(o)) {
+            m_shapes.push_back(s);
+            if (s->emitter()) m_emitters.push_back(s->emitter());
+            if (s->transmitter()) m_transmitters.push_back(s->transmitter());
+            if (s->sensor()) m_sensors.push_back(s->sensor());
+            if (s->receiver()) m_receivers.push_back(s->receiver());
+        } else if (auto *e = dynamic_cast<Emitter *>(o)) {
+            m_emitters.push_back(e);
+        } else if (auto *t = dynamic_cast<Transmitter *>(o)) {
+            m_transmitters.push_back(t);
+        } else if (auto *se = dynamic_cast<Sensor *>(o)) {
+            m_sensors.push_back(se);
+        } else if (auto *r = dynamic_cast<Receiver *>(o)) {
+            m_receivers.push_back(r);
+        } else if (auto *in = dynamic_cast<Integrator *>(o)) {
+            if (m_integrator) Throw("Only one integrator can be specified per scene.");
+            m_integrator = in;
+        }
+    }
+    auto pm = PluginManager::instance();
+    if (m_sensors.empty() && m_receivers.empty()) {
+        // scene.cpp:73-98 synthesises a perspective camera that frames the
+        // scene; radar scenes always carry a sensor / receiver
+        Throw("Scene: no sensor or receiver specified (the auto-camera of scene.cpp:73-98 is not part of the radar path)");
+    }
+    if (!m_integrator) {
+        Log(Warn, "No integrator found! Instantiating a path tracer..");   // scene.cpp:100-104
+        m_integrator = dynamic_cast<Integrator *>(pm->create_object(Properties("path"), "Integrator").get());
+    }
+}
+Scene::~Scene() {
+    if (m_flat && m_flat->device) bf_scene_destroy(m_flat->device);
+}
+
+static void copy16(float *dst, const Matrix4f &m) { std::memcpy(dst, m.m, 16 * sizeof(float)); }
+
+void Scene::flatten(const Endpoint *endpoint) {
+    auto fl = std::make_unique<Flat>();
+    fl->endpoint = endpoint;
+    std::map<const BSDF *, uint32_t> mat_index;
+    std::memset(&fl->desc, 0, sizeof(fl->desc));
+    bf_sensor &sen = fl->desc.sensor;
+    sen.shape = -1;
+    bool endpoint_found = false;
+    // standalone emitters first keep their scene order; shape emitters follow shape order
+    std::vector<std::pair<const Endpoint *, int32_t>> em_slots;   // (endpoint, shape index)
+    const bool use_transmitters = dynamic_cast<const Receiver *>(endpoint) != nullptr;
+    for (size_t i = 0; i < m_shapes.size(); ++i) {
+        Shape *s = m_shapes[i].get();
+        bf_shape bs;
+        std::memset(&bs, 0, sizeof(bs));
+        auto it = mat_index.find(s->bsdf());
+        if (it == mat_index.end()) {
+            mat_index[s->bsdf()] = (uint32_t) fl->materials.size();
+            fl->materials.push_back(s->bsdf()->flatten());
+            it = mat_index.find(s->bsdf());
+        }
+        bs.material = it->second;
+        bs.emitter = -1;
+        if (s->is_rectangle()) {
+            bs.type = BF_SHAPE_RECTANGLE;
+            copy16(bs.to_world, s->to_world().matrix);
+            copy16(bs.to_object, s->to_world().inverse);
+        } else {
+            bs.type = BF_SHAPE_MESH;
+            copy16(bs.to_world, Matrix4f::identity());
+            copy16(bs.to_object, Matrix4f::identity());
+            bs.positions = s->positions()->data();
+            bs.normals = s->normals() ? s->normals()->data() : nullptr;
+            bs.indices = s->faces()->data();
+            bs.n_vertices = (uint32_t) (s->positions()->size() / 3);
+            bs.n_faces = (uint32_t) (s->faces()->size() / 3);
+        }
+        if ((const Endpoint *) s->sensor() == endpoint || (const Endpoint *) s->receiver() == endpoint) {
+            bs.is_sensor = 1;
+            sen.shape = (int32_t) i;
+            endpoint_found = true;
+        }
+        fl->shapes.push_back(bs);
+    }
+    // emitters in Scene order (scene.cpp:34-61 pushes shape emitters when the shape is visited)
+    if (use_transmitters) {
+        for (auto &t : m_transmitters) {
+            int32_t si = -1;
+            for (size_t i = 0; i < m_shapes.size(); ++i)
+                if (m_shapes[i]->transmitter() == t.get()) si = (int32_t) i;
+            bf_emitter e = t->flatten(si);
+            if (si >= 0) fl->shapes[si].emitter = (int32_t) fl->emitters.size();
+            fl->emitters.push_back(e);
+        }
+    } else {
+        for (auto &em : m_emitters) {
+            int32_t si = -1;
+            for (size_t i = 0; i < m_shapes.size(); ++i)
+                if (m_shapes[i]->emitter() == em.get()) si = (int32_t) i;
+            bf_emitter e = em->flatten(si);
+            if (si >= 0) fl->shapes[si].emitter = (int32_t) fl->emitters.size();
+            fl->emitters.push_back(e);
+        }
+    }
+    if (auto *se = dynamic_cast<const Sensor *>(endpoint)) {
+        se->flatten(sen, sen.shape);
+        endpoint_found = true;
+    } else if (auto *re = dynamic_cast<const Receiver *>(endpoint)) {
+        re->flatten(sen, sen.shape);
+    }
+    if (!endpoint_found) Throw("Scene: the given sensor / receiver does not belong to this scene");
+    // physics constants of the fork at HEAD (spectrum.h:15-40, math.h:40-41)
+    fl->desc.physics.c = 340.0f;
+    fl->desc.physics.lambda_min_nm = 7555556.f;
+    fl->desc.physics.lambda_max_nm = 9714286.f;
+    fl->desc.shapes = fl->shapes.data();
+    fl->desc.n_shapes = (uint32_t) fl->shapes.size();
+    fl->desc.materials = fl->materials.data();
+    fl->desc.n_materials = (uint32_t) fl->materials.size();
+    fl->desc.emitters = fl->emitters.data();
+    fl->desc.n_emitters = (uint32_t) fl->emitters.size();
+    if (m_flat && m_flat->device) bf_scene_destroy(m_flat->device);
+    m_flat = std::move(fl);
+}
+
+const bf_scene_desc *Scene::flat_desc(const Endpoint *endpoint) {
+    if (!m_flat || m_flat->endpoint != endpoint) flatten(endpoint);
+    return &m_flat->desc;
+}
+
+bf_scene *Scene::device_scene(const Endpoint *endpoint) {
+    flat_desc(endpoint);
+    if (!m_flat->device) {
+        bf_status st = bf_scene_create(&m_flat->desc, &m_flat->device);
+        if (st != BF_OK) Throw("bf_scene_create failed (status %d): %s", st, bf_last_error());
+    }
+    return m_flat->device;
+}
+
+// ---- integrator ------------------------------------------------------------------
+SamplingIntegrator::SamplingIntegrator(const Properties &props) : Integrator(props) {
+    // MonteCarloIntegrator — integrator.cpp:1713-1728
+    m_rr_depth = (int) props.int_("rr_depth", 5);
+    if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
+    m_max_depth = (int) props.int_("max_depth", -1);
+    if (m_max_depth < 0 && m_max_depth != -1) Throw("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+}
+
+static uint32_t color_mode_of_variant() {
+    // scalar_rgb converts through srgb_to_xyz (integrator.cpp:292-294); mono and
+    // spectral-with-uniform-spectra replicate the lane (CIE tables are out of scope)
+    return variant() == "scalar_rgb" ? BF_COLOR_RGB : BF_COLOR_MONO;
+}
+
+bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
+    // integrator.cpp:58-204 for a 1x1 film: channels X,Y,Z,A,W + aov_names()
+    Film *film = sensor->film();
+    std::vector<std::string> channels = {"X", "Y", "Z", "A", "W"};
+    for (auto &n : aov_names()) channels.push_back(n);
+    film->prepare(channels);
+    bf_launch lp;
+    std::memset(&lp, 0, sizeof(lp));
+    lp.color_mode = color_mode_of_variant();
+    lp.n_paths = sensor->sampler()->sample_count();
+    lp.seed = sensor->sampler()->base_seed();
+    lp.max_depth = m_max_depth;
+    lp.rr_depth = m_rr_depth;
+    lp.time_c = 3.0e8f;
+    configure(lp);
+    if (lp.mode == BF_MODE_RECEIVE_RAW) Throw("this integrator only supports receive(), not render()");
+    uint32_t n = bf_launch_channels(&lp);
+    if (n != channels.size()) Throw("internal error: channel count mismatch (%u vs %zu)", n, channels.size());
+    std::vector<float> hist(n);
+    auto t0 = std::chrono::steady_clock::now();
+    bf_status st = bf_render(scene->device_scene(sensor), &lp, hist.data(), nullptr, &m_stats.stats);
+    if (st != BF_OK) Throw("bf_render failed (status %d): %s", st, bf_last_error());
+    m_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    film->put(hist.data(), hist.size());
+    return !m_stop;
+}
+
+bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
+    // integrator.cpp:315-768 (live branch :484-666): channels Y,A,W + aov_names()
+    ADC *adc = receiver->adc();
+    std::vector<std::string> channels = {"Y", "A", "W"};
+    for (auto &n : aov_names()) channels.push_back(n);
+    adc->prepare(channels);
+    if (receiver->receive_type() != "raw") Throw("receive_type \"%s\" is not supported (only \"raw\")", receiver->receive_type().c_str());
+    bf_launch lp;
+    std::memset(&lp, 0, sizeof(lp));
+    lp.color_mode = BF_COLOR_MONO;
+    lp.n_paths = receiver->sampler()->sample_count();
+    lp.seed = receiver->sampler()->base_seed();
+    lp.max_depth = m_max_depth;
+    lp.rr_depth = m_rr_depth;
+    lp.time_c = 3.0e8f;
+    configure(lp);
+    if (lp.mode != BF_MODE_RECEIVE_RAW) Throw("this integrator does not implement receive()");
+    lp.bins = adc->t_bins();
+    lp.bins_y = adc->f_bins();
+    uint32_t n = bf_launch_channels(&lp);
+    std::vector<float> hist(n);
+    auto t0 = std::chrono::steady_clock::now();
+    bf_status st = bf_render(scene->device_scene(receiver), &lp, hist.data(), nullptr, &m_stats.stats);
+    if (st != BF_OK) Throw("bf_render failed (status %d): %s", st, bf_last_error());
+    m_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    adc->put(hist.data(), hist.size());
+    return !m_stop;
+}
+
+}  // namespace bfh

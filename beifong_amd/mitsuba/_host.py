@@ -1,0 +1,228 @@
+"""ctypes binding of libbeifong_host.so (beifong_amd/host/capi.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import capi
+
+_HOST_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host")
+LIB_PATH = os.path.join(_HOST_DIR, "libbeifong_host.so")
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HostError(f"{LIB_PATH} not found: run __graft_entry__.build() first")
+    capi.load_library()            # libbeifong_hip.so first (same instance for both)
+    l = C.CDLL(LIB_PATH)
+    vp, cp = C.c_void_p, C.c_char_p
+    l.bfh_last_error.restype = cp
+    l.bfh_variant.restype = cp
+    l.bfh_set_variant.argtypes = [cp]
+    l.bfh_load_file.argtypes = [cp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.POINTER(vp)]
+    l.bfh_load_string.argtypes = [cp, cp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.POINTER(vp)]
+    l.bfh_release.argtypes = [vp]
+    l.bfh_class_name.argtypes = [vp]
+    l.bfh_class_name.restype = cp
+    l.bfh_scene_counts.argtypes = [vp] + [C.POINTER(C.c_int)] * 5
+    for f in ("bfh_scene_integrator",):
+        getattr(l, f).argtypes = [vp]
+        getattr(l, f).restype = vp
+    for f in ("bfh_scene_sensor", "bfh_scene_receiver", "bfh_scene_shape"):
+        getattr(l, f).argtypes = [vp, C.c_int]
+        getattr(l, f).restype = vp
+    l.bfh_shape_info.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_float)]
+    l.bfh_scene_flat_desc.argtypes = [vp, vp]
+    l.bfh_scene_flat_desc.restype = C.POINTER(capi.bf_scene_desc)
+    l.bfh_integrator_launch.argtypes = [vp, vp, C.POINTER(capi.bf_launch)]
+    l.bfh_integrator_render.argtypes = [vp, vp, vp]
+    l.bfh_integrator_receive.argtypes = [vp, vp, vp]
+    l.bfh_integrator_stats.argtypes = [vp, C.POINTER(capi.bf_stats), C.POINTER(C.c_double)]
+    l.bfh_sensor_sample_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    l.bfh_bitmap.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    l.bfh_channel_name.argtypes = [vp, C.c_uint]
+    l.bfh_channel_name.restype = cp
+    l.bfh_loaded_plugins.argtypes = [C.c_char_p, C.c_int]
+    _lib = l
+    return l
+
+
+def check(status):
+    if status != 0:
+        raise HostError(lib().bfh_last_error().decode())
+
+
+def params(kwargs):
+    n = len(kwargs)
+    keys = (C.c_char_p * max(n, 1))(*[str(k).encode() for k in kwargs])
+    vals = (C.c_char_p * max(n, 1))(*[str(v).encode() for v in kwargs.values()])
+    return n, keys, vals
+
+
+class Bitmap:
+    """Raw float32 storage of a film / ADC; np.array(bitmap) gives [rows, cols, channels]."""
+
+    def __init__(self, arr, names):
+        self._arr = arr
+        self._names = names
+
+    def __array__(self, dtype=None, copy=None):
+        return self._arr if dtype is None else self._arr.astype(dtype)
+
+    def channel_names(self):
+        return list(self._names)
+
+    def size(self):
+        return (self._arr.shape[1], self._arr.shape[0])
+
+    def channel_count(self):
+        return self._arr.shape[2]
+
+
+class _Handle:
+    def __init__(self, ptr, owner=None, owned=False):
+        self._ptr = C.c_void_p(ptr) if not isinstance(ptr, C.c_void_p) else ptr
+        self._owner = owner        # keeps the parent (scene) alive
+        self._owned = owned
+
+    def __del__(self):
+        try:
+            if self._owned and self._ptr:
+                lib().bfh_release(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+    def class_name(self):
+        return lib().bfh_class_name(self._ptr).decode()
+
+    def __repr__(self):
+        return f"<{self.class_name()}>"
+
+
+class Sampler:
+    def __init__(self, endpoint):
+        self._e = endpoint
+
+    def sample_count(self):
+        n = C.c_ulonglong()
+        check(lib().bfh_sensor_sample_count(self._e._ptr, C.byref(n)))
+        return n.value
+
+
+class _Storage:
+    def __init__(self, endpoint):
+        self._e = endpoint
+
+    def bitmap(self, raw=True):
+        data = C.POINTER(C.c_float)()
+        r, c, ch = C.c_uint(), C.c_uint(), C.c_uint()
+        check(lib().bfh_bitmap(self._e._ptr, C.byref(data), C.byref(r), C.byref(c), C.byref(ch)))
+        arr = np.ctypeslib.as_array(data, shape=(r.value, c.value, ch.value)).copy()
+        names = [lib().bfh_channel_name(self._e._ptr, i).decode() for i in range(ch.value)]
+        return Bitmap(arr, names)
+
+    def size(self):
+        b = self.bitmap()
+        return b.size()
+
+    def crop_size(self):
+        return self.size()
+
+
+class Sensor(_Handle):
+    def film(self):
+        return _Storage(self)
+
+    def sampler(self):
+        return Sampler(self)
+
+
+class Receiver(_Handle):
+    def adc(self):
+        return _Storage(self)
+
+    def sampler(self):
+        return Sampler(self)
+
+
+class Shape(_Handle):
+    def primitive_count(self):
+        p, a = C.c_uint(), C.c_float()
+        check(lib().bfh_shape_info(self._ptr, C.byref(p), C.byref(a)))
+        return p.value
+
+    def surface_area(self):
+        p, a = C.c_uint(), C.c_float()
+        check(lib().bfh_shape_info(self._ptr, C.byref(p), C.byref(a)))
+        return a.value
+
+
+class Integrator(_Handle):
+    def render(self, scene, sensor):
+        check(lib().bfh_integrator_render(self._ptr, scene._ptr, sensor._ptr))
+        return True
+
+    def receive(self, scene, receiver):
+        check(lib().bfh_integrator_receive(self._ptr, scene._ptr, receiver._ptr))
+        return True
+
+    def launch_for(self, endpoint):
+        lp = capi.bf_launch()
+        check(lib().bfh_integrator_launch(self._ptr, endpoint._ptr, C.byref(lp)))
+        return lp
+
+    def stats(self):
+        st, ms = capi.bf_stats(), C.c_double()
+        check(lib().bfh_integrator_stats(self._ptr, C.byref(st), C.byref(ms)))
+        return st, ms.value
+
+
+class Scene(_Handle):
+    def _counts(self):
+        v = [C.c_int() for _ in range(5)]
+        check(lib().bfh_scene_counts(self._ptr, *[C.byref(x) for x in v]))
+        return [x.value for x in v]
+
+    def integrator(self):
+        return Integrator(lib().bfh_scene_integrator(self._ptr), owner=self)
+
+    def sensors(self):
+        return [Sensor(lib().bfh_scene_sensor(self._ptr, i), owner=self) for i in range(self._counts()[1])]
+
+    def receivers(self):
+        return [Receiver(lib().bfh_scene_receiver(self._ptr, i), owner=self) for i in range(self._counts()[2])]
+
+    def shapes(self):
+        return [Shape(lib().bfh_scene_shape(self._ptr, i), owner=self) for i in range(self._counts()[0])]
+
+    def flat_desc(self, endpoint):
+        """The bf_scene_desc the integrator hands to the HIP library (tests feed
+        the same pointer to the CPU oracle)."""
+        p = lib().bfh_scene_flat_desc(self._ptr, endpoint._ptr)
+        if not p:
+            raise HostError(lib().bfh_last_error().decode())
+
+        class Holder:
+            pass
+
+        h = Holder()
+        h.desc = p.contents
+        h._scene = self
+        return h
+
+
+def wrap(ptr, dict_src=None):
+    name = lib().bfh_class_name(ptr).decode()
+    cls = {"Scene": Scene}.get(name, _Handle)
+    o = cls(ptr, owned=True)
+    o._dict = dict_src
+    return o

@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the sample-sharding + histogram all-reduce logic
+(the N > 1 path of bench.py / beifong_amd.dist), with the CPU oracle standing in
+for the per-rank renderer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from beifong_amd import capi, scenes
+from beifong_amd.dist import render_sharded, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for off, cnt in spans:
+                assert off == pos
+                pos += cnt
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_paths, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.oracle_lib import OracleScene
+    sd, lp = scenes.trans_rad(spp=n_paths)
+    o = OracleScene(sd)
+    n_floats = o.lib.bfo_launch_channels(lp)
+
+    def render(off, cnt, out):
+        l = capi.make_launch(lp.mode, cnt, seed=lp.seed, path_offset=off, bins=lp.bins, bin_width=lp.bin_width,
+                             time_c=lp.time_c, color_mode=lp.color_mode)
+        h, _, _ = o.render(l)
+        out += torch.from_numpy(h)
+
+    hist, span = render_sharded(render, n_paths, n_floats)
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist.numpy())
+    np.save(os.path.join(out_dir, f"span_{rank}.npy"), np.array(span))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_all_reduce_equals_single_run(tmp_path):
+    n_paths, world = 6001, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_paths, str(tmp_path)), nprocs=world, join=True)
+    from tests.oracle_lib import OracleScene
+    sd, lp = scenes.trans_rad(spp=n_paths)
+    ref, _, _ = OracleScene(sd).render(lp)
+    h0 = np.load(tmp_path / "hist_0.npy")
+    h1 = np.load(tmp_path / "hist_1.npy")
+    assert np.array_equal(h0, h1)                       # all-reduce leaves every rank with the sum
+    assert np.allclose(h0, ref, rtol=1e-6, atol=1e-6)   # union of shards == one sample set
+    assert h0[4] == n_paths
+    s0, s1 = np.load(tmp_path / "span_0.npy"), np.load(tmp_path / "span_1.npy")
+    assert s0[0] == 0 and s0[0] + s0[1] == s1[0] and s1[0] + s1[1] == n_paths

@@ -1,0 +1,329 @@
+"""Host layer (beifong_amd/host): the Mitsuba-shaped plugin surface, the XML
+loader and the flattening into the C ABI.  CPU-only: results are checked by
+feeding the flattened bf_scene_desc to the oracle."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from beifong_amd import capi, meshgen, scenes
+from tests.oracle_lib import OracleScene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "beifong_amd", "host")
+REF_XML = "/root/reference/python_scripts/trans_rad.xml"
+
+
+@pytest.fixture(scope="module")
+def mitsuba():
+    if not os.path.exists(os.path.join(HOST, "libbeifong_host.so")):
+        import __graft_entry__ as g
+        g.build()
+    from beifong_amd import mitsuba as m
+    m.set_variant("scalar_rgb")
+    return m
+
+
+TRANS_RAD_LIKE = """
+<scene version="2.1.0">
+    <default name="spp" value="100"/>
+    <integrator type="time"><integrator type="pathtime"/></integrator>
+    <shape type="rectangle" id="rx">
+        <transform name="to_world"><scale x="0.05" y="0.05"/><lookat origin="0, 0, 0" target="0, -1, 0" up="0, 0, 1"/></transform>
+        <sensor type="fluxmeter">
+            <film type="hdrfilm"><integer name="width" value="1"/><integer name="height" value="1"/><rfilter type="box"/></film>
+            <sampler type="independent"><integer name="sample_count" value="$spp"/></sampler>
+        </sensor>
+    </shape>
+    <bsdf type="twosided" id="material"><bsdf type="diffuse"><spectrum value="1.0" name="reflectance"/></bsdf></bsdf>
+    <emitter type="spot">
+        <spectrum value="1.0" name="intensity"/><float name="cutoff_angle" value="25"/><float name="beam_width" value="20"/>
+        <transform name="to_world"><lookat origin="0, 0, 0" target="0, -1, 0" up="0, 0, 1"/></transform>
+    </emitter>
+    <shape type="rectangle" id="target">
+        <transform name="to_world"><scale x="1" y="1"/><lookat origin="0, -4, 0" target="0, 0, 0" up="0, 0, 1"/></transform>
+        <ref id="material" name="bsdf"/>
+    </shape>
+    <shape type="rectangle" id="gnd">
+        <transform name="to_world"><scale x="20" y="20"/><lookat origin="0, 0, -0.5" target="0, 0, 0.5"/></transform>
+        <ref id="material" name="bsdf"/>
+    </shape>
+</scene>
+"""
+
+
+def _oracle_on_host_scene(scene, endpoint):
+    lp = scene.integrator().launch_for(endpoint)
+    h, rec, st = OracleScene(scene.flat_desc(endpoint)).render(lp, records=True)
+    return lp, h, rec
+
+
+def test_every_plugin_exports_the_reference_plugin_abi(mitsuba):
+    # include/mitsuba/core/class.h:195-211: extern "C" plugin_name() / plugin_descr()
+    sos = sorted(glob.glob(os.path.join(HOST, "plugins", "*.so")))
+    names = set()
+    for so in sos:
+        lib = C.CDLL(so)
+        lib.plugin_name.restype = C.c_char_p
+        lib.plugin_descr.restype = C.c_char_p
+        n = lib.plugin_name().decode()
+        assert n == os.path.basename(so)[:-3]
+        assert len(lib.plugin_descr()) > 0
+        names.add(n)
+    for need in ("path", "pathlength", "range", "pathtime", "time", "pathtimefrequency", "rectangle", "obj", "ply", "diffuse",
+                 "twosided", "roughconductor", "spot", "area", "areatransmitter", "wignertransmitter", "fluxmeter",
+                 "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent"):
+        assert need in names, need
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML), reason="reference tree not present (GPU box)")
+def test_reference_trans_rad_xml_loads_unchanged(mitsuba):
+    """python_scripts/trans_rad.xml, -Dspp=16 (BASELINE configs[0]): the loaded
+    scene flattens to the same description as the hand-built one."""
+    from beifong_amd.mitsuba.core.xml import load_file
+    scene = load_file(REF_XML, spp=16)
+    sen = scene.sensors()[0]
+    assert sen.sampler().sample_count() == 16
+    lp, h, rec = _oracle_on_host_scene(scene, sen)
+    assert (lp.mode, lp.bins, lp.n_paths) == (capi.BF_MODE_TIME, 50, 16)
+    sd, lp2 = scenes.trans_rad(16)
+    h2, rec2, _ = OracleScene(sd).render(lp2, records=True)
+    assert np.array_equal(h, h2) and np.array_equal(rec["L"], rec2["L"])
+    assert h.shape == (5 + 150,)            # float32[1,1,155]
+
+
+def test_xml_transform_composition_and_defaults(mitsuba):
+    from beifong_amd.mitsuba.core.xml import load_string
+    scene = load_string(TRANS_RAD_LIKE, spp=2000)
+    sen = scene.sensors()[0]
+    assert sen.sampler().sample_count() == 2000           # caller overrides <default>
+    assert [round(s.surface_area(), 4) for s in scene.shapes()] == [0.01, 4.0, 1600.0]
+    lp, h, rec = _oracle_on_host_scene(scene, sen)
+    sd, lp2 = scenes.trans_rad(2000)
+    h2, _, _ = OracleScene(sd).render(lp2)
+    assert np.array_equal(h, h2)
+    scene = load_string(TRANS_RAD_LIKE)
+    assert scene.sensors()[0].sampler().sample_count() == 100
+
+
+def test_xml_errors_are_reported_like_the_reference(mitsuba):
+    from beifong_amd.mitsuba._host import HostError
+    from beifong_amd.mitsuba.core.xml import load_string
+    with pytest.raises(HostError, match="unreferenced property"):
+        load_string(TRANS_RAD_LIKE.replace('<float name="cutoff_angle" value="25"/>',
+                                           '<float name="cutoff_angle" value="25"/><float name="bogus" value="1"/>'))
+    with pytest.raises(HostError, match="not found"):
+        load_string(TRANS_RAD_LIKE.replace('type="spot"', 'type="nosuchplugin"'))
+    with pytest.raises(HostError, match="Type mismatch"):
+        load_string(TRANS_RAD_LIKE.replace('<emitter type="spot">', '<emitter type="diffuse">').replace(
+            '<spectrum value="1.0" name="intensity"/><float name="cutoff_angle" value="25"/><float name="beam_width" value="20"/>', "")
+            .replace('<transform name="to_world"><lookat origin="0, 0, 0" target="0, -1, 0" up="0, 0, 1"/></transform>\n    </emitter>', "</emitter>"))
+    with pytest.raises(HostError, match="undefined parameter"):
+        load_string(TRANS_RAD_LIKE.replace('<default name="spp" value="100"/>', ""))
+    with pytest.raises(HostError, match="1x1"):
+        load_string(TRANS_RAD_LIKE.replace('name="width" value="1"', 'name="width" value="4"'))
+
+
+def _write_obj(path, v, f, with_normals=False):
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %r %r %r\n" % tuple(float(x) for x in p))
+        if with_normals:
+            fh.write("vn 0 0 1\n")
+        for t in f:
+            if with_normals:
+                fh.write("f %d//1 %d//1 %d//1\n" % tuple(int(i) + 1 for i in t))
+            else:
+                fh.write("f %d %d %d\n" % tuple(int(i) + 1 for i in t))
+
+
+MESH_SCENE = """
+<scene version="2.1.0">
+    <integrator type="range"><integrator type="pathlength"/><float name="dr" value="0.1"/><integer name="bins" value="64"/></integrator>
+    <sensor type="perspective">
+        <float name="fov" value="45"/><float name="near_clip" value="0.1"/><float name="far_clip" value="100"/>
+        <transform name="to_world"><lookat origin="0, 0, -3" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <film type="hdrfilm"><integer name="width" value="1"/><integer name="height" value="1"/><rfilter type="box"/></film>
+        <sampler type="independent"><integer name="sample_count" value="3000"/></sampler>
+    </sensor>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.2" y="0.2"/><lookat origin="0.5, 0.5, -3" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <emitter type="area"><spectrum name="radiance" value="100"/></emitter>
+    </shape>
+    <shape type="%s">
+        <string name="filename" value="%s"/>%s
+        <bsdf type="twosided"><bsdf type="roughconductor"><float name="alpha" value="0.2"/></bsdf></bsdf>
+    </shape>
+</scene>
+"""
+
+
+def test_obj_loader_known_answers_and_normals(mitsuba, tmp_path):
+    """src/librender/tests/test_mesh.py:257-298 on a synthesised rectangle.obj,
+    through the obj plugin (to_world at load, fan triangulation, vertex de-dup,
+    normals recomputed when the file has none: obj.cpp:339-344)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    v, f = meshgen.rectangle_obj()
+    _write_obj(tmp_path / "rectangle.obj", v, f)
+    scene = load_string(MESH_SCENE % ("obj", "rectangle.obj", ""), base_dir=str(tmp_path))
+    shape = scene.shapes()[1]
+    assert shape.primitive_count() == 2 and np.isclose(shape.surface_area(), 4.0)
+    desc = scene.flat_desc(scene.sensors()[0])
+    sh = desc.desc.shapes[1]
+    assert sh.n_vertices == 4 and sh.n_faces == 2 and bool(sh.normals)
+    nrm = np.ctypeslib.as_array(sh.normals, shape=(4, 3))
+    assert np.allclose(nrm, [[0, 0, 1]] * 4, atol=1e-6)            # recomputed vertex normals of a flat quad
+    o = OracleScene(desc)
+    eps = np.float32(1500 * 2.0 ** -24)
+    r = o.intersect_full([-0.3, -0.3, -10, eps, 0, 0, 1, np.inf])
+    t, prim, _, uv = o.trace_closest([[-0.3, -0.3, -10, eps, 0, 0, 1, np.inf]])
+    assert np.isclose(r["t"], 10) and np.allclose(r["prim_uv"], [0.35, 0.3], atol=1e-6)
+    assert prim[0] == 1                  # global primitive index: the emitter rectangle is primitive 0
+    # quad face + face_normals=true: one polygon fan-triangulated, no normals kept
+    with open(tmp_path / "quad.obj", "w") as fh:
+        fh.write("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n")
+    scene = load_string(MESH_SCENE % ("obj", "quad.obj", '<boolean name="face_normals" value="true"/>'), base_dir=str(tmp_path))
+    sh = scene.flat_desc(scene.sensors()[0]).desc.shapes[1]
+    assert sh.n_faces == 2 and sh.n_vertices == 4 and not bool(sh.normals)
+    # to_world is applied at load time
+    scene = load_string(MESH_SCENE % ("obj", "rectangle.obj", '<transform name="to_world"><scale value="2"/><translate x="1"/></transform>'),
+                        base_dir=str(tmp_path))
+    sh = scene.flat_desc(scene.sensors()[0]).desc.shapes[1]
+    pos = np.ctypeslib.as_array(sh.positions, shape=(4, 3))
+    assert np.allclose(sorted(pos[:, 0]), [-1, -1, 3, 3])
+
+
+def test_ply_loader_on_the_reference_fixtures(mitsuba):
+    """tests/golden/triangle*.ply are the reference's own data files
+    (src/librender/tests/data/): ASCII, and binary LE with normals + extra face
+    properties."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    gold = os.path.join(ROOT, "tests", "golden")
+    for name, has_n in (("triangle.ply", False), ("triangle_face_colors.ply", True)):
+        scene = load_string(MESH_SCENE % ("ply", name, ""), base_dir=gold)
+        sh = scene.flat_desc(scene.sensors()[0]).desc.shapes[1]
+        assert sh.n_vertices == 3 and sh.n_faces == 1
+        pos = np.ctypeslib.as_array(sh.positions, shape=(3, 3))
+        assert np.allclose(pos, [[0, 0, 0], [0, 0, 1], [0, 1, 0]])
+        nrm = np.ctypeslib.as_array(sh.normals, shape=(3, 3))
+        assert np.allclose(np.abs(nrm), [[1, 0, 0]] * 3, atol=1e-6)
+        assert np.isclose(scene.shapes()[1].surface_area(), 0.5)
+
+
+def test_ply_binary_big_endian_and_ascii_agree(mitsuba, tmp_path):
+    from beifong_amd.mitsuba.core.xml import load_string
+    v, f = meshgen.triangle_soup(50, seed=3)
+    hdr = "ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n" \
+          "element face %d\nproperty list uchar int vertex_indices\nend_header\n"
+    with open(tmp_path / "a.ply", "w") as fh:
+        fh.write(hdr % ("ascii", len(v), len(f)))
+        for p in v:
+            fh.write("%r %r %r 7\n" % tuple(float(x) for x in p))
+        for t in f:
+            fh.write("3 %d %d %d\n" % tuple(int(i) for i in t))
+    for fmt, end in (("binary_big_endian", ">"), ("binary_little_endian", "<")):
+        with open(tmp_path / (fmt + ".ply"), "wb") as fh:
+            fh.write((hdr % (fmt, len(v), len(f))).encode())
+            for p in v:
+                fh.write(p.astype(end + "f4").tobytes() + b"\x07")
+            for t in f:
+                fh.write(b"\x03" + t.astype(end + "i4").tobytes())
+    out = []
+    for name in ("a.ply", "binary_big_endian.ply", "binary_little_endian.ply"):
+        scene = load_string(MESH_SCENE % ("ply", name, '<boolean name="face_normals" value="true"/>'), base_dir=str(tmp_path))
+        sh = scene.flat_desc(scene.sensors()[0]).desc.shapes[1]
+        out.append((np.ctypeslib.as_array(sh.positions, shape=(sh.n_vertices, 3)).copy(),
+                    np.ctypeslib.as_array(sh.indices, shape=(sh.n_faces, 3)).copy()))
+    for p, i in out[1:]:
+        assert np.array_equal(p, out[0][0]) and np.array_equal(i, out[0][1])
+    assert np.array_equal(out[0][0], v) and np.array_equal(out[0][1], f)
+
+
+def test_mesh_scene_flattens_like_the_python_builder(mitsuba, tmp_path):
+    from beifong_amd.mitsuba.core.xml import load_string
+    v, f = meshgen.triangle_soup(300, seed=5, extent=0.8, size=0.3)
+    _write_obj(tmp_path / "soup.obj", v, f)
+    scene = load_string(MESH_SCENE % ("obj", "soup.obj", '<boolean name="face_normals" value="true"/>'), base_dir=str(tmp_path))
+    lp, h, rec = _oracle_on_host_scene(scene, scene.sensors()[0])
+    assert lp.mode == capi.BF_MODE_RANGE and lp.bins == 64 and h.shape == (69,)
+    assert h[4] == 3000 and h[3] > 0 and np.abs(h[5:]).sum() > 0
+
+
+RECEIVE_SCENE = """
+<scene version="2.1.0">
+    <integrator type="pathtimefrequency"/>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.02" y="0.05"/><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+        <transmitter type="wignertransmitter">
+            <string name="signaltype" value="pulse"/><float name="amplitude" value="1"/>
+            <float name="pulse_len" value="0.000588235"/><float name="prf" value="6.640625"/>
+            <float name="freq_centre" value="39375"/><float name="freq_ext" value="1700"/>
+        </transmitter>
+    </shape>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.02" y="0.05"/><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+        <receiver type="omnidirectional">
+            <float name="adc_sampling_start" value="0"/><float name="adc_sampling_end" value="0.150588"/>
+            <adc type="hdradc"><integer name="t_bins" value="256"/><integer name="f_bins" value="1"/>
+                <float name="t_bandwidth" value="0.150588"/><float name="f_bandwidth" value="90000"/><rfilter type="box"/></adc>
+            <sampler type="independent"><integer name="sample_count" value="4000"/></sampler>
+        </receiver>
+    </shape>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="20" y="20"/></transform>
+        <bsdf type="twosided"><bsdf type="diffuse"><spectrum name="reflectance" value="0.5"/></bsdf></bsdf>
+    </shape>
+</scene>
+"""
+
+
+def test_receive_scene_with_fork_plugins(mitsuba):
+    """<transmitter>, <receiver>, <adc> tags (class aliases of the fork's base
+    classes: transmitter.cpp:10, receiver.cpp:205, adc.cpp:106)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    scene = load_string(RECEIVE_SCENE)
+    assert len(scene.receivers()) == 1 and len(scene.sensors()) == 0
+    rx = scene.receivers()[0]
+    lp, h, rec = _oracle_on_host_scene(scene, rx)
+    assert (lp.mode, lp.bins, lp.bins_y, lp.n_paths) == (capi.BF_MODE_RECEIVE_RAW, 256, 1, 4000)
+    h = h.reshape(1, 256, 3)
+    assert h[0, :, 2].sum() == 4000 and np.abs(h[0, :, 0]).sum() > 0
+    d = scene.flat_desc(rx).desc
+    assert d.n_emitters == 1 and d.emitters[0].type == capi.BF_TRANSMITTER_WIGNER and d.emitters[0].signal_type == capi.BF_SIGNAL_PULSE
+    assert d.shapes[0].emitter == 0 and d.sensor.type == capi.BF_RECEIVER_OMNI and d.sensor.shape == 1
+
+
+def test_load_dict_matches_load_string(mitsuba):
+    """animated_trans_rad.py-style dictionaries (python_scripts/animated_trans_rad.py:100-230)."""
+    from beifong_amd.mitsuba.core import Transform4f
+    from beifong_amd.mitsuba.core.xml import load_dict
+    bsdfs = load_dict({"type": "twosided", "id": "material", "bsdf": {"type": "diffuse", "reflectance": {"type": "spectrum", "value": 1}}})
+    targ = load_dict({"type": "rectangle", "to_world": Transform4f.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1]), "bsdf": bsdfs})
+    scene = load_dict({
+        "type": "scene",
+        "integrator": {"type": "range", "integrator": {"type": "pathlength"}, "dr": 0.2, "bins": 50},
+        "sensor": {"type": "perspective", "near_clip": 0.2, "far_clip": 10.2, "fov_axis": "x", "fov": 45,
+                   "to_world": Transform4f.look_at([0, 0, 0], [0, -1, 0], [0, 0, 1]),
+                   "sampler": {"type": "independent", "sample_count": 500},
+                   "film": {"type": "hdrfilm", "rfilter": {"type": "box"}, "width": 1, "height": 1}},
+        "emitter": {"type": "spot", "cutoff_angle": 25, "beam_width": 20, "intensity": {"type": "spectrum", "value": 1000},
+                    "to_world": Transform4f.look_at([0, 0, 0], [0, -1, 0], [0, 0, 1])},
+        "so": targ,
+    })
+    lp, h, rec = _oracle_on_host_scene(scene, scene.sensors()[0])
+    assert lp.mode == capi.BF_MODE_RANGE and lp.bins == 50 and np.isclose(lp.bin_width, 0.2)
+    assert h[4] == 500 and h[5:].sum() > 0
+    assert np.nonzero(h[5:])[0].min() >= 19          # target plate 4 m away, dr 0.2 m: first return at bin >= 19
+
+
+def test_bfrender_cli_without_gpu_fails_cleanly(mitsuba, tmp_path):
+    lib = capi.load_library()
+    if lib.bf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = tmp_path / "s.xml"
+    p.write_text(TRANS_RAD_LIKE)
+    r = subprocess.run([os.path.join(HOST, "bfrender"), "-m", "scalar_rgb", "-Dspp=16", str(p)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
