@@ -25,7 +25,7 @@ extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const 
 
 extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
-                                   hipStream_t stream);
+                                   hipStream_t stream, int waves);
 extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
                                    hipStream_t stream);
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
@@ -425,6 +425,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sh0, n * 16));
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
     HIP_TRY(alloc((void **) &wf.sh2, n * 8));
+    HIP_TRY(alloc((void **) &wf.spill, (size_t) scene->n_cus * bfd::kTraceBlocksPerCU * bfd::kBlock * bfd::kSpillDepth * sizeof(int)));
     uint32_t *ctr = nullptr;
     HIP_TRY(alloc((void **) &ctr, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.n_q = ctr;
@@ -432,6 +433,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     wf.head_shade = ctr + 2 * (bfd::kWfMaxIter + 2);
     wf.head_trace = ctr + 3 * (bfd::kWfMaxIter + 2);
     wf.counters = scene->counters;
+    HIP_TRY(alloc((void **) &wf.pool, 2 * bfd::kMaxShadeWaves * sizeof(unsigned long long)));
     wf.capacity = capacity;
     if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
     if (!scene->wf_event) HIP_TRY(hipEventCreateWithFlags(&scene->wf_event, hipEventDisableTiming));
@@ -457,11 +459,17 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     uint32_t pool = (uint32_t) std::min<uint64_t>(wf.capacity, lp.n_paths);
     HIP_TRY(hipMemsetAsync(wf.n_q, 0, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
     HIP_TRY(hipMemcpyAsync(wf.n_q, &pool, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(wf.pool, 0, 2 * bfd::kMaxShadeWaves * sizeof(unsigned long long), stream));
     size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan + 15) & ~size_t(15)) : 0;
     size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
-    // persistent grids: shade is register-heavy (2 workgroups per CU), trace is
-    // LDS-stack bound (5 workgroups of 32 KiB per CU)
-    const unsigned grid_shade = (unsigned) scene->n_cus * 2, grid_trace = (unsigned) scene->n_cus * 5;
+    // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
+    // 8 workgroups per CU (16 KiB LDS stack each, <= 64 VGPRs)
+    static const int shade_waves = [] {
+        const char *e = getenv("BF_SHADE_WAVES");
+        int w = e ? atoi(e) : 2;
+        return w < 1 ? 1 : (w > 4 ? 4 : w);
+    }();
+    const unsigned grid_shade = (unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), grid_trace = (unsigned) scene->n_cus * bfd::kTraceBlocksPerCU;
     const uint32_t tail_max = wf_tail_threshold();
     uint32_t n_cur = pool;                       // live slots entering bounce `it` (host's view)
     volatile uint32_t *hq = scene->wf_host;      // [0] = n_q[it+1], [2..3] = next path counter
@@ -501,10 +509,10 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         unsigned blocks = (n_cur + bfd::kBlock - 1) / bfd::kBlock;
         HIP_TRY(tic(1));
         HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev,
-                             std::max(1u, std::min(grid_shade, blocks)), lds_shade, stream));
+                             std::max(1u, std::min(grid_shade, blocks)), lds_shade, stream, shade_waves));
         HIP_TRY(toc());
         HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_q + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync((void *) &hq[2], wf.counters + bfd::CTR_NEXT_PATH, sizeof(unsigned long long),
+        HIP_TRY(hipMemcpyAsync((void *) &hq[2], wf.counters + bfd::CTR_STARTED, sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(scene->wf_event, stream));
         // rays of this bounce: at most one shadow + one closest ray per live slot
@@ -513,7 +521,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         HIP_TRY(toc());
         HIP_TRY(hipEventSynchronize(scene->wf_event));
         uint32_t n_next = hq[0];
-        unsigned long long next_path = ((unsigned long long) hq[3] << 32) | hq[2];
+        unsigned long long next_path = ((unsigned long long) hq[3] << 32) | hq[2];   // paths started so far
         if (n_next == 0) return finish(it + 1, it + 1);
         if (next_path >= lp.n_paths && n_next <= tail_max) {
             HIP_TRY(tic(2));

@@ -10,6 +10,9 @@
 namespace bfd {
 
 constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce queue counters
+constexpr uint32_t kSpillDepth = 16;    // stack entries beyond the 16 kept in LDS (tree depth <= 31)
+constexpr uint32_t kTraceBlocksPerCU = 8;
+constexpr uint32_t kMaxShadeWaves = 1u << 14;
 
 struct WF {
     // path state, double buffered [2][capacity]
@@ -25,12 +28,14 @@ struct WF {
     float4 *sh0;        // o.xyz, mint
     float4 *sh1;        // d.xyz, maxt
     uint2 *sh2;         // slot in the next state buffer, NEE contribution bits
+    int *spill;         // traversal-stack overflow: [kSpillDepth][max trace threads]
     // per-bounce counters [kWfMaxIter + 2]
     uint32_t *n_q;          // live slots entering bounce `it`
     uint32_t *n_sh;         // shadow rays produced by bounce `it`
     uint32_t *head_shade;   // work-queue heads of the persistent kernels
     uint32_t *head_trace;
     unsigned long long *counters;   // CTR_* (bf_device.h)
+    unsigned long long *pool;       // per shade-wave pool of path indices {next, end} [kMaxShadeWaves]
     uint32_t capacity;
 };
 

@@ -25,8 +25,8 @@
 
 namespace bfd {
 
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
+template <bool FIRST, int W>
+__global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                    bf_path_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     float *s_hist = reinterpret_cast<float *>(s_raw);
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
     const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0;
+    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_started = 0;
 
     // static wave-granular partition of the queue: a device-wide queue head
     // saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"),
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
                 if (path_i < lp.n_paths) {
                     generate_path(sc, lp, path_i, s);
                     ++c_closest;
+                    ++c_started;
                     cont = true;
                 }
             }
@@ -127,9 +128,11 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
     }
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
-    unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
+    unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces,
+                       v_started = c_started;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v_started += __shfl_down(v_started, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
         v_invalid += __shfl_down(v_invalid, off);
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
         if (v_shadow) atomicAdd(&wf.counters[CTR_SHADOW], v_shadow);
         if (v_invalid) atomicAdd(&wf.counters[CTR_INVALID], v_invalid);
         if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
+        if (v_started) atomicAdd(&wf.counters[CTR_STARTED], v_started);   // host: supply exhausted iff == n_paths
     }
 }
 
@@ -149,18 +153,32 @@ __global__ __launch_bounds__(kBlock) void wf_shade(DScene sc, DLaunch lp, WF wf,
 // soon as the wave's occupancy drops below kRefill lanes (__ballot/__popcll
 // prefix, no atomics), so the wave's cost tracks the SUM of its rays'
 // traversal steps instead of 64 x the longest one.
+//
+// "while-while" form: lanes first descend through internal nodes together
+// (postponing the leaf they reach), then all lanes holding a leaf intersect
+// its triangles together, so the triangle code never runs for one straggler
+// while 63 lanes wait at nodes.
+//
+// Stack: the first kLdsStack entries live in LDS (lane-strided, conflict-free),
+// deeper entries — rare: one entry per tree level where BOTH children are hit —
+// spill to a per-thread column in HBM.  16 KiB of LDS per workgroup instead of
+// 32 lifts the kernel from 5 to 8 waves/SIMD.
 constexpr int kRefill = 44;
+constexpr int kLdsStack = 16;
+constexpr int kNoNode = INT32_MIN;
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void wf_trace(DScene sc, WF wf, uint32_t it) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+__global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t it) {
+    __shared__ int s_stack[kLdsStack * kBlock];
     int *stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int nxt = (it & 1) ^ 1;
     const uint32_t n_sh = wf.n_sh[it], n_ext = wf.n_q[it + 1];
     const uint32_t total = n_sh + n_ext;
     uint32_t c_nodes = 0, c_tris = 0;
+    const uint32_t n_threads = gridDim.x * kBlock;
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int *spill = wf.spill + (blockIdx.x * kBlock + threadIdx.x);    // entry k at spill[k * n_threads]
     // segment per wave, multiple of 64 so that the first fetch of each wave is a coalesced 1 KiB read
     uint32_t seg = (uint32_t) (((uint64_t) total + n_waves - 1) / n_waves);
     seg = (seg + 63u) & ~63u;
@@ -177,8 +195,20 @@ __global__ __launch_bounds__(kBlock) void wf_trace(DScene sc, WF wf, uint32_t it
     best.u = best.v = 0.f;
     best.prim = 0;
     best.slot = 0;
-    int node = 0, sp = 0;
+    int node = kNoNode, sp = 0;
     bool found = false;      // any-hit result
+
+    auto push = [&](int v) {
+        if (sp < kLdsStack)
+            stack[sp * kBlock] = v;
+        else
+            spill[(size_t) (sp - kLdsStack) * n_threads] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        return sp < kLdsStack ? stack[sp * kBlock] : spill[(size_t) (sp - kLdsStack) * n_threads];
+    };
 
     while (true) {
         // ---- refill idle lanes from the wave's segment -------------------------
@@ -224,85 +254,74 @@ __global__ __launch_bounds__(kBlock) void wf_trace(DScene sc, WF wf, uint32_t it
                 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
                 node = sc.root;
                 sp = 0;
-                if (!live || sc.n_tris == 0 || (any && found)) node = INT32_MIN;   // nothing to traverse
+                if (!live || sc.n_tris == 0 || (any && found)) node = kNoNode;   // nothing to traverse
             }
         }
         if (__ballot(has) == 0ull) break;
 
-        // ---- traversal steps until the wave thins out ----------------------------
+        // ---- traversal until the wave thins out -----------------------------------
         while (true) {
-            if (has) {
-                bool finished = false;
-                if (node == INT32_MIN) {
-                    finished = true;
+            // (a) descend through internal nodes; a lane that reaches a leaf (node < 0) waits
+            while (__ballot(has && node >= 0)) {
+                if (has && node >= 0) {
+                    const float4 *np = sc.nodes + 4u * (uint32_t) node;
+                    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    if (STATS) ++c_nodes;
+                    float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
+                    float tn0, tn1;
+                    bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
+                    bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
+                    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                    if (h0 && h1) {
+                        if (tn1 < tn0) {
+                            int tmp = c0;
+                            c0 = c1;
+                            c1 = tmp;
+                        }
+                        push(c1);
+                        node = c0;
+                    } else if (h0) {
+                        node = c0;
+                    } else if (h1) {
+                        node = c1;
+                    } else {
+                        node = sp ? pop() : kNoNode;
+                    }
+                }
+            }
+            // (b) every lane now holds a leaf or nothing: intersect the leaves together
+            if (has && node != kNoNode) {
+                uint32_t enc = ~(uint32_t) node;
+                uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4 *tp = sc.tris + 3u * (first + i);
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (STATS) ++c_tris;
+                    float t, u, v;
+                    if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
+                        if (any) {
+                            found = true;
+                            break;
+                        }
+                        consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
+                    }
+                }
+                node = ((any && found) || sp == 0) ? kNoNode : pop();
+            }
+            // (c) retire finished rays
+            if (has && node == kNoNode) {
+                if (any) {
+                    // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
+                    if (!found) {
+                        uint2 e = wf.sh2[job];
+                        float4 a = wf.sa[nxt][e.x];
+                        a.w += __uint_as_float(e.y);
+                        wf.sa[nxt][e.x] = a;
+                    }
                 } else {
-                    if (node >= 0) {
-                        const float4 *np = sc.nodes + 4 * (size_t) node;
-                        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                        if (STATS) ++c_nodes;
-                        float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
-                        float tn0, tn1;
-                        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
-                        bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
-                        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                        if (h0 && h1) {
-                            if (tn1 < tn0) {
-                                int tmp = c0;
-                                c0 = c1;
-                                c1 = tmp;
-                            }
-                            stack[sp * kBlock] = c1;
-                            ++sp;
-                            node = c0;
-                        } else if (h0) {
-                            node = c0;
-                        } else if (h1) {
-                            node = c1;
-                        } else if (sp == 0) {
-                            finished = true;
-                        } else {
-                            --sp;
-                            node = stack[sp * kBlock];
-                        }
-                    } else {
-                        uint32_t enc = ~(uint32_t) node;
-                        uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-                        for (uint32_t i = 0; i < cnt; ++i) {
-                            const float4 *tp = sc.tris + 3 * (size_t) (first + i);
-                            float4 a = tp[0], b = tp[1], c = tp[2];
-                            if (STATS) ++c_tris;
-                            float t, u, v;
-                            if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u,
-                                              v)) {
-                                if (any) {
-                                    found = true;
-                                    break;
-                                }
-                                consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
-                            }
-                        }
-                        if ((any && found) || sp == 0) {
-                            finished = true;
-                        } else {
-                            --sp;
-                            node = stack[sp * kBlock];
-                        }
-                    }
+                    wf.hit[job - n_sh] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
                 }
-                if (finished) {
-                    if (any) {
-                        // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
-                        if (!found) {
-                            uint2 e = wf.sh2[job];
-                            float4 a = wf.sa[nxt][e.x];
-                            a.w += __uint_as_float(e.y);
-                            wf.sa[nxt][e.x] = a;
-                        }
-                    } else {
-                        wf.hit[job - n_sh] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
-                    }
-                    has = false;
-                }
+                has = false;
             }
             unsigned long long act = __ballot(has);
             if (act == 0ull) break;
@@ -327,13 +346,23 @@ __global__ __launch_bounds__(kBlock) void wf_trace(DScene sc, WF wf, uint32_t it
 
 extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
-                                   hipStream_t stream) {
-    if (first)
-        hipLaunchKernelGGL(bfd::wf_shade<true>, dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist,
-                           records);
-    else
-        hipLaunchKernelGGL(bfd::wf_shade<false>, dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist,
-                           records);
+                                   hipStream_t stream, int waves) {
+    // `waves`: register budget of the shading kernel (waves per SIMD): 1 = no spills, 2..4 trade
+    // scratch spills of the fp64 transcendental code for occupancy
+#define BF_SHADE_LAUNCH(F, W)                                                                                             \
+    hipLaunchKernelGGL((bfd::wf_shade<F, W>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
+                       records)
+    if (first) {
+        BF_SHADE_LAUNCH(true, 1);
+    } else {
+        switch (waves) {
+            case 2: BF_SHADE_LAUNCH(false, 2); break;
+            case 3: BF_SHADE_LAUNCH(false, 3); break;
+            case 4: BF_SHADE_LAUNCH(false, 4); break;
+            default: BF_SHADE_LAUNCH(false, 1); break;
+        }
+    }
+#undef BF_SHADE_LAUNCH
     return hipGetLastError();
 }
 
