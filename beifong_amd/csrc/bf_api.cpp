@@ -102,6 +102,7 @@ struct bf_scene {
     mutable std::vector<void *> wf_owned;
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
+    mutable unsigned long long *wf_masks = nullptr;
     mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only)
     mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render
     mutable uint32_t wf_iters = 0, wf_trace_launches = 0;
@@ -411,29 +412,23 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
         if (e == hipSuccess) scene->wf_owned.push_back(*p);
         return e;
     };
-    size_t n = capacity;
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(alloc((void **) &wf.ray0[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.ray1[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.sa[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.sb[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.sc[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.sd[b], n * 16));
-        HIP_TRY(alloc((void **) &wf.se[b], n * 16));
-    }
+    size_t n = capacity, nb = capacity / 64;
+    HIP_TRY(alloc((void **) &wf.ray0, n * 16));
+    HIP_TRY(alloc((void **) &wf.ray1, n * 16));
+    HIP_TRY(alloc((void **) &wf.sa, n * 16));
+    HIP_TRY(alloc((void **) &wf.sb, n * 16));
+    HIP_TRY(alloc((void **) &wf.sc, n * 16));
+    HIP_TRY(alloc((void **) &wf.sd, n * 16));
+    HIP_TRY(alloc((void **) &wf.se, n * 16));
     HIP_TRY(alloc((void **) &wf.hit, n * 16));
     HIP_TRY(alloc((void **) &wf.sh0, n * 16));
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
-    HIP_TRY(alloc((void **) &wf.sh2, n * 8));
-    HIP_TRY(alloc((void **) &wf.spill, (size_t) scene->n_cus * bfd::kTraceBlocksPerCU * bfd::kBlock * bfd::kSpillDepth * sizeof(int)));
-    uint32_t *ctr = nullptr;
-    HIP_TRY(alloc((void **) &ctr, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
-    wf.n_q = ctr;
-    wf.n_sh = ctr + (bfd::kWfMaxIter + 2);
-    wf.head_shade = ctr + 2 * (bfd::kWfMaxIter + 2);
-    wf.head_trace = ctr + 3 * (bfd::kWfMaxIter + 2);
+    HIP_TRY(alloc((void **) &wf.sh2, n * 4));
+    HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
+    HIP_TRY(alloc((void **) &wf.spill,
+                  (size_t) scene->n_cus * bfd::kTraceBlocksPerCU * bfd::kBlock * bfd::kSpillDepth * sizeof(int)));
+    HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.counters = scene->counters;
-    HIP_TRY(alloc((void **) &wf.pool, 2 * bfd::kMaxShadeWaves * sizeof(unsigned long long)));
     wf.capacity = capacity;
     if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
     if (!scene->wf_event) HIP_TRY(hipEventCreateWithFlags(&scene->wf_event, hipEventDisableTiming));
@@ -445,34 +440,41 @@ static uint32_t wf_tail_threshold() {
     return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 17);
 }
 
-// Host control loop.  Per bounce `it`: wf_shade(it) -> [copy the two queue
-// counters] -> wf_trace(it).  The host waits for the counters of bounce `it`
-// while wf_trace(it) is still running, so the device never idles on the
-// decision; once the path supply is exhausted and at most wf_tail_threshold()
-// paths survive, one tail launch finishes them.
+// Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
+// [copy the live-slot counter] -> wf_trace(it).  The host waits for the counter of
+// bounce `it` while wf_trace(it) is still running, so the device never idles on
+// the decision; once at most wf_tail_threshold() slots are live, one tail launch
+// finishes them (including the paths those slots still have to start).
 static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float *hist_dev, bf_path_record *records_dev,
                            hipStream_t stream, bool count_nodes, bool stats) {
-    uint32_t cap = (uint32_t) std::min<uint64_t>(wf_pool_capacity(), std::max<uint64_t>(lp.n_paths, 1024));
+    uint64_t want = std::min<uint64_t>(wf_pool_capacity(), std::max<uint64_t>(lp.n_paths, 64));
+    uint32_t cap = (uint32_t) ((want + 63) & ~uint64_t(63));
     bf_status st = wf_ensure(scene, cap);
     if (st != BF_OK) return st;
-    const bfd::WF &wf = scene->wf;
-    uint32_t pool = (uint32_t) std::min<uint64_t>(wf.capacity, lp.n_paths);
-    HIP_TRY(hipMemsetAsync(wf.n_q, 0, 4 * (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemcpyAsync(wf.n_q, &pool, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(wf.pool, 0, 2 * bfd::kMaxShadeWaves * sizeof(unsigned long long), stream));
+    bfd::WF &wf = scene->wf;
+    wf.n_slots = (uint32_t) ((std::min<uint64_t>(wf.capacity, lp.n_paths) + 63) & ~uint64_t(63));
+    const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
+    for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
+        wf.m_alive[b] = scene->wf_masks + (3 * b + 0) * nb;
+        wf.m_trace[b] = scene->wf_masks + (3 * b + 1) * nb;
+        wf.m_shadow[b] = scene->wf_masks + (3 * b + 2) * nb;
+    }
+    HIP_TRY(hipMemsetAsync(wf.n_live, 0, (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
     size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan + 15) & ~size_t(15)) : 0;
     size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
-    // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
-    // 8 workgroups per CU (16 KiB LDS stack each, <= 64 VGPRs)
     static const int shade_waves = [] {
         const char *e = getenv("BF_SHADE_WAVES");
         int w = e ? atoi(e) : 2;
         return w < 1 ? 1 : (w > 4 ? 4 : w);
     }();
-    const unsigned grid_shade = (unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), grid_trace = (unsigned) scene->n_cus * bfd::kTraceBlocksPerCU;
+    // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
+    // 8 workgroups per CU (16 KiB LDS stack each, <= 64 VGPRs)
+    const unsigned batches_per_block = bfd::kBlock / 64;
+    const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
+    const unsigned grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), max_blocks));
+    const unsigned grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * bfd::kTraceBlocksPerCU, max_blocks));
     const uint32_t tail_max = wf_tail_threshold();
-    uint32_t n_cur = pool;                       // live slots entering bounce `it` (host's view)
-    volatile uint32_t *hq = scene->wf_host;      // [0] = n_q[it+1], [2..3] = next path counter
+    volatile uint32_t *hq = scene->wf_host;      // [0] = n_live[it]
     // per-kernel timing (stats renders only): events bracket every launch
     const size_t kMaxTimed = 96;
     size_t n_ev = 0;
@@ -506,31 +508,27 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         return BF_OK;
     };
     for (uint32_t it = 0; it < bfd::kWfMaxIter; ++it) {
-        unsigned blocks = (n_cur + bfd::kBlock - 1) / bfd::kBlock;
+        const int nxt = (it & 1) ^ 1;
+        HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, mask_bytes, stream));    // alive, trace, shadow are contiguous
         HIP_TRY(tic(1));
-        HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev,
-                             std::max(1u, std::min(grid_shade, blocks)), lds_shade, stream, shade_waves));
+        HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev, grid_shade, lds_shade, stream,
+                             shade_waves));
         HIP_TRY(toc());
-        HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_q + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync((void *) &hq[2], wf.counters + bfd::CTR_STARTED, sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_live + it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(scene->wf_event, stream));
-        // rays of this bounce: at most one shadow + one closest ray per live slot
         HIP_TRY(tic(0));
-        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, std::max(1u, std::min(grid_trace, 2 * blocks)), stream));
+        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream));
         HIP_TRY(toc());
         HIP_TRY(hipEventSynchronize(scene->wf_event));
-        uint32_t n_next = hq[0];
-        unsigned long long next_path = ((unsigned long long) hq[3] << 32) | hq[2];   // paths started so far
-        if (n_next == 0) return finish(it + 1, it + 1);
-        if (next_path >= lp.n_paths && n_next <= tail_max) {
+        uint32_t n_live = hq[0];
+        if (n_live == 0) return finish(it + 1, it + 1);
+        if (n_live <= tail_max) {
             HIP_TRY(tic(2));
-            HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, it + 1, n_next, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail,
+            HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, it + 1, n_live, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail,
                                     stream));
             HIP_TRY(toc());
             return finish(it + 1, it + 1);
         }
-        n_cur = n_next;
     }
     return fail(BF_ERR_UNSUPPORTED, "path depth exceeded the wavefront iteration limit (%u bounces)", bfd::kWfMaxIter);
 }

@@ -12,6 +12,7 @@
 //
 // Reference semantics (file:line) are cited at each function; the oracle
 // (oracle/bf_oracle.cpp) restates the same functions independently on the CPU.
+#include <algorithm>
 #include <cstring>
 
 #include "bf_path_logic.h"
@@ -58,28 +59,47 @@ __global__ __launch_bounds__(kBlock) void bf_render_kernel(DScene sc, DLaunch lp
     resume_hit.prim = 0;
     resume_hit.slot = 0;
     bool resume_first = false;
+    // RESUME: this wave's segment of the pool's alive mask; lanes adopt live slots
+    // from it whenever they are free (same on-the-fly compaction as wf_shade)
+    uint32_t resume_slots = 0;
+    MaskCursor rcur;
+    rcur.masks = nullptr;
+    rcur.b = rcur.b_end = 0;
+    rcur.m = 0ull;
     if (RESUME) {
-        done = true;
-        const uint32_t n_cur = wf.n_q[wf_it];
-        const uint32_t i = blockIdx.x * kBlock + tid;
-        if (i < n_cur) {
-            load_state(wf, wf_it & 1, i, receive, s);
-            alive = true;
-            if (!(s.flags & kFlagTermPending)) {
-                float4 hq = wf.hit[i];
-                resume_hit.t = hq.x;
-                resume_hit.u = hq.y;
-                resume_hit.v = hq.z;
-                resume_hit.slot = __float_as_int(hq.w);
-                resume_first = true;
-            }
-        }
+        resume_slots = wf.n_slots;
+        const uint32_t n_batches = wf.n_slots >> 6;
+        const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
+        const uint32_t per = (n_batches + n_waves - 1) / n_waves;
+        const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
+        cursor_init(rcur, wf.m_alive[wf_it & 1], b0, b1);
     }
 
     while (true) {
         // ---- 1. path regeneration: dead lanes pull new path indices -------
         unsigned long long need = __ballot(!alive && !done);
-        if (need) {
+        if (need && RESUME) {
+            uint32_t slot = 0;
+            const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t got = cursor_take(rcur, (uint32_t) __popcll(need), !alive && !done, rank, slot);
+            if (!alive && !done) {
+                if (rank < got) {
+                    load_state(wf, slot, receive, s);
+                    alive = true;
+                    resume_first = false;
+                    if (!(s.flags & kFlagTermPending)) {
+                        float4 hq = wf.hit[slot];
+                        resume_hit.t = hq.x;
+                        resume_hit.u = hq.y;
+                        resume_hit.v = hq.z;
+                        resume_hit.slot = __float_as_int(hq.w);
+                        resume_first = true;
+                    }
+                } else {
+                    done = true;       // the segment has no live slot left for this lane
+                }
+            }
+        } else if (need) {
             uint32_t n_need = __popcll(need);
             uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
             uint64_t path_i = 0;
@@ -115,13 +135,13 @@ __global__ __launch_bounds__(kBlock) void bf_render_kernel(DScene sc, DLaunch lp
         hit.prim = 0;
         hit.slot = 0;
         const bool term_pending = alive && (s.flags & kFlagTermPending);
-        if (RESUME && resume_first) {
+        if (RESUME && alive && resume_first) {
             hit = resume_hit;              // traced (and counted) by wf_trace already
         } else if (alive && !term_pending) {
             traverse<false, STATS>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
             ++c_closest;
         }
-        resume_first = false;
+        if (alive) resume_first = false;
 
         // ---- 3. vertex logic --------------------------------------------------
         ShadowReq sh;
@@ -149,6 +169,14 @@ __global__ __launch_bounds__(kBlock) void bf_render_kernel(DScene sc, DLaunch lp
         if (alive && (film || (s.flags & kFlagTermPending))) {
             film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
             alive = false;
+            if (RESUME) {
+                // the slot's static path sequence: i, i + n_slots, i + 2 n_slots, ...
+                uint64_t next_path = s.path_i + resume_slots;
+                if (next_path < lp.n_paths) {
+                    generate_path(sc, lp, next_path, s);
+                    alive = true;
+                }
+            }
         }
     }
 
@@ -231,7 +259,8 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
                                       hipStream_t stream) {
-    unsigned grid = (n_slots + bfd::kBlock - 1) / bfd::kBlock;
+    // one lane per live slot (gathered from the alive masks), at most one thread per pool slot
+    unsigned grid = (std::min(n_slots, wf->n_slots) + bfd::kBlock - 1) / bfd::kBlock;
     if (grid == 0) return hipSuccess;
     if (stats)
         hipLaunchKernelGGL((bfd::bf_render_kernel<true, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,

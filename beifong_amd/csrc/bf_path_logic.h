@@ -40,9 +40,9 @@ struct PathState {
     float lambda0;       // ray.wavelengths[0] in nm
 };
 
-BF_DEV void load_state(const WF &wf, int b, uint32_t i, bool receive, PathState &s) {
-    float4 r0 = wf.ray0[b][i], r1 = wf.ray1[b][i], a = wf.sa[b][i], bb = wf.sb[b][i];
-    uint4 c = wf.sc[b][i], d = wf.sd[b][i];
+BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
+    float4 r0 = wf.ray0[i], r1 = wf.ray1[i], a = wf.sa[i], bb = wf.sb[i];
+    uint4 c = wf.sc[i], d = wf.sd[i];
     s.ro = mk(r0.x, r0.y, r0.z);
     s.rmint = r0.w;
     s.rd = mk(r1.x, r1.y, r1.z);
@@ -60,21 +60,85 @@ BF_DEV void load_state(const WF &wf, int b, uint32_t i, bool receive, PathState 
     s.path_i = ((uint64_t) d.w << 32) | d.z;
     s.time = s.t_rx = s.lambda0 = 0.f;
     if (receive) {
-        float4 e = wf.se[b][i];
+        float4 e = wf.se[i];
         s.time = e.x;
         s.t_rx = e.y;
         s.lambda0 = e.z;
     }
 }
-BF_DEV void store_state(const WF &wf, int b, uint32_t j, bool receive, const PathState &s) {
-    wf.ray0[b][j] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
-    wf.ray1[b][j] = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
-    wf.sa[b][j] = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
-    wf.sb[b][j] = make_float4(s.aux, s.bs_pdf, s.prev_p.x, s.prev_p.y);
-    wf.sc[b][j] = make_uint4(__float_as_uint(s.prev_p.z), s.flags, s.n_rays, 0u);
-    wf.sd[b][j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
-                             (uint32_t) (s.path_i >> 32));
-    if (receive) wf.se[b][j] = make_float4(s.time, s.t_rx, s.lambda0, 0.f);
+BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState &s) {
+    wf.ray0[j] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
+    wf.ray1[j] = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
+    wf.sa[j] = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
+    wf.sb[j] = make_float4(s.aux, s.bs_pdf, s.prev_p.x, s.prev_p.y);
+    wf.sc[j] = make_uint4(__float_as_uint(s.prev_p.z), s.flags, s.n_rays, 0u);
+    wf.sd[j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
+                          (uint32_t) (s.path_i >> 32));
+    if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// on-the-fly compaction: a cursor over a segment of 64-bit batch masks hands the
+// next set bits (= slots that need work) to the lanes that ask for one
+// ---------------------------------------------------------------------------
+BF_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
+    // position of the r-th (0-based) set bit of m; caller guarantees r < popc(m)
+    uint32_t pos = 0;
+#pragma unroll
+    for (int shift = 32; shift >= 1; shift >>= 1) {
+        unsigned long long lowmask = (1ull << shift) - 1ull;
+        uint32_t cnt = (uint32_t) __popcll(m & lowmask);
+        if (r >= cnt) {
+            r -= cnt;
+            m >>= shift;
+            pos += shift;
+        } else {
+            m &= lowmask;
+        }
+    }
+    return pos;
+}
+
+struct MaskCursor {
+    const unsigned long long *masks;
+    uint32_t b, b_end;          // current / end batch of the segment (wave-uniform)
+    unsigned long long m;       // unconsumed bits of batch b (wave-uniform)
+};
+BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t b0, uint32_t b1) {
+    c.masks = masks;
+    c.b = b0;
+    c.b_end = b1;
+    c.m = b0 < b1 ? masks[b0] : 0ull;
+}
+BF_DEV bool cursor_empty(const MaskCursor &c) { return c.b >= c.b_end; }
+BF_DEV void cursor_skip_empty(MaskCursor &c) {
+    while (c.b < c.b_end && c.m == 0ull) {
+        ++c.b;
+        c.m = c.b < c.b_end ? c.masks[c.b] : 0ull;
+    }
+}
+// Hands out up to `want` slots: the requesting lane of rank r (0-based among the
+// requesters) receives a slot iff r < return value.  All control flow is uniform.
+BF_DEV uint32_t cursor_take(MaskCursor &c, uint32_t want, bool requesting, uint32_t rank, uint32_t &slot) {
+    uint32_t taken = 0;
+    while (taken < want && c.b < c.b_end) {
+        if (c.m == 0ull) {
+            ++c.b;
+            c.m = c.b < c.b_end ? c.masks[c.b] : 0ull;
+            continue;
+        }
+        uint32_t cnt = (uint32_t) __popcll(c.m);
+        uint32_t take = min(want - taken, cnt);
+        if (requesting && rank >= taken && rank < taken + take) slot = c.b * 64u + nth_set_bit(c.m, rank - taken);
+        if (take == cnt) {
+            c.m = 0ull;
+        } else {
+            uint32_t p = nth_set_bit(c.m, take - 1u);        // drop the `take` lowest set bits
+            c.m &= ~((2ull << p) - 1ull);
+        }
+        taken += take;
+    }
+    return taken;
 }
 
 // ---------------------------------------------------------------------------

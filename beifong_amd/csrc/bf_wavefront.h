@@ -1,42 +1,52 @@
-// Wavefront workspace: path state streamed through HBM in queue order.
+// Wavefront workspace: per-slot path state resident in HBM.
 //
-// All per-path arrays are SoA float4/uint4 so that a wave reads and writes
-// 1 KiB contiguous per array (16 B per lane, coalesced); the two state buffers
-// ping-pong between bounces while survivors are compacted.
+// The pool holds `n_slots` path slots (multiple of 64).  A slot's state stays IN
+// PLACE for the whole render (no ping-pong, no queue compaction — device-wide
+// queue counters serialise at ~88 returning atomics/us on MI355X, which made
+// one atomic per 64-slot batch the bottleneck of the shading kernel); which
+// slots need work is described by three bit masks per 64-slot batch:
+//   alive  : the slot holds a live path (shade it next bounce)
+//   trace  : its next closest-hit ray has to be traced
+//   shadow : it queued an NEE shadow ray this bounce
+// The kernels walk contiguous segments of batches and compact on the fly: a wave
+// pulls the next set bits of its segment's masks into its idle lanes
+// (__popcll / n-th-set-bit select), so sparse pools still run full waves.
+//
+// All per-slot arrays are SoA float4/uint4: a wave touching one dense batch reads
+// and writes 1 KiB contiguous per array.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace bfd {
 
-constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce queue counters
+constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce live counters
 constexpr uint32_t kSpillDepth = 16;    // stack entries beyond the 16 kept in LDS (tree depth <= 31)
 constexpr uint32_t kTraceBlocksPerCU = 8;
-constexpr uint32_t kMaxShadeWaves = 1u << 14;
 
 struct WF {
-    // path state, double buffered [2][capacity]
-    float4 *ray0[2];    // o.xyz, mint
-    float4 *ray1[2];    // d.xyz, maxt
-    float4 *sa[2];      // throughput, eta, emission_weight, result
-    float4 *sb[2];      // aux, bs_pdf, prev_p.x, prev_p.y
-    uint4 *sc[2];       // prev_p.z, depth|flags, n_rays, -
-    uint4 *sd[2];       // rng state lo/hi, path index lo/hi
-    float4 *se[2];      // receive mode only: ray.time, t_rx, lambda0, -
-    float4 *hit;        // t, u, v, slot      [capacity]
-    // shadow-ray queue [capacity]
+    // path state [n_slots]
+    float4 *ray0;       // o.xyz, mint
+    float4 *ray1;       // d.xyz, maxt
+    float4 *sa;         // throughput, eta, emission_weight, result
+    float4 *sb;         // aux, bs_pdf, prev_p.x, prev_p.y
+    uint4 *sc;          // prev_p.z, depth|flags, n_rays, -
+    uint4 *sd;          // rng state lo/hi, path index lo/hi
+    float4 *se;         // receive mode only: ray.time, t_rx, lambda0, -
+    float4 *hit;        // t, u, v, triangle slot
+    // NEE shadow ray of the slot (valid iff its shadow bit is set)
     float4 *sh0;        // o.xyz, mint
     float4 *sh1;        // d.xyz, maxt
-    uint2 *sh2;         // slot in the next state buffer, NEE contribution bits
-    int *spill;         // traversal-stack overflow: [kSpillDepth][max trace threads]
-    // per-bounce counters [kWfMaxIter + 2]
-    uint32_t *n_q;          // live slots entering bounce `it`
-    uint32_t *n_sh;         // shadow rays produced by bounce `it`
-    uint32_t *head_shade;   // work-queue heads of the persistent kernels
-    uint32_t *head_trace;
+    float *sh2;         // contribution released when unoccluded
+    // batch masks, double buffered by bounce parity: [2][n_slots / 64]
+    unsigned long long *m_alive[2];
+    unsigned long long *m_trace[2];
+    unsigned long long *m_shadow[2];
+    int *spill;                     // traversal-stack overflow: [kSpillDepth][max trace threads]
+    uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
-    unsigned long long *pool;       // per shade-wave pool of path indices {next, end} [kMaxShadeWaves]
-    uint32_t capacity;
+    uint32_t n_slots;               // slots in use this render (multiple of 64)
+    uint32_t capacity;              // slots allocated
 };
 
 }  // namespace bfd

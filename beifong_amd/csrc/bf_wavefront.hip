@@ -25,9 +25,24 @@
 
 namespace bfd {
 
+// OR-reduce per-lane bit contributions into the per-batch mask words.  Dense,
+// aligned rounds (every lane holds slot batch*64 + lane) store the ballot
+// directly; gathered rounds use atomicOr on the (pre-zeroed) words — spread over
+// many addresses, non-returning.
+BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, uint32_t batch0, uint32_t slot, bool valid_lane, bool bit) {
+    if (aligned) {
+        unsigned long long w = __ballot(bit);
+        if ((threadIdx.x & 63) == 0 && w) m_out[batch0] = w;
+    } else if (valid_lane && bit) {
+        atomicOr(&m_out[slot >> 6], 1ull << (slot & 63u));
+    }
+}
+
+// wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
+//   FIRST = true : bounce 0, every slot < n_slots starts its first path.
 template <bool FIRST, int W>
 __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
-                                                   bf_path_record *__restrict__ records) {
+                                                      bf_path_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     float *s_hist = reinterpret_cast<float *>(s_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -37,37 +52,62 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         __syncthreads();
     }
     const int cur = it & 1, nxt = cur ^ 1;
-    const uint32_t n_cur = wf.n_q[it];
     const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+    const uint32_t n_batches = wf.n_slots >> 6;
+    unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_started = 0;
+    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0;
 
-    // static wave-granular partition of the queue: a device-wide queue head
-    // saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md "dequeue"),
-    // which throttled 64-slot batches; batches are plentiful per wave, so a
-    // grid-stride walk balances well without any atomic.
+    // contiguous segment of batches per wave
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
-    for (uint32_t base = wave_id * 64u; base < n_cur; base += n_waves * 64u) {
-        const uint32_t i = base + lane;
-        const bool has = i < n_cur;
+    const uint32_t per = (n_batches + n_waves - 1) / n_waves;
+    const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
+    MaskCursor cur_alive;
+    if (!FIRST) cursor_init(cur_alive, wf.m_alive[cur], b0, b1);
+    uint32_t first_b = b0;
+
+    while (true) {
+        // ---- gather up to 64 live slots of the segment into the lanes -----------
+        uint32_t slot = 0, got;
+        bool aligned;
+        if (FIRST) {
+            if (first_b >= b1) break;
+            slot = first_b * 64u + lane;
+            got = 64;
+            aligned = true;
+            ++first_b;
+        } else {
+            cursor_skip_empty(cur_alive);
+            if (cursor_empty(cur_alive)) break;
+            const uint32_t batch_before = cur_alive.b;
+            const bool whole = __popcll(cur_alive.m) == 64;
+            got = cursor_take(cur_alive, 64u, true, (uint32_t) lane, slot);
+            if (got == 0) break;
+            aligned = whole && got == 64 && slot == batch_before * 64u + (uint32_t) lane;
+            aligned = __all(aligned);
+        }
+        const bool has = (uint32_t) lane < got;
+        const uint32_t batch0 = slot >> 6;
 
         PathState s;
         ShadowReq sh;
         sh.want = false;
         bool need_gen = false, cont = false;
+        uint64_t prev_path = 0;
 
         if (has) {
             if (FIRST) {
                 need_gen = true;
             } else {
-                load_state(wf, cur, i, receive, s);
+                load_state(wf, slot, receive, s);
+                prev_path = s.path_i;
                 if (s.flags & kFlagTermPending) {
                     // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
                     film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else {
-                    float4 hq = wf.hit[i];
+                    float4 hq = wf.hit[slot];
                     Hit hit;
                     hit.t = hq.x;
                     hit.u = hq.y;
@@ -85,74 +125,59 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 }
             }
         }
-
-        // ---- regeneration: finished slots pull fresh paths -------------------
-        unsigned long long gmask = __ballot(need_gen);
-        if (gmask) {
-            unsigned long long pbase = 0;
-            if (lane == 0) pbase = atomicAdd(&wf.counters[CTR_NEXT_PATH], (unsigned long long) __popcll(gmask));
-            pbase = __shfl(pbase, 0);
-            if (need_gen) {
-                uint64_t path_i = pbase + __popcll(gmask & ((1ull << lane) - 1ull));
-                if (path_i < lp.n_paths) {
-                    generate_path(sc, lp, path_i, s);
-                    ++c_closest;
-                    ++c_started;
-                    cont = true;
-                }
+        // ---- regeneration: slot i renders paths i, i + n_slots, i + 2 n_slots, ... --------
+        // (static assignment: no device-wide path counter to serialise on)
+        if (need_gen) {
+            uint64_t path_i = FIRST ? (uint64_t) slot : prev_path + wf.n_slots;
+            if (path_i < lp.n_paths) {
+                generate_path(sc, lp, path_i, s);
+                ++c_closest;
+                cont = true;
             }
         }
-
-        // ---- compaction: survivors -> next queue, shadow rays -> shadow queue --
-        unsigned long long cmask = __ballot(cont);
-        uint32_t j = 0;
-        if (cmask) {
-            uint32_t qb = 0;
-            if (lane == 0) qb = atomicAdd(&wf.n_q[it + 1], (uint32_t) __popcll(cmask));
-            qb = __shfl(qb, 0);
-            j = qb + __popcll(cmask & ((1ull << lane) - 1ull));
-            if (cont) store_state(wf, nxt, j, receive, s);
-        }
-        unsigned long long smask = __ballot(sh.want);
-        if (smask) {
-            uint32_t sb = 0;
-            if (lane == 0) sb = atomicAdd(&wf.n_sh[it], (uint32_t) __popcll(smask));
-            sb = __shfl(sb, 0);
+        // ---- write back in place + publish the batch masks ------------------------------
+        const bool tracing = cont && !(s.flags & kFlagTermPending);
+        if (cont) {
+            store_state(wf, slot, receive, s);
+            ++c_live;
             if (sh.want) {
-                uint32_t k = sb + __popcll(smask & ((1ull << lane) - 1ull));
-                wf.sh0[k] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
-                wf.sh1[k] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
-                wf.sh2[k] = make_uint2(j, __float_as_uint(sh.c));
+                wf.sh0[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
+                wf.sh1[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
+                wf.sh2[slot] = sh.c;
             }
         }
+        publish_masks(m_alive, aligned, batch0, slot, has, cont);
+        publish_masks(m_trace, aligned, batch0, slot, has, tracing);
+        publish_masks(m_shadow, aligned, batch0, slot, has, cont && sh.want);
     }
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
-    unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces,
-                       v_started = c_started;
+    unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
+    uint32_t v_live = c_live;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        v_started += __shfl_down(v_started, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
         v_invalid += __shfl_down(v_invalid, off);
         v_bounces += __shfl_down(v_bounces, off);
+        v_live += __shfl_down(v_live, off);
     }
     if (lane == 0) {
         if (v_closest) atomicAdd(&wf.counters[CTR_CLOSEST], v_closest);
         if (v_shadow) atomicAdd(&wf.counters[CTR_SHADOW], v_shadow);
         if (v_invalid) atomicAdd(&wf.counters[CTR_INVALID], v_invalid);
         if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
-        if (v_started) atomicAdd(&wf.counters[CTR_STARTED], v_started);   // host: supply exhausted iff == n_paths
+        if (v_live) atomicAdd(&wf.n_live[it], v_live);      // one non-returning atomic per wave per launch
     }
 }
 
-// Persistent-wave traversal with dynamic ray replacement: each wave owns a
-// contiguous segment of the job list (shadow rays first, then closest-hit
-// rays); a lane whose ray has finished takes the next job of the segment as
-// soon as the wave's occupancy drops below kRefill lanes (__ballot/__popcll
-// prefix, no atomics), so the wave's cost tracks the SUM of its rays'
-// traversal steps instead of 64 x the longest one.
+// Persistent-wave traversal with dynamic ray replacement.  Each wave owns a
+// contiguous segment of batches and walks first their shadow masks (any-hit
+// rays) and then their trace masks (closest-hit rays); a lane whose ray has
+// finished receives the next set bit as soon as the wave's occupancy drops to
+// kRefill lanes (MaskCursor: __popcll / n-th-set-bit select, no atomics), so the
+// wave's cost tracks the SUM of its rays' traversal steps instead of 64 x the
+// longest one, and sparse pools still traverse with full waves.
 //
 // "while-while" form: lanes first descend through internal nodes together
 // (postponing the leaf they reach), then all lanes holding a leaf intersect
@@ -173,18 +198,16 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
     int *stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int nxt = (it & 1) ^ 1;
-    const uint32_t n_sh = wf.n_sh[it], n_ext = wf.n_q[it + 1];
-    const uint32_t total = n_sh + n_ext;
     uint32_t c_nodes = 0, c_tris = 0;
     const uint32_t n_threads = gridDim.x * kBlock;
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     int *spill = wf.spill + (blockIdx.x * kBlock + threadIdx.x);    // entry k at spill[k * n_threads]
-    // segment per wave, multiple of 64 so that the first fetch of each wave is a coalesced 1 KiB read
-    uint32_t seg = (uint32_t) (((uint64_t) total + n_waves - 1) / n_waves);
-    seg = (seg + 63u) & ~63u;
-    uint64_t sb64 = (uint64_t) wave_id * seg;
-    uint32_t next = (uint32_t) (sb64 < total ? sb64 : total);
-    const uint32_t seg_end = (uint32_t) ((sb64 + seg) < total ? (sb64 + seg) : total);
+    const uint32_t n_batches = wf.n_slots >> 6;
+    const uint32_t per = (n_batches + n_waves - 1) / n_waves;
+    const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
+    MaskCursor cursor;
+    cursor_init(cursor, wf.m_shadow[nxt], b0, b1);
+    bool phase_shadow = true;       // wave-uniform: which job list the cursor walks
 
     bool has = false, any = false;
     uint32_t job = 0;
@@ -209,37 +232,41 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
         --sp;
         return sp < kLdsStack ? stack[sp * kBlock] : spill[(size_t) (sp - kLdsStack) * n_threads];
     };
+    auto work_left = [&]() -> bool { return phase_shadow || !cursor_empty(cursor); };
 
     while (true) {
         // ---- refill idle lanes from the wave's segment -------------------------
         unsigned long long idle = __ballot(!has);
-        if (idle && next < seg_end) {
-            uint32_t k = next + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
-            next += (uint32_t) __popcll(idle);
-            if (!has && k < seg_end) {
-                job = k;
-                float4 r0, r1;
-                if (k < n_sh) {
-                    r0 = wf.sh0[k];
-                    r1 = wf.sh1[k];
-                    any = true;
-                } else {
-                    r0 = wf.ray0[nxt][k - n_sh];
-                    r1 = wf.ray1[nxt][k - n_sh];
-                    any = false;
-                }
-                o = mk(r0.x, r0.y, r0.z);
-                d = mk(r1.x, r1.y, r1.z);
-                mint = r0.w;
-                maxt = r1.w;
-                best.t = BF_INF;
-                best.u = best.v = 0.f;
-                best.prim = 0;
-                best.slot = 0;
-                found = false;
-                has = true;
-                bool live = mint <= maxt;       // TERM_PENDING slots carry an empty interval
-                if (live) {
+        if (idle) {
+            uint32_t want = (uint32_t) __popcll(idle);
+            const uint32_t rank = (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+            uint32_t served = 0;
+            while (want && work_left()) {
+                uint32_t slot = 0;
+                const bool req = !has && rank >= served;
+                uint32_t got = cursor_take(cursor, want, req, rank - served, slot);
+                if (req && rank - served < got) {
+                    job = slot;
+                    float4 r0, r1;
+                    if (phase_shadow) {
+                        r0 = wf.sh0[slot];
+                        r1 = wf.sh1[slot];
+                        any = true;
+                    } else {
+                        r0 = wf.ray0[slot];
+                        r1 = wf.ray1[slot];
+                        any = false;
+                    }
+                    o = mk(r0.x, r0.y, r0.z);
+                    d = mk(r1.x, r1.y, r1.z);
+                    mint = r0.w;
+                    maxt = r1.w;
+                    best.t = BF_INF;
+                    best.u = best.v = 0.f;
+                    best.prim = 0;
+                    best.slot = 0;
+                    found = false;
+                    has = true;
                     for (uint32_t i = 0; i < sc.n_rects; ++i) {
                         const DRect &rc = sc.rects[i];
                         float t, lx, ly;
@@ -250,11 +277,17 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                                 consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
                         }
                     }
+                    id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                    node = sc.root;
+                    sp = 0;
+                    if (sc.n_tris == 0 || (any && found)) node = kNoNode;   // nothing to traverse
                 }
-                id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-                node = sc.root;
-                sp = 0;
-                if (!live || sc.n_tris == 0 || (any && found)) node = kNoNode;   // nothing to traverse
+                served += got;
+                want -= got;
+                if (want && cursor_empty(cursor) && phase_shadow) {
+                    phase_shadow = false;                       // shadow rays done: closest-hit rays next
+                    cursor_init(cursor, wf.m_trace[nxt], b0, b1);
+                }
             }
         }
         if (__ballot(has) == 0ull) break;
@@ -313,19 +346,18 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                 if (any) {
                     // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
                     if (!found) {
-                        uint2 e = wf.sh2[job];
-                        float4 a = wf.sa[nxt][e.x];
-                        a.w += __uint_as_float(e.y);
-                        wf.sa[nxt][e.x] = a;
+                        float4 a = wf.sa[job];
+                        a.w += wf.sh2[job];
+                        wf.sa[job] = a;
                     }
                 } else {
-                    wf.hit[job - n_sh] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
+                    wf.hit[job] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
                 }
                 has = false;
             }
             unsigned long long act = __ballot(has);
             if (act == 0ull) break;
-            if (next < seg_end && __popcll(act) <= kRefill) break;
+            if (work_left() && __popcll(act) <= kRefill) break;
         }
     }
     if (STATS) {
