@@ -421,6 +421,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sd, n * 16));
     HIP_TRY(alloc((void **) &wf.se, n * 16));
     HIP_TRY(alloc((void **) &wf.hit, n * 16));
+    HIP_TRY(alloc((void **) &wf.hit_prim, n * 4));
     HIP_TRY(alloc((void **) &wf.sh0, n * 16));
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
     HIP_TRY(alloc((void **) &wf.sh2, n * 4));

@@ -68,6 +68,23 @@ BF_DEV bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
     return tn <= tf * 1.0000004f;
 }
 
+// Same test with the origin folded in: t = lo * (1/d) - o * (1/d), one fma per plane
+// (12 instead of 24 VALU ops for the two child boxes).  The rounding of o * (1/d)
+// adds an absolute error of ~6e-8 * |o| to the plane distances; node boxes are
+// padded by 2e-6 * max|coordinate| (bf_bvh.cpp), 30x that, so the test stays
+// conservative.  Box tests only decide WHICH triangles get tested, never a hit value.
+BF_DEV bool slab_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 id, V3 oid, float mint, float tmax,
+                     float &tn) {
+    float t0x = fmadd(lox, id.x, oid.x), t1x = fmadd(hix, id.x, oid.x);
+    float t0y = fmadd(loy, id.y, oid.y), t1y = fmadd(hiy, id.y, oid.y);
+    float t0z = fmadd(loz, id.z, oid.z), t1z = fmadd(hiz, id.z, oid.z);
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                         __builtin_fmaxf(__builtin_fminf(t0z, t1z), mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                               __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
+    return tn <= tf * 1.0000004f;
+}
+
 // Scene::ray_intersect / ray_test — src/librender/scene.cpp:129-178.
 // `stack` points at this lane's column of the workgroup's LDS stack
 // (entry k at stack[k * kBlock]).

@@ -34,6 +34,7 @@ struct WF {
     uint4 *sd;          // rng state lo/hi, path index lo/hi
     float4 *se;         // receive mode only: ray.time, t_rx, lambda0, -
     float4 *hit;        // t, u, v, triangle slot
+    uint32_t *hit_prim; // global primitive index of `hit` (tie rule) while a ray is in flight
     // NEE shadow ray of the slot (valid iff its shadow bit is set)
     float4 *sh0;        // o.xyz, mint
     float4 *sh1;        // d.xyz, maxt

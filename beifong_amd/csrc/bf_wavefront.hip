@@ -38,6 +38,41 @@ BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, uint32_t batc
     }
 }
 
+// Early resolution of a freshly spawned ray, done by the shading lane itself
+// while the whole wave is active: the analytic rectangles (rectangle.cpp:229-263)
+// are tested here, and if the ray misses both child boxes of the BVH root no
+// triangle can be hit, so the query is already answered.  Only rays that enter
+// the mesh BVH are handed to wf_trace (with the best rectangle hit so far as
+// their starting point), which keeps that kernel's waves filled with comparable
+// work instead of mixing 3-step misses with 60-step hits.
+//   returns true if the ray still needs BVH traversal
+BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, bool &found) {
+    best.t = BF_INF;
+    best.u = best.v = 0.f;
+    best.prim = 0;
+    best.slot = 0;
+    found = false;
+    for (uint32_t i = 0; i < sc.n_rects; ++i) {
+        const DRect &rc = sc.rects[i];
+        float t, lx, ly;
+        if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
+            if (any) {
+                found = true;
+                return false;
+            }
+            consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
+        }
+    }
+    if (sc.n_tris == 0) return false;
+    if (sc.root < 0) return true;                 // the whole mesh is one leaf
+    const float4 *np = sc.nodes + 4u * (uint32_t) sc.root;
+    float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    V3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    float tmax = any ? maxt : __builtin_fminf(maxt, best.t), tn;
+    return slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn) ||
+           slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn);
+}
+
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
 //   FIRST = true : bounce 0, every slot < n_slots starts its first path.
 template <bool FIRST, int W>
@@ -135,12 +170,29 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 cont = true;
             }
         }
-        // ---- write back in place + publish the batch masks ------------------------------
-        const bool tracing = cont && !(s.flags & kFlagTermPending);
+        // ---- early resolution of the new rays, write back in place -----------------------
+        bool tracing = cont && !(s.flags & kFlagTermPending);
+        bool shadowing = cont && sh.want;
+        if (shadowing) {
+            Hit tmp;
+            bool found;
+            if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
+                if (!found) s.result += sh.c;        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
+                shadowing = false;
+            }
+        }
+        if (tracing) {
+            Hit best;
+            bool found;
+            tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, best, found);
+            // resolved rays get their final hit here; the others start wf_trace from the rectangle hit
+            wf.hit[slot] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
+            wf.hit_prim[slot] = best.prim;
+        }
         if (cont) {
             store_state(wf, slot, receive, s);
             ++c_live;
-            if (sh.want) {
+            if (shadowing) {
                 wf.sh0[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
                 wf.sh1[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
                 wf.sh2[slot] = sh.c;
@@ -148,7 +200,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         }
         publish_masks(m_alive, aligned, batch0, slot, has, cont);
         publish_masks(m_trace, aligned, batch0, slot, has, tracing);
-        publish_masks(m_shadow, aligned, batch0, slot, has, cont && sh.want);
+        publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
     }
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
@@ -189,6 +241,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 // spill to a per-thread column in HBM.  16 KiB of LDS per workgroup instead of
 // 32 lifts the kernel from 5 to 8 waves/SIMD.
 constexpr int kRefill = 44;
+constexpr int kStragglers = 12;
 constexpr int kLdsStack = 16;
 constexpr int kNoNode = INT32_MIN;
 
@@ -211,7 +264,7 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
 
     bool has = false, any = false;
     uint32_t job = 0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), id = mk(0, 0, 0);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), id = mk(0, 0, 0), oid = mk(0, 0, 0);
     float mint = 0.f, maxt = 0.f;
     Hit best;
     best.t = BF_INF;
@@ -220,6 +273,7 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
     best.slot = 0;
     int node = kNoNode, sp = 0;
     bool found = false;      // any-hit result
+    uint32_t guard = 0;
 
     auto push = [&](int v) {
         if (sp < kLdsStack)
@@ -261,26 +315,29 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                     d = mk(r1.x, r1.y, r1.z);
                     mint = r0.w;
                     maxt = r1.w;
+                    found = false;
+                    has = true;
                     best.t = BF_INF;
                     best.u = best.v = 0.f;
                     best.prim = 0;
                     best.slot = 0;
-                    found = false;
-                    has = true;
-                    for (uint32_t i = 0; i < sc.n_rects; ++i) {
-                        const DRect &rc = sc.rects[i];
-                        float t, lx, ly;
-                        if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
-                            if (any)
-                                found = true;
-                            else
-                                consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
-                        }
+                    if (!phase_shadow) {
+                        // closest-hit rays continue from the rectangle hit wf_shade found (presolve_ray)
+                        float4 hq = wf.hit[slot];
+                        best.t = hq.x;
+                        best.u = hq.y;
+                        best.v = hq.z;
+                        best.slot = __float_as_int(hq.w);
+                        best.prim = wf.hit_prim[slot];
                     }
+                    // a zero direction component gives +-inf; clamp so that 0 * inf never appears in the fma form
                     id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+                    id.x = __builtin_fminf(__builtin_fmaxf(id.x, -3.0e38f), 3.0e38f);
+                    id.y = __builtin_fminf(__builtin_fmaxf(id.y, -3.0e38f), 3.0e38f);
+                    id.z = __builtin_fminf(__builtin_fmaxf(id.z, -3.0e38f), 3.0e38f);
+                    oid = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
                     node = sc.root;
                     sp = 0;
-                    if (sc.n_tris == 0 || (any && found)) node = kNoNode;   // nothing to traverse
                 }
                 served += got;
                 want -= got;
@@ -294,16 +351,26 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
 
         // ---- traversal until the wave thins out -----------------------------------
         while (true) {
-            // (a) descend through internal nodes; a lane that reaches a leaf (node < 0) waits
-            while (__ballot(has && node >= 0)) {
+            if (++guard > (1u << 26)) {      // safety net: a persistent wave must always drain
+                has = false;
+                break;
+            }
+            // (a) descend through internal nodes; a lane that reaches a leaf (node < 0) waits.
+            // Stop descending once fewer than kStragglers lanes are still at internal nodes:
+            // they resume after the others' leaves have been intersected.
+            while (true) {
+                const unsigned long long at_node = __ballot(has && node >= 0);
+                if (!at_node) break;
+                // progress guarantee: only postpone the stragglers if some lane has a leaf to intersect
+                if (__popcll(at_node) < kStragglers && __ballot(has && node < 0 && node != kNoNode)) break;
                 if (has && node >= 0) {
                     const float4 *np = sc.nodes + 4u * (uint32_t) node;
                     float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     if (STATS) ++c_nodes;
                     float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
                     float tn0, tn1;
-                    bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
-                    bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
+                    bool h0 = slab_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, id, oid, mint, tmax, tn0);
+                    bool h1 = slab_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, id, oid, mint, tmax, tn1);
                     int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
                     if (h0 && h1) {
                         if (tn1 < tn0) {
@@ -322,8 +389,8 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                     }
                 }
             }
-            // (b) every lane now holds a leaf or nothing: intersect the leaves together
-            if (has && node != kNoNode) {
+            // (b) intersect the postponed leaves together
+            if (has && node < 0 && node != kNoNode) {
                 uint32_t enc = ~(uint32_t) node;
                 uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
                 for (uint32_t i = 0; i < cnt; ++i) {
