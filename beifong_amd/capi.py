@@ -88,7 +88,7 @@ class bf_stats(C.Structure):
                 ("n_nodes_visited", C.c_uint64), ("n_tris_tested", C.c_uint64), ("n_invalid", C.c_uint64),
                 ("n_bounces", C.c_uint64), ("kernel_ms", C.c_float), ("trace_ms", C.c_float),
                 ("shade_ms", C.c_float), ("tail_ms", C.c_float), ("n_launches_trace", C.c_uint32),
-                ("n_bounce_iters", C.c_uint32), ("n_rays_tail", C.c_uint64)]
+                ("n_bounce_iters", C.c_uint32), ("n_rays_tail", C.c_uint64), ("n_rays_traced", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -104,7 +104,7 @@ class bf_scene_info(C.Structure):
 EXPORTED_SYMBOLS = [
     "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
     "bf_scene_destroy", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
-    "bf_trace_closest", "bf_trace_any",
+    "bf_trace_closest", "bf_trace_any", "bf_eval_elementary",
 ]
 
 _lib = None
@@ -139,6 +139,7 @@ def load_library(path=None):
     lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
     lib.bf_trace_any.argtypes = [vp, C.c_uint64, vp, vp]
+    lib.bf_eval_elementary.argtypes = [C.c_int, C.c_uint64, vp, vp]
     if path is None:
         _lib = lib
     return lib

@@ -19,6 +19,8 @@
 extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunch *lp, float *g_hist, bf_path_record *records,
                                         unsigned long long *counters, int stats, unsigned grid, size_t lds_bytes,
                                         hipStream_t stream);
+extern "C" float bfk_host_cos(float x);
+extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y);
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
                                        hipStream_t stream);
@@ -242,8 +244,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             de.cutoff = e.cutoff_angle_deg * (pi / 180.f);
             de.beam = e.beam_width_deg * (pi / 180.f);
             de.inv_transition = 1.0f / (de.cutoff - de.beam);
-            de.cos_cutoff = (float) std::cos((double) de.cutoff);
-            de.cos_beam = (float) std::cos((double) de.beam);
+            de.cos_cutoff = bfk_host_cos(de.cutoff);
+            de.cos_beam = bfk_host_cos(de.beam);
         } else if (e.type == BF_EMITTER_AREA || e.type == BF_TRANSMITTER_AREA || e.type == BF_TRANSMITTER_WIGNER) {
             if (e.shape < 0 || e.shape >= (int32_t) desc->n_shapes || desc->shapes[e.shape].type != BF_SHAPE_RECTANGLE)
                 return fail(BF_ERR_UNSUPPORTED, "emitter %u: area emitters / transmitters must sit on a rectangle", i);
@@ -610,6 +612,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         stats_out->n_invalid = c[bfd::CTR_INVALID];
         stats_out->n_bounces = c[bfd::CTR_BOUNCES];
         stats_out->n_rays_tail = c[bfd::CTR_TAIL_RAYS];
+        stats_out->n_rays_traced = c[bfd::CTR_TRACED];
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         stats_out->kernel_ms = ms;
@@ -700,6 +703,22 @@ bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays,
 
 bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays, uint8_t *out_hit) {
     return trace_common(scene, n, rays, 1, nullptr, nullptr, nullptr, nullptr, out_hit);
+}
+
+bf_status bf_eval_elementary(int op, uint64_t n, const float *x, float *y) {
+    if (op < 0 || op > 6 || (n && (!x || !y))) return fail(BF_ERR_INVALID, "bf_eval_elementary: bad arguments");
+    if (n == 0) return BF_OK;
+    float *d_x = nullptr, *d_y = nullptr;
+    hipError_t e = hipMalloc((void **) &d_x, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **) &d_y, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = bfk_launch_elementary(op, n, d_x, d_y);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(y, d_y, n * 4, hipMemcpyDeviceToHost);
+    (void) hipFree(d_x);
+    (void) hipFree(d_y);
+    if (e != hipSuccess) return fail(BF_ERR_DEVICE, "bf_eval_elementary: %s", hipGetErrorString(e));
+    return BF_OK;
 }
 
 }  // extern "C"

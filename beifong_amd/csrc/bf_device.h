@@ -87,6 +87,6 @@ struct DLaunch {
 };
 
 // device counters (uint64 each)
-enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_COUNT };
+enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_TRACED, CTR_COUNT };
 
 }  // namespace bfd

@@ -6,9 +6,9 @@
 // form, normalize = v * (1/sqrt(dot))), and nowhere else — the translation
 // unit is compiled with -ffp-contract=off.  Division and sqrt are IEEE
 // (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).  Scalar
-// transcendentals (sin, cos, acos, exp, log, erf) are evaluated in double and
-// rounded once, which is what the reference's scalar variant gets from libm to
-// within rounding.
+// transcendentals (sin, cos, acos, exp, log, erf) follow the fp32 specification
+// below (bf_exp, bf_log, ...): fixed IEEE operation sequences shared with the
+// oracle, within 2.5 ulp of the libm calls the reference's scalar variant makes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,6 +16,7 @@
 namespace bfd {
 
 #define BF_DEV __device__ __forceinline__
+#define BF_HD __host__ __device__ __forceinline__
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kInvPi = 0.31830988618379067154f;
@@ -31,13 +32,207 @@ BF_DEV float fnmadd(float a, float b, float c) { return __builtin_fmaf(-a, b, c)
 BF_DEV float sqr(float x) { return x * x; }
 BF_DEV float rcp(float x) { return 1.f / x; }
 BF_DEV float safe_sqrt(float x) { return __builtin_sqrtf(__builtin_fmaxf(x, 0.f)); }
-BF_DEV float sin_cr(float x) { return (float) ::sin((double) x); }
-BF_DEV float cos_cr(float x) { return (float) ::cos((double) x); }
-BF_DEV float acos_cr(float x) { return (float) ::acos((double) x); }
-BF_DEV float exp_cr(float x) { return (float) ::exp((double) x); }
-BF_DEV float log_cr(float x) { return (float) ::log((double) x); }
-BF_DEV float erf_cr(float x) { return (float) ::erf((double) x); }
-BF_DEV float tan_cr(float x) { return (float) ::tan((double) x); }
+
+// ---------------------------------------------------------------------------
+// fp32 elementary functions — the engine's SPECIFICATION of sin/cos/acos/exp/
+// log/erf/tan.  The reference's scalar variants call libm (glibc) for these;
+// here each function is a fixed sequence of IEEE fp32 operations (+ - * / fma
+// sqrt rint, integer bit tricks), so that the HIP kernels and the CPU oracle
+// produce bit-identical values without fp64 anywhere on the device.  Algorithms:
+// Cephes single precision (expf, logf, sinf/cosf with three-part pi/4 reduction,
+// asinf/acosf); erf: three-range polynomial fit (tools/gen_erf_coeffs.py).
+// Accuracy vs libm: <= 2.5 ulp (tests/test_oracle_known_answers.py::test_elementary_functions).
+// ---------------------------------------------------------------------------
+BF_HD float bf_bits_to_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+BF_HD uint32_t bf_float_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+BF_HD float bf_exp(float x) {
+    if (!(x >= -87.0f)) return (x != x) ? x : 0.f;           // results below FLT_MIN are flushed to 0
+    if (x > 88.72283905f) return __builtin_huge_valf();
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    p = __builtin_fmaf(p, r * r, r);
+    p = p + 1.f;
+    int ni = (int) n;
+    if (ni > 127) {
+        p = p * 2.f;
+        ni -= 1;
+    }
+    return p * bf_bits_to_float((uint32_t) (ni + 127) << 23);
+}
+
+BF_HD float bf_log(float x) {
+    if (!(x > 0.f)) return (x == 0.f) ? -__builtin_huge_valf() : __builtin_nanf("");
+    if (x == __builtin_huge_valf()) return x;
+    int e_adj = 0;
+    if (x < 1.17549435e-38f) {
+        x = x * 8388608.f;
+        e_adj = -23;
+    }
+    uint32_t b = bf_float_to_bits(x);
+    int e = (int) ((b >> 23) & 0xffu) - 126 + e_adj;
+    float m = bf_bits_to_float((b & 0x007fffffu) | 0x3f000000u);     // [0.5, 1)
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.f;
+    } else {
+        m = m - 1.f;
+    }
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = __builtin_fmaf(y, m, -1.1514610310e-1f);
+    y = __builtin_fmaf(y, m, 1.1676998740e-1f);
+    y = __builtin_fmaf(y, m, -1.2420140846e-1f);
+    y = __builtin_fmaf(y, m, 1.4249322787e-1f);
+    y = __builtin_fmaf(y, m, -1.6668057665e-1f);
+    y = __builtin_fmaf(y, m, 2.0000714765e-1f);
+    y = __builtin_fmaf(y, m, -2.4999993993e-1f);
+    y = __builtin_fmaf(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    float fe = (float) e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// sin and cos of x together (three-part Cody-Waite reduction by pi/4; exact for |x| < ~5e4)
+BF_HD void bf_sincos(float x, float &s_out, float &c_out) {
+    float ax = __builtin_fabsf(x);
+    if (!(ax < 3.0e9f)) {          // inf / nan / absurdly large: NaN like libm would for inf
+        s_out = c_out = (ax != ax || ax == __builtin_huge_valf()) ? __builtin_nanf("") : 0.f;
+        if (ax == ax && ax != __builtin_huge_valf()) c_out = 1.f;
+        return;
+    }
+    uint32_t j = (uint32_t) (ax * 1.27323954473516f);
+    if (j & 1u) j += 1u;
+    float y = (float) j;
+    float r = __builtin_fmaf(-y, 0.78515625f, ax);
+    r = __builtin_fmaf(-y, 2.4187564849853515625e-4f, r);
+    r = __builtin_fmaf(-y, 3.77489497744594108e-8f, r);
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = __builtin_fmaf(ps, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    ps = __builtin_fmaf(ps * z, r, r);                       // sin(r)
+    float pc = 2.443315711809948e-5f;
+    pc = __builtin_fmaf(pc, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.f));     // cos(r)
+    uint32_t q = j & 7u;                           // octant pair: 0,2,4,6
+    float sv = (q == 2u || q == 6u) ? pc : ps;
+    float cv = (q == 2u || q == 6u) ? ps : pc;
+    if (q == 4u || q == 6u) sv = -sv;
+    if (q == 2u || q == 4u) cv = -cv;
+    s_out = (x < 0.f) ? -sv : sv;
+    c_out = cv;
+}
+BF_HD float bf_sin(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return s;
+}
+BF_HD float bf_cos(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return c;
+}
+BF_HD float bf_tan(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return s / c;
+}
+
+BF_HD float bf_asin_core(float a) {               // a in [0, 1]
+    bool flag = a > 0.5f;
+    float z, x;
+    if (flag) {
+        z = 0.5f * (1.f - a);
+        x = __builtin_sqrtf(z);
+    } else {
+        x = a;
+        z = x * x;
+    }
+    float p = 4.2163199048e-2f;
+    p = __builtin_fmaf(p, z, 2.4181311049e-2f);
+    p = __builtin_fmaf(p, z, 4.5470025998e-2f);
+    p = __builtin_fmaf(p, z, 7.4953002686e-2f);
+    p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+    p = __builtin_fmaf(p * z, x, x);
+    if (flag) p = 1.5707963267948966f - (p + p);
+    return p;
+}
+BF_HD float bf_acos(float x) {
+    if (!(x >= -1.f && x <= 1.f)) return __builtin_nanf("");
+    if (x < -0.5f) return 3.14159265358979323846f - 2.f * bf_asin_core(__builtin_sqrtf(0.5f * (1.f + x)));
+    if (x > 0.5f) return 2.f * bf_asin_core(__builtin_sqrtf(0.5f * (1.f - x)));
+    float a = bf_asin_core(__builtin_fabsf(x));
+    return 1.5707963267948966f - ((x < 0.f) ? -a : a);
+}
+
+BF_HD float bf_erf(float x) {
+    float a = __builtin_fabsf(x);
+    if (a != a) return x;
+    float r;
+    if (a < 0.8f) {
+        float z = x * x;
+        float p = -1.128872449e-05f;
+        p = __builtin_fmaf(p, z, 1.169606002e-04f);
+        p = __builtin_fmaf(p, z, -8.529368140e-04f);
+        p = __builtin_fmaf(p, z, 5.223417615e-03f);
+        p = __builtin_fmaf(p, z, -2.686608035e-02f);
+        p = __builtin_fmaf(p, z, 1.128379095e-01f);
+        p = __builtin_fmaf(p, z, -3.761263888e-01f);
+        p = __builtin_fmaf(p, z, 1.128379167e+00f);
+        return p * x;
+    } else if (a < 1.6f) {
+        float t = a - 1.2f;
+        float p = 3.210465009e-04f;
+        p = __builtin_fmaf(p, t, -5.621837162e-03f);
+        p = __builtin_fmaf(p, t, 5.989846125e-03f);
+        p = __builtin_fmaf(p, t, 1.957314866e-02f);
+        p = __builtin_fmaf(p, t, -5.334181702e-02f);
+        p = __builtin_fmaf(p, t, 6.419227034e-03f);
+        p = __builtin_fmaf(p, t, 1.675358269e-01f);
+        p = __builtin_fmaf(p, t, -3.208132755e-01f);
+        p = __builtin_fmaf(p, t, 2.673443467e-01f);
+        p = __builtin_fmaf(p, t, 9.103139784e-01f);
+        r = p;
+    } else if (a < 4.0f) {
+        float t = a - 2.8f;
+        float p = 1.378729715e-09f;
+        p = __builtin_fmaf(p, t, -1.412586080e-07f);
+        p = __builtin_fmaf(p, t, 1.344892106e-06f);
+        p = __builtin_fmaf(p, t, -9.056785943e-06f);
+        p = __builtin_fmaf(p, t, 5.432784894e-05f);
+        p = __builtin_fmaf(p, t, -3.038591482e-04f);
+        p = __builtin_fmaf(p, t, 1.626972312e-03f);
+        p = __builtin_fmaf(p, t, -8.600132565e-03f);
+        p = __builtin_fmaf(p, t, -9.526015505e-01f);
+        p = __builtin_fmaf(p, t, -5.921730786e+00f);
+        p = __builtin_fmaf(p, t, -9.497846531e+00f);
+        r = 1.f - bf_exp(p);
+    } else {
+        r = 1.f;
+    }
+    return (x < 0.f) ? -r : r;
+}
+
+BF_DEV float sin_cr(float x) { return bf_sin(x); }
+BF_DEV float cos_cr(float x) { return bf_cos(x); }
+BF_DEV float acos_cr(float x) { return bf_acos(x); }
+BF_DEV float exp_cr(float x) { return bf_exp(x); }
+BF_DEV float log_cr(float x) { return bf_log(x); }
+BF_DEV float erf_cr(float x) { return bf_erf(x); }
+BF_DEV float tan_cr(float x) { return bf_tan(x); }
 BF_DEV float mulsign(float a, float b) { return __builtin_signbitf(b) ? -a : a; }
 BF_DEV float mulsign_neg(float a, float b) { return __builtin_signbitf(b) ? a : -a; }
 
@@ -144,10 +339,10 @@ BF_DEV void square_to_uniform_disk_concentric(float sx, float sy, float &ox, flo
     float phi = .25f * kPi * rp / r;
     if (q13) phi = .5f * kPi - phi;
     if (is_zero) phi = 0.f;
-    double s, c;
-    ::sincos((double) phi, &s, &c);
-    ox = r * (float) c;
-    oy = r * (float) s;
+    float s, c;
+    bf_sincos(phi, s, c);
+    ox = r * c;
+    oy = r * s;
 }
 BF_DEV V3 square_to_cosine_hemisphere(float sx, float sy) {
     float px, py;

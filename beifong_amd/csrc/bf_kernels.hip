@@ -271,6 +271,34 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     return hipGetLastError();
 }
 
+/* Host-side evaluation of the engine's fp32 cosine (bf_device_math.h), used by scene setup so that
+ * precomputed emitter constants follow the same specification as the kernels. */
+extern "C" float bfk_host_cos(float x) { return bfd::bf_cos(x); }
+
+namespace bfd {
+__global__ void bf_elementary_kernel(int op, uint64_t n, const float *__restrict__ x, float *__restrict__ y) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i], r;
+    switch (op) {
+        case 0: r = sin_cr(v); break;
+        case 1: r = cos_cr(v); break;
+        case 2: r = acos_cr(v); break;
+        case 3: r = exp_cr(v); break;
+        case 4: r = log_cr(v); break;
+        case 5: r = erf_cr(v); break;
+        default: r = tan_cr(v); break;
+    }
+    y[i] = r;
+}
+}  // namespace bfd
+
+extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y) {
+    unsigned grid = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(bfd::bf_elementary_kernel, dim3(grid), dim3(256), 0, 0, op, n, x, y);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
                                        hipStream_t stream) {

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0;
+    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0;
 
     // contiguous segment of batches per wave
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
@@ -201,13 +201,16 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         publish_masks(m_alive, aligned, batch0, slot, has, cont);
         publish_masks(m_trace, aligned, batch0, slot, has, tracing);
         publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
+        c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
     }
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
     uint32_t v_live = c_live;
+    unsigned long long v_traced = c_traced;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v_traced += __shfl_down(v_traced, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
         v_invalid += __shfl_down(v_invalid, off);
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         if (v_invalid) atomicAdd(&wf.counters[CTR_INVALID], v_invalid);
         if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
         if (v_live) atomicAdd(&wf.n_live[it], v_live);      // one non-returning atomic per wave per launch
+        if (v_traced) atomicAdd(&wf.counters[CTR_TRACED], v_traced);
     }
 }
 

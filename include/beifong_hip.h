@@ -208,6 +208,8 @@ typedef struct bf_stats {
     uint32_t n_launches_trace; /* wf_trace launches in this render                  */
     uint32_t n_bounce_iters;   /* wavefront iterations executed                     */
     uint64_t n_rays_tail;      /* rays traced by the tail kernel (not by wf_trace)   */
+    uint64_t n_rays_traced;    /* rays that entered wf_trace (the others were resolved
+                                  by wf_shade: rectangles + BVH root-box test)       */
 } bf_stats;
 
 typedef struct bf_scene_info {
@@ -254,6 +256,13 @@ bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays,
                            float *out_uv);
 bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays,
                        uint8_t *out_hit);
+
+/* Evaluate the engine's fp32 elementary functions ON THE DEVICE over a HOST
+ * array (conformance checks: the kernels use these in place of the libm calls
+ * the reference's scalar variants make, e.g. spot.cpp:136, microfacet.h:160-190,
+ * wignertransmitter.cpp signal models).  op: 0 sin, 1 cos, 2 acos, 3 exp, 4 log,
+ * 5 erf, 6 tan.  Needs no scene. */
+bf_status bf_eval_elementary(int op, uint64_t n, const float *x, float *y);
 
 #ifdef __cplusplus
 }

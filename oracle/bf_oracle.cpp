@@ -19,10 +19,11 @@
  * submodule): PCG32 (O'Neill's published pcg32 algorithm and constants),
  * dot/cross/normalize/fmadd conventions (enoki's generic array
  * implementation: dot = fma chain from lane 0, cross = fmsub form,
- * normalize = v * (1/sqrt(dot))), scalar sin/cos/acos/exp/log/erf (libm;
- * evaluated here in double and rounded once to float, which is what glibc's
- * float routines deliver to within rounding), erfinv (Giles' single precision
- * polynomial, the algorithm enoki cites).
+ * normalize = v * (1/sqrt(dot))), scalar sin/cos/acos/exp/log/erf (libm in the
+ * reference; here the engine's fp32 specification bf_exp/bf_log/bf_sincos/
+ * bf_acos/bf_erf — fixed IEEE operation sequences, <= 2.5 ulp from libm — so
+ * that the GPU can match bit for bit without fp64), erfinv (Giles' single
+ * precision polynomial, the algorithm enoki cites).
  *
  * Build: see oracle/Makefile (g++ -O2 -ffp-contract=off; fused multiply-adds
  * appear only where the reference writes fmadd/fmsub/fnmadd).
@@ -61,12 +62,206 @@ inline float fnmadd(float a, float b, float c) { return std::fmaf(-a, b, c); }
 inline float sqr(float x) { return x * x; }
 inline float rcp(float x) { return 1.f / x; }
 inline float safe_sqrt(float x) { return std::sqrt(std::max(x, 0.f)); }
-inline float sinf_cr(float x) { return (float) std::sin((double) x); }
-inline float cosf_cr(float x) { return (float) std::cos((double) x); }
-inline float acosf_cr(float x) { return (float) std::acos((double) x); }
-inline float expf_cr(float x) { return (float) std::exp((double) x); }
-inline float logf_cr(float x) { return (float) std::log((double) x); }
-inline float erff_cr(float x) { return (float) std::erf((double) x); }
+
+// ---------------------------------------------------------------------------
+// fp32 elementary functions — the engine's SPECIFICATION of sin/cos/acos/exp/
+// log/erf/tan.  The reference's scalar variants call libm (glibc) for these;
+// here each function is a fixed sequence of IEEE fp32 operations (+ - * / fma
+// sqrt rint, integer bit tricks), so that the HIP kernels and the CPU oracle
+// produce bit-identical values without fp64 anywhere on the device.  Algorithms:
+// Cephes single precision (expf, logf, sinf/cosf with three-part pi/4 reduction,
+// asinf/acosf); erf: three-range polynomial fit (tools/gen_erf_coeffs.py).
+// Accuracy vs libm: <= 2.5 ulp (tests/test_oracle_known_answers.py::test_elementary_functions).
+// ---------------------------------------------------------------------------
+inline float bf_bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t bf_float_to_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+inline float bf_exp(float x) {
+    if (!(x >= -87.0f)) return (x != x) ? x : 0.f;           // results below FLT_MIN are flushed to 0
+    if (x > 88.72283905f) return std::numeric_limits<float>::infinity();
+    float n = std::rintf(x * 1.44269504088896341f);
+    float r = std::fmaf(n, -0.693359375f, x);
+    r = std::fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = std::fmaf(p, r, 1.3981999507e-3f);
+    p = std::fmaf(p, r, 8.3334519073e-3f);
+    p = std::fmaf(p, r, 4.1665795894e-2f);
+    p = std::fmaf(p, r, 1.6666665459e-1f);
+    p = std::fmaf(p, r, 5.0000001201e-1f);
+    p = std::fmaf(p, r * r, r);
+    p = p + 1.f;
+    int ni = (int) n;
+    if (ni > 127) {
+        p = p * 2.f;
+        ni -= 1;
+    }
+    return p * bf_bits_to_float((uint32_t) (ni + 127) << 23);
+}
+
+inline float bf_log(float x) {
+    if (!(x > 0.f)) return (x == 0.f) ? -std::numeric_limits<float>::infinity() : std::numeric_limits<float>::quiet_NaN();
+    if (x == std::numeric_limits<float>::infinity()) return x;
+    int e_adj = 0;
+    if (x < 1.17549435e-38f) {
+        x = x * 8388608.f;
+        e_adj = -23;
+    }
+    uint32_t b = bf_float_to_bits(x);
+    int e = (int) ((b >> 23) & 0xffu) - 126 + e_adj;
+    float m = bf_bits_to_float((b & 0x007fffffu) | 0x3f000000u);     // [0.5, 1)
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.f;
+    } else {
+        m = m - 1.f;
+    }
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = std::fmaf(y, m, -1.1514610310e-1f);
+    y = std::fmaf(y, m, 1.1676998740e-1f);
+    y = std::fmaf(y, m, -1.2420140846e-1f);
+    y = std::fmaf(y, m, 1.4249322787e-1f);
+    y = std::fmaf(y, m, -1.6668057665e-1f);
+    y = std::fmaf(y, m, 2.0000714765e-1f);
+    y = std::fmaf(y, m, -2.4999993993e-1f);
+    y = std::fmaf(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    float fe = (float) e;
+    y = std::fmaf(fe, -2.12194440e-4f, y);
+    y = std::fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = std::fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// sin and cos of x together (three-part Cody-Waite reduction by pi/4; exact for |x| < ~5e4)
+inline void bf_sincos(float x, float &s_out, float &c_out) {
+    float ax = std::fabs(x);
+    if (!(ax < 3.0e9f)) {          // inf / nan / absurdly large: NaN like libm would for inf
+        s_out = c_out = (ax != ax || ax == std::numeric_limits<float>::infinity()) ? std::numeric_limits<float>::quiet_NaN() : 0.f;
+        if (ax == ax && ax != std::numeric_limits<float>::infinity()) c_out = 1.f;
+        return;
+    }
+    uint32_t j = (uint32_t) (ax * 1.27323954473516f);
+    if (j & 1u) j += 1u;
+    float y = (float) j;
+    float r = std::fmaf(-y, 0.78515625f, ax);
+    r = std::fmaf(-y, 2.4187564849853515625e-4f, r);
+    r = std::fmaf(-y, 3.77489497744594108e-8f, r);
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = std::fmaf(ps, z, 8.3321608736e-3f);
+    ps = std::fmaf(ps, z, -1.6666654611e-1f);
+    ps = std::fmaf(ps * z, r, r);                       // sin(r)
+    float pc = 2.443315711809948e-5f;
+    pc = std::fmaf(pc, z, -1.388731625493765e-3f);
+    pc = std::fmaf(pc, z, 4.166664568298827e-2f);
+    pc = std::fmaf(pc * z, z, std::fmaf(-0.5f, z, 1.f));     // cos(r)
+    uint32_t q = j & 7u;                           // octant pair: 0,2,4,6
+    float sv = (q == 2u || q == 6u) ? pc : ps;
+    float cv = (q == 2u || q == 6u) ? ps : pc;
+    if (q == 4u || q == 6u) sv = -sv;
+    if (q == 2u || q == 4u) cv = -cv;
+    s_out = (x < 0.f) ? -sv : sv;
+    c_out = cv;
+}
+inline float bf_sin(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return s;
+}
+inline float bf_cos(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return c;
+}
+inline float bf_tan(float x) {
+    float s, c;
+    bf_sincos(x, s, c);
+    return s / c;
+}
+
+inline float bf_asin_core(float a) {               // a in [0, 1]
+    bool flag = a > 0.5f;
+    float z, x;
+    if (flag) {
+        z = 0.5f * (1.f - a);
+        x = std::sqrt(z);
+    } else {
+        x = a;
+        z = x * x;
+    }
+    float p = 4.2163199048e-2f;
+    p = std::fmaf(p, z, 2.4181311049e-2f);
+    p = std::fmaf(p, z, 4.5470025998e-2f);
+    p = std::fmaf(p, z, 7.4953002686e-2f);
+    p = std::fmaf(p, z, 1.6666752422e-1f);
+    p = std::fmaf(p * z, x, x);
+    if (flag) p = 1.5707963267948966f - (p + p);
+    return p;
+}
+inline float bf_acos(float x) {
+    if (!(x >= -1.f && x <= 1.f)) return std::numeric_limits<float>::quiet_NaN();
+    if (x < -0.5f) return 3.14159265358979323846f - 2.f * bf_asin_core(std::sqrt(0.5f * (1.f + x)));
+    if (x > 0.5f) return 2.f * bf_asin_core(std::sqrt(0.5f * (1.f - x)));
+    float a = bf_asin_core(std::fabs(x));
+    return 1.5707963267948966f - ((x < 0.f) ? -a : a);
+}
+
+inline float bf_erf(float x) {
+    float a = std::fabs(x);
+    if (a != a) return x;
+    float r;
+    if (a < 0.8f) {
+        float z = x * x;
+        float p = -1.128872449e-05f;
+        p = std::fmaf(p, z, 1.169606002e-04f);
+        p = std::fmaf(p, z, -8.529368140e-04f);
+        p = std::fmaf(p, z, 5.223417615e-03f);
+        p = std::fmaf(p, z, -2.686608035e-02f);
+        p = std::fmaf(p, z, 1.128379095e-01f);
+        p = std::fmaf(p, z, -3.761263888e-01f);
+        p = std::fmaf(p, z, 1.128379167e+00f);
+        return p * x;
+    } else if (a < 1.6f) {
+        float t = a - 1.2f;
+        float p = 3.210465009e-04f;
+        p = std::fmaf(p, t, -5.621837162e-03f);
+        p = std::fmaf(p, t, 5.989846125e-03f);
+        p = std::fmaf(p, t, 1.957314866e-02f);
+        p = std::fmaf(p, t, -5.334181702e-02f);
+        p = std::fmaf(p, t, 6.419227034e-03f);
+        p = std::fmaf(p, t, 1.675358269e-01f);
+        p = std::fmaf(p, t, -3.208132755e-01f);
+        p = std::fmaf(p, t, 2.673443467e-01f);
+        p = std::fmaf(p, t, 9.103139784e-01f);
+        r = p;
+    } else if (a < 4.0f) {
+        float t = a - 2.8f;
+        float p = 1.378729715e-09f;
+        p = std::fmaf(p, t, -1.412586080e-07f);
+        p = std::fmaf(p, t, 1.344892106e-06f);
+        p = std::fmaf(p, t, -9.056785943e-06f);
+        p = std::fmaf(p, t, 5.432784894e-05f);
+        p = std::fmaf(p, t, -3.038591482e-04f);
+        p = std::fmaf(p, t, 1.626972312e-03f);
+        p = std::fmaf(p, t, -8.600132565e-03f);
+        p = std::fmaf(p, t, -9.526015505e-01f);
+        p = std::fmaf(p, t, -5.921730786e+00f);
+        p = std::fmaf(p, t, -9.497846531e+00f);
+        r = 1.f - bf_exp(p);
+    } else {
+        r = 1.f;
+    }
+    return (x < 0.f) ? -r : r;
+}
+
+inline float sinf_cr(float x) { return bf_sin(x); }
+inline float cosf_cr(float x) { return bf_cos(x); }
+inline float acosf_cr(float x) { return bf_acos(x); }
+inline float expf_cr(float x) { return bf_exp(x); }
+inline float logf_cr(float x) { return bf_log(x); }
+inline float erff_cr(float x) { return bf_erf(x); }
 inline float mulsign(float a, float b) { return std::signbit(b) ? -a : a; }
 inline float mulsign_neg(float a, float b) { return std::signbit(b) ? a : -a; }
 
@@ -240,7 +435,8 @@ inline void square_to_uniform_disk_concentric(float sx, float sy, float &ox, flo
     float phi = .25f * kPi * rp / r;
     if (q13) phi = .5f * kPi - phi;
     if (is_zero) phi = 0.f;
-    float s = sinf_cr(phi), c = cosf_cr(phi);
+    float s, c;
+    bf_sincos(phi, s, c);
     ox = r * c;
     oy = r * s;
 }
@@ -650,7 +846,7 @@ struct Microfacet {
                 cos_phi = cosf_cr(ang);
                 alpha_2 = au * au;
             } else {
-                float ratio = av / au, tmp = ratio * (float) std::tan((double) ((2.f * kPi) * sy));
+                float ratio = av / au, tmp = ratio * bf_tan((2.f * kPi) * sy);
                 cos_phi = 1.f / std::sqrt(fmadd(tmp, tmp, 1.f));
                 cos_phi = mulsign(cos_phi, std::fabs(sy - .5f) - .25f);
                 sin_phi = cos_phi * tmp;
@@ -1771,6 +1967,20 @@ float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x
     return w;
 }
 float bfo_erfinv(float x) { return erfinv_giles(x); }
+/* op: 0 sin, 1 cos, 2 acos, 3 exp, 4 log, 5 erf, 6 tan */
+void bfo_elementary(int op, uint32_t n, const float *x, float *y) {
+    for (uint32_t i = 0; i < n; ++i) {
+        switch (op) {
+            case 0: y[i] = bf_sin(x[i]); break;
+            case 1: y[i] = bf_cos(x[i]); break;
+            case 2: y[i] = bf_acos(x[i]); break;
+            case 3: y[i] = bf_exp(x[i]); break;
+            case 4: y[i] = bf_log(x[i]); break;
+            case 5: y[i] = bf_erf(x[i]); break;
+            default: y[i] = bf_tan(x[i]); break;
+        }
+    }
+}
 float bfo_rect_area(const bfo_scene *s, uint32_t rect) { return s->sc.rects[rect].area; }
 
 }  // extern "C"

@@ -52,6 +52,8 @@ def load():
     lib.bfo_bsdf_sample.restype = C.c_float
     lib.bfo_erfinv.argtypes = [C.c_float]
     lib.bfo_erfinv.restype = C.c_float
+    lib.bfo_elementary.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.bfo_elementary.restype = None
     lib.bfo_rect_area.argtypes = [vp, C.c_uint32]
     lib.bfo_rect_area.restype = C.c_float
     _lib = lib

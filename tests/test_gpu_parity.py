@@ -258,3 +258,25 @@ def test_full_size_properties_c2(hiplib):
     h2, _, st2 = g.render(lp)
     assert st2.n_rays_closest == st.n_rays_closest and st2.n_rays_shadow == st.n_rays_shadow
     assert np.allclose(h2, h, rtol=1e-4, atol=1e-2)
+
+
+def test_elementary_functions_bit_equal(hiplib):
+    """The fp32 sin/cos/acos/exp/log/erf/tan specification evaluates to the same bits on the
+    device as in the oracle (the oracle's accuracy against libm is checked on the CPU in
+    test_oracle_known_answers.py::test_elementary_functions)."""
+    from tests import oracle_lib
+    olib = oracle_lib.load()
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.inf, -np.inf, np.nan, 1e-30, 88.8, -87.2, 4.0, 0.8, 1.6], f32)
+    ranges = {0: (-4000, 4000), 1: (-4000, 4000), 2: (-1, 1), 3: (-90, 90), 4: (0, 1e6), 5: (-5, 5), 6: (-1.55, 1.55)}
+    for op, (lo, hi) in ranges.items():
+        x = np.concatenate([rng.uniform(lo, hi, n).astype(f32), rng.uniform(-1, 1, n).astype(f32), special])
+        x = np.ascontiguousarray(x)
+        yo = np.empty_like(x)
+        yg = np.empty_like(x)
+        olib.bfo_elementary(op, x.size, x.ctypes.data, yo.ctypes.data)
+        capi.check(hiplib, hiplib.bf_eval_elementary(op, x.size, x.ctypes.data, yg.ctypes.data), "bf_eval_elementary")
+        nan_o, nan_g = np.isnan(yo), np.isnan(yg)
+        assert np.array_equal(nan_o, nan_g), op
+        assert np.array_equal(yo[~nan_o].view(np.uint32), yg[~nan_g].view(np.uint32)), op

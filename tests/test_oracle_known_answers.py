@@ -256,3 +256,54 @@ def test_erfinv(oracle):
     from scipy.special import erfinv
     for x in np.linspace(-0.999, 0.999, 41):
         assert np.isclose(oracle.bfo_erfinv(f32(x)), erfinv(x), rtol=2e-6, atol=1e-6)
+
+
+def _ulp_err(got, want64):
+    want32 = want64.astype(np.float32)
+    ulp = np.spacing(np.abs(want32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want64) / ulp
+
+
+def test_elementary_functions(oracle):
+    """The fp32 elementary-function specification (bf_exp, bf_log, bf_sincos, bf_acos,
+    bf_erf, bf_tan) stays within a few ulp of libm, which is what the reference's
+    scalar variants call (enoki scalar fallbacks -> std::sin etc.)."""
+    from scipy.special import erf
+    rng = np.random.default_rng(7)
+
+    def run(op, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        oracle.bfo_elementary(op, x.size, x.ctypes.data, y.ctypes.data)
+        return x, y
+
+    n = 400000
+    # sin / cos over the range the path uses (phases up to a few thousand radians)
+    for lo, hi in ((-8.0, 8.0), (-4000.0, 4000.0)):
+        x, y = run(0, rng.uniform(lo, hi, n))
+        err = np.abs(y.astype(np.float64) - np.sin(x.astype(np.float64)))
+        assert err.max() < 2.5e-7, (lo, hi, err.max())
+        x, y = run(1, rng.uniform(lo, hi, n))
+        err = np.abs(y.astype(np.float64) - np.cos(x.astype(np.float64)))
+        assert err.max() < 2.5e-7, (lo, hi, err.max())
+    x, y = run(0, rng.uniform(-0.7, 0.7, n))
+    assert _ulp_err(y, np.sin(x.astype(np.float64))).max() < 2.5
+    # acos
+    x, y = run(2, np.concatenate([rng.uniform(-1, 1, n), [-1.0, 1.0, 0.0, 0.5, -0.5]]))
+    assert _ulp_err(y, np.arccos(x.astype(np.float64))).max() < 3.0
+    # exp
+    x, y = run(3, np.concatenate([rng.uniform(-86.9, 88.0, n), rng.uniform(-2, 2, n)]))
+    assert _ulp_err(y, np.exp(x.astype(np.float64))).max() < 2.5
+    x, y = run(3, [-100.0, -87.5, 89.0, 0.0])
+    assert y[0] == 0 and y[1] == 0 and np.isinf(y[2]) and y[3] == 1.0
+    # log
+    x, y = run(4, np.concatenate([np.exp(rng.uniform(-80, 80, n)), rng.uniform(0.5, 2.0, n)]))
+    assert _ulp_err(y, np.log(x.astype(np.float64))).max() < 2.5
+    x, y = run(4, [0.0, -1.0, 1.0])
+    assert np.isneginf(y[0]) and np.isnan(y[1]) and y[2] == 0.0
+    # erf
+    x, y = run(5, np.concatenate([rng.uniform(-5, 5, n), rng.uniform(-0.1, 0.1, n)]))
+    assert _ulp_err(y, erf(x.astype(np.float64))).max() < 4.0
+    # tan (Beckmann phi warp argument range)
+    x, y = run(6, rng.uniform(-1.5, 1.5, n))
+    assert _ulp_err(y, np.tan(x.astype(np.float64))).max() < 4.0
