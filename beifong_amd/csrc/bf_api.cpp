@@ -467,7 +467,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
     static const int shade_waves = [] {
         const char *e = getenv("BF_SHADE_WAVES");
-        int w = e ? atoi(e) : 2;
+        int w = e ? atoi(e) : 3;
         return w < 1 ? 1 : (w > 4 ? 4 : w);
     }();
     // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs

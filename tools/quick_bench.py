@@ -12,6 +12,8 @@ elif scene_name == "car":
     sd, lp = scenes.car_radar(n_tris=1_000_000, n_paths=n_paths)
 else:
     sd, lp = scenes.multi_mesh_radar(n_paths=n_paths)
+if os.environ.get('MAXDEPTH'):
+    lp.max_depth = int(os.environ['MAXDEPTH'])
 g = capi.Scene(sd)
 for name, flags in (("wavefront", 0), ("megakernel", capi.BF_FLAG_MEGAKERNEL)):
     if os.environ.get("ONLY") and os.environ["ONLY"] != name:
