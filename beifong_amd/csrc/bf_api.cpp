@@ -29,7 +29,7 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
                                    hipStream_t stream, int waves);
 extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
-                                   hipStream_t stream);
+                                   hipStream_t stream, int waves);
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
                                       hipStream_t stream);
@@ -306,8 +306,19 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sen.shutter_open_time = desc->sensor.shutter_open_time;
 
     // BVH over all mesh triangles; triangles stored in leaf order
+    // rays start on scene surfaces, sensors or emitters: bound |origin| for the builder's padding
+    float origin_scale = 0.f;
+    auto grow_scale = [&](const float *m /* 3x4 */, float ex, float ey) {
+        for (int r = 0; r < 3; ++r)
+            origin_scale = std::max(origin_scale, std::fabs(m[4 * r + 3]) + std::fabs(m[4 * r + 0]) * ex + std::fabs(m[4 * r + 1]) * ey);
+    };
+    for (const auto &r : rects) grow_scale(r.to_world, 1.f, 1.f);
+    for (const auto &e : emitters) grow_scale(e.to_world, 0.f, 0.f);
+    grow_scale(sen.to_world, 0.f, 0.f);
     bf::BVH bvh;
-    bf::build_bvh(btris, bvh);
+    bf::build_bvh(btris, bvh, origin_scale);
+    bf::BVH4 bvh4;
+    bf::collapse_bvh4(bvh, bvh4);
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
     if (any_normals) nrm_data.resize(3 * btris.size());
     for (size_t slot = 0; slot < btris.size(); ++slot) {
@@ -332,8 +343,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             }
         }
     }
-    std::vector<float4> node_data(4 * bvh.nodes.size());
-    if (!bvh.nodes.empty()) std::memcpy(node_data.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(bf::Node));
+    std::vector<float4> node_data(8 * bvh4.nodes.size());
+    if (!bvh4.nodes.empty()) std::memcpy(node_data.data(), bvh4.nodes.data(), bvh4.nodes.size() * sizeof(bf::Node4));
     std::vector<bf_material> mats(desc->materials, desc->materials + desc->n_materials);
 
     uint64_t bytes = 0;
@@ -355,8 +366,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->d.n_rects = (uint32_t) rects.size();
     sc->d.n_emitters = (uint32_t) emitters.size();
     for (const auto &e : emitters) sc->emitter_types.push_back(e.type);
-    sc->d.n_nodes = (uint32_t) bvh.nodes.size();
-    sc->d.root = bvh.root_child;
+    sc->d.n_nodes = (uint32_t) bvh4.nodes.size();
+    sc->d.root = bvh4.root_child;
     sc->d.c = desc->physics.c;
     sc->d.lambda_min = desc->physics.lambda_min_nm;
     sc->d.lambda_max = desc->physics.lambda_max_nm;
@@ -375,7 +386,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     inf.n_rects = sc->d.n_rects;
     inf.n_triangles = sc->d.n_tris;
     inf.n_bvh_nodes = sc->d.n_nodes;
-    inf.node_bytes = (uint32_t) sizeof(bf::Node);
+    inf.node_bytes = (uint32_t) sizeof(bf::Node4);
     inf.tri_bytes = 48;
     inf.device_bytes = bytes;
     for (int k = 0; k < 3; ++k) {
@@ -440,7 +451,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
 
 static uint32_t wf_tail_threshold() {
     const char *e = getenv("BF_WF_TAIL");
-    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 17);
+    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 19);
 }
 
 // Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
@@ -470,12 +481,17 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         int w = e ? atoi(e) : 3;
         return w < 1 ? 1 : (w > 4 ? 4 : w);
     }();
+    static const int trace_waves = [] {
+        const char *e = getenv("BF_TRACE_WAVES");
+        int w = e ? atoi(e) : 6;
+        return w < 4 ? 4 : (w > 8 ? 8 : (w == 7 ? 6 : w));
+    }();
     // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
     // 8 workgroups per CU (16 KiB LDS stack each, <= 64 VGPRs)
     const unsigned batches_per_block = bfd::kBlock / 64;
     const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
     const unsigned grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), max_blocks));
-    const unsigned grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * bfd::kTraceBlocksPerCU, max_blocks));
+    const unsigned grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) trace_waves, max_blocks));
     const uint32_t tail_max = wf_tail_threshold();
     volatile uint32_t *hq = scene->wf_host;      // [0] = n_live[it]
     // per-kernel timing (stats renders only): events bracket every launch
@@ -520,7 +536,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_live + it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(scene->wf_event, stream));
         HIP_TRY(tic(0));
-        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream));
+        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream, trace_waves));
         HIP_TRY(toc());
         HIP_TRY(hipEventSynchronize(scene->wf_event));
         uint32_t n_live = hq[0];

@@ -45,15 +45,16 @@ struct Builder {
     std::vector<uint32_t> &order;
     std::vector<Node> &nodes;
     uint32_t max_depth = 0;
+    float abs_pad = 0.f;          // origin-rounding allowance (see bf_bvh.h)
 
     Builder(const std::vector<BuildTri> &t, BVH &out) : tris(t), order(out.order), nodes(out.nodes) {}
 
-    static void pad(Box &b) {
+    void pad(Box &b) const {
         // fp32 hit distances can land a hair outside the exact box: widen by a
         // relative epsilon of the box scale (and of its distance from the origin)
         float m = 0.f;
         for (int i = 0; i < 3; ++i) m = std::max({m, b.hi[i] - b.lo[i], std::fabs(b.lo[i]), std::fabs(b.hi[i])});
-        float e = 2e-6f * m + 1e-30f;
+        float e = 2e-6f * m + abs_pad + 1e-30f;
         for (int i = 0; i < 3; ++i) {
             b.lo[i] -= e;
             b.hi[i] += e;
@@ -170,7 +171,7 @@ struct Builder {
 
 }  // namespace
 
-void build_bvh(const std::vector<BuildTri> &tris, BVH &out) {
+void build_bvh(const std::vector<BuildTri> &tris, BVH &out, float origin_scale) {
     out.nodes.clear();
     out.order.resize(tris.size());
     out.max_depth = 0;
@@ -197,13 +198,109 @@ void build_bvh(const std::vector<BuildTri> &tris, BVH &out) {
         all.grow(x);
     }
     out.nodes.reserve(n);
+    float scale = origin_scale;
+    for (int k = 0; k < 3; ++k) scale = std::max({scale, std::fabs(all.lo[k]), std::fabs(all.hi[k])});
+    b.abs_pad = 2e-7f * scale;
     out.root_child = b.build(0, (uint32_t) n, all, 0);
-    Builder::pad(all);
+    b.pad(all);
     for (int i = 0; i < 3; ++i) {
         out.lo[i] = all.lo[i];
         out.hi[i] = all.hi[i];
     }
     out.max_depth = b.max_depth;
+}
+
+namespace {
+
+struct ChildRef {
+    int32_t ref;        // BVH2 child encoding
+    float lo[3], hi[3];
+    float area() const {
+        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    }
+};
+
+void children_of(const Node &n, ChildRef out[2]) {
+    for (int k = 0; k < 3; ++k) {
+        out[0].lo[k] = n.c0lo[k];
+        out[0].hi[k] = n.c0hi[k];
+        out[1].lo[k] = n.c1lo[k];
+        out[1].hi[k] = n.c1hi[k];
+    }
+    out[0].ref = n.child[0];
+    out[1].ref = n.child[1];
+}
+
+struct Collapser {
+    const BVH &in;
+    BVH4 &out;
+    int width;
+    // returns the stack need of the subtree; writes the node at index `self`
+    uint32_t emit(int32_t node2, uint32_t self, uint32_t depth) {
+        out.max_depth = std::max(out.max_depth, depth);
+        ChildRef c[4];
+        int n = 2;
+        children_of(in.nodes[(size_t) node2], c);
+        while (n < width) {
+            int best = -1;
+            float best_area = -1.f;
+            for (int i = 0; i < n; ++i)
+                if (c[i].ref >= 0 && c[i].area() > best_area) {
+                    best_area = c[i].area();
+                    best = i;
+                }
+            if (best < 0) break;
+            ChildRef g[2];
+            children_of(in.nodes[(size_t) c[best].ref], g);
+            c[best] = g[0];
+            c[n++] = g[1];
+        }
+        int32_t refs[4];
+        uint32_t need_below = 0;
+        for (int i = 0; i < n; ++i) {
+            if (c[i].ref >= 0) {
+                uint32_t idx = (uint32_t) out.nodes.size();
+                out.nodes.emplace_back();
+                refs[i] = (int32_t) idx;
+                need_below = std::max(need_below, emit(c[i].ref, idx, depth + 1));
+            } else {
+                refs[i] = c[i].ref;
+            }
+        }
+        Node4 &w = out.nodes[self];
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int i = 0; i < 4; ++i) {
+            bool used = i < n;
+            w.lox[i] = used ? c[i].lo[0] : inf;
+            w.loy[i] = used ? c[i].lo[1] : inf;
+            w.loz[i] = used ? c[i].lo[2] : inf;
+            w.hix[i] = used ? c[i].hi[0] : -inf;
+            w.hiy[i] = used ? c[i].hi[1] : -inf;
+            w.hiz[i] = used ? c[i].hi[2] : -inf;
+            w.child[i] = used ? refs[i] : kEmptyChild;
+            w.pad[i] = 0;
+        }
+        return (uint32_t) (n - 1) + need_below;
+    }
+};
+
+}  // namespace
+
+void collapse_bvh4(const BVH &in, BVH4 &out) {
+    for (int width = 4; width >= 2; width -= 2) {
+        out.nodes.clear();
+        out.root_child = in.root_child;
+        out.stack_need = 0;
+        out.max_depth = 0;
+        if (in.nodes.empty() || in.root_child < 0) return;
+        out.nodes.reserve(in.nodes.size() / 2 + 1);
+        out.nodes.emplace_back();
+        Collapser c{in, out, width};
+        out.root_child = 0;
+        out.stack_need = c.emit(in.root_child, 0, 1);
+        if (out.stack_need <= (uint32_t) kMaxDepth) return;      // else: stay two-wide (need <= binary depth)
+    }
 }
 
 }  // namespace bf

@@ -43,9 +43,40 @@ struct BVH {
     uint32_t max_depth;
 };
 
+// 128-byte four-wide node (one L2 line), read by the kernels as eight float4:
+//   q0..q2 = lo.x[4], lo.y[4], lo.z[4];  q3..q5 = hi.x[4], hi.y[4], hi.z[4]
+//   q6     = child[4] as int bits (same encoding as Node::child)
+//   q7     = unused
+// Unused child slots hold an inverted box (lo = +inf, hi = -inf), which no ray
+// segment can overlap, and child = kEmptyChild.
+struct alignas(16) Node4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "wide node must be 128 bytes");
+constexpr int32_t kEmptyChild = INT32_MIN;
+
+struct BVH4 {
+    std::vector<Node4> nodes;         // nodes[0] is the root if root_child >= 0
+    int32_t root_child;               // >= 0: node index, < 0: the whole mesh is one leaf
+    uint32_t stack_need;              // worst-case traversal stack entries (<= kMaxDepth by construction)
+    uint32_t max_depth;
+};
+
+// Collapse the binary tree into four-wide nodes: a node adopts its grandchildren
+// (largest surface area first) until it has four children or only leaves.  Half
+// the dependent node fetches per ray.  If the worst-case traversal stack
+// (sum over levels of children - 1) would exceed kMaxDepth, nodes stay two-wide.
+void collapse_bvh4(const BVH &in, BVH4 &out);
+
 // Binned SAH build (16 bins, leaf <= kMaxLeaf).  Boxes are padded by a few
 // ulps so that a fp32 Moeller-Trumbore hit distance never falls outside the
-// box that holds its triangle.
-void build_bvh(const std::vector<BuildTri> &tris, BVH &out);
+// box that holds its triangle.  `origin_scale`: largest |coordinate| a ray origin
+// can have (scene geometry, sensors, emitters); the kernels' slab test folds the
+// origin into one fma per plane (t = lo * (1/d) - o * (1/d)), whose rounding
+// shifts a plane by up to 2^-24 * |o|, so boxes are also padded by
+// 2e-7 * origin_scale to keep the test conservative.
+void build_bvh(const std::vector<BuildTri> &tris, BVH &out, float origin_scale = 0.f);
 
 }  // namespace bf

@@ -85,9 +85,103 @@ BF_DEV bool slab_fma(float lox, float loy, float loz, float hix, float hiy, floa
     return tn <= tf * 1.0000004f;
 }
 
+// ---------------------------------------------------------------------------
+// Four-wide BVH traversal step (bf_bvh.h: Node4, 128 B = one L2 line).
+// ---------------------------------------------------------------------------
+constexpr int kNoNode = INT32_MIN;          // "no node": also Node4's empty-child marker
+constexpr uint32_t kMissKey = 0x7f000000u;  // sort key of a child the ray misses
+
+// 1/d with zero components mapped to +-1e30 instead of +-inf, so that the folded form
+// lo * (1/d) - o * (1/d) never meets inf - inf or 0 * inf (|o|, |lo| < 3e8).
+BF_DEV void ray_inverse(V3 o, V3 d, V3 &id, V3 &oid) {
+    id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    id.x = __builtin_fminf(__builtin_fmaxf(id.x, -1.0e30f), 1.0e30f);
+    id.y = __builtin_fminf(__builtin_fmaxf(id.y, -1.0e30f), 1.0e30f);
+    id.z = __builtin_fminf(__builtin_fmaxf(id.z, -1.0e30f), 1.0e30f);
+    oid = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+}
+
+// Entry distance and child slot packed into one sortable word (distances are >= mint >= 0,
+// so their bit patterns order like the values; the two low mantissa bits carry the slot —
+// the order of near-equal children is only a traversal heuristic, never a result).
+BF_DEV uint32_t child_key(bool hit, float tn, uint32_t slot) {
+    uint32_t b = min(__float_as_uint(tn), kMissKey - 4u);
+    return hit ? ((b & ~3u) | slot) : (kMissKey | slot);
+}
+BF_DEV int pick_child(float4 ch, uint32_t key) {
+    uint32_t i = key & 3u;
+    return __float_as_int(i == 0u ? ch.x : (i == 1u ? ch.y : (i == 2u ? ch.z : ch.w)));
+}
+
+// Per-lane traversal stack: column `tid` of a lane-strided LDS array (entry k at
+// lds[k * kBlock]: bank = tid mod 32, conflict-free), optionally continued in a
+// per-thread HBM column (entry k at spill[k * spill_stride]).  Capacity
+// n_lds + spill entries >= 32 > BVH4::stack_need (bf_bvh.h).
+template <int N_LDS, bool SPILL>
+struct LaneStack {
+    int *lds;
+    int *spill;
+    uint32_t spill_stride;
+    int sp;
+    BF_DEV void push(int v) {
+        if (!SPILL || sp < N_LDS)
+            lds[sp * kBlock] = v;
+        else
+            spill[(size_t) (sp - N_LDS) * spill_stride] = v;
+        ++sp;
+    }
+    BF_DEV int pop() {
+        --sp;
+        return (!SPILL || sp < N_LDS) ? lds[sp * kBlock] : spill[(size_t) (sp - N_LDS) * spill_stride];
+    }
+    BF_DEV int pop_or_none() { return sp ? pop() : kNoNode; }
+};
+
+// Visit internal node `node`: test its (up to) four child boxes against the ray segment
+// [mint, tmax], push the hit children far-to-near and return the nearest one (or the next
+// stack entry, or kNoNode when the traversal is finished).
+template <class Stack>
+BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, float mint, float tmax, Stack &st) {
+    const float4 *np = nodes + 8u * (uint32_t) node;
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    float t0, t1, t2, t3;
+    const bool h0 = slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, mint, tmax, t0);
+    const bool h1 = slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, mint, tmax, t1);
+    const bool h2 = slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, mint, tmax, t2) && __float_as_int(ch.z) != kNoNode;
+    const bool h3 = slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, mint, tmax, t3) && __float_as_int(ch.w) != kNoNode;
+    const uint32_t k0 = child_key(h0, t0, 0u), k1 = child_key(h1, t1, 1u), k2 = child_key(h2, t2, 2u), k3 = child_key(h3, t3, 3u);
+    // 5-comparator sorting network
+    const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
+    const uint32_t lo = min(a, c), x = max(a, c), y = min(b, d), hi = max(b, d);
+    const uint32_t m1 = min(x, y), m2 = max(x, y);
+    if (hi < kMissKey) st.push(pick_child(ch, hi));
+    if (m2 < kMissKey) st.push(pick_child(ch, m2));
+    if (m1 < kMissKey) st.push(pick_child(ch, m1));
+    if (lo < kMissKey) return pick_child(ch, lo);
+    return st.pop_or_none();
+}
+
+// all triangles of one leaf; returns true when an any-hit query is decided
+template <bool STATS>
+BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, uint32_t &n_tris) {
+    const uint32_t enc = ~(uint32_t) node;
+    const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const float4 *tp = sc.tris + 3u * (first + i);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) ++n_tris;
+        float t, u, v;
+        if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
+            if (any) return true;
+            consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
+        }
+    }
+    return false;
+}
+
 // Scene::ray_intersect / ray_test — src/librender/scene.cpp:129-178.
 // `stack` points at this lane's column of the workgroup's LDS stack
-// (entry k at stack[k * kBlock]).
+// (entry k at stack[k * kBlock], kStackDepth entries).
 template <bool ANY, bool STATS>
 BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
                      uint32_t &n_tris) {
@@ -106,53 +200,18 @@ BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *
     }
     if (sc.n_tris == 0) return best.t != BF_INF;
 
-    V3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    V3 id, oid;
+    ray_inverse(o, d, id, oid);
+    LaneStack<kStackDepth, false> st = {stack, nullptr, 0u, 0};
     int node = sc.root;
-    int sp = 0;
-    while (true) {
+    while (node != kNoNode) {
         if (node >= 0) {
-            const float4 *np = sc.nodes + 4 * (size_t) node;
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             if (STATS) ++n_nodes;
-            float tmax = ANY ? maxt : __builtin_fminf(maxt, best.t);
-            float tn0, tn1;
-            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn0);
-            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn1);
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                if (tn1 < tn0) {
-                    int tmp = c0;
-                    c0 = c1;
-                    c1 = tmp;
-                }
-                stack[sp * kBlock] = c1;
-                ++sp;
-                node = c0;
-                continue;
-            } else if (h0) {
-                node = c0;
-                continue;
-            } else if (h1) {
-                node = c1;
-                continue;
-            }
+            node = node4_step(sc.nodes, node, id, oid, mint, ANY ? maxt : __builtin_fminf(maxt, best.t), st);
         } else {
-            uint32_t enc = ~(uint32_t) node;
-            uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const float4 *tp = sc.tris + 3 * (size_t) (first + i);
-                float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) ++n_tris;
-                float t, u, v;
-                if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
-                    if (ANY) return true;
-                    consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
-                }
-            }
+            if (leaf_intersect<STATS>(sc, node, ANY, o, d, mint, maxt, best, n_tris)) return true;
+            node = st.pop_or_none();
         }
-        if (sp == 0) break;
-        --sp;
-        node = stack[sp * kBlock];
     }
     return best.t != BF_INF;
 }

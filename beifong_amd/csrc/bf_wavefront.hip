@@ -65,12 +65,15 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     }
     if (sc.n_tris == 0) return false;
     if (sc.root < 0) return true;                 // the whole mesh is one leaf
-    const float4 *np = sc.nodes + 4u * (uint32_t) sc.root;
-    float4 q0 = np[0], q1 = np[1], q2 = np[2];
-    V3 id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    const float4 *np = sc.nodes + 8u * (uint32_t) sc.root;
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    V3 id, oid;
+    ray_inverse(o, d, id, oid);
     float tmax = any ? maxt : __builtin_fminf(maxt, best.t), tn;
-    return slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, id, mint, tmax, tn) ||
-           slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, id, mint, tmax, tn);
+    return slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, mint, tmax, tn) ||
+           slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, mint, tmax, tn) ||
+           (__float_as_int(ch.z) != kNoNode && slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, mint, tmax, tn)) ||
+           (__float_as_int(ch.w) != kNoNode && slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, mint, tmax, tn));
 }
 
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
@@ -247,10 +250,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 constexpr int kRefill = 44;
 constexpr int kStragglers = 12;
 constexpr int kLdsStack = 16;
-constexpr int kNoNode = INT32_MIN;
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t it) {
+template <bool STATS, int W>
+__global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t it) {
     __shared__ int s_stack[kLdsStack * kBlock];
     int *stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
     uint32_t c_nodes = 0, c_tris = 0;
     const uint32_t n_threads = gridDim.x * kBlock;
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    int *spill = wf.spill + (blockIdx.x * kBlock + threadIdx.x);    // entry k at spill[k * n_threads]
+    LaneStack<kLdsStack, true> st = {stack, wf.spill + (blockIdx.x * kBlock + threadIdx.x), n_threads, 0};
     const uint32_t n_batches = wf.n_slots >> 6;
     const uint32_t per = (n_batches + n_waves - 1) / n_waves;
     const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
@@ -275,21 +277,10 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
     best.u = best.v = 0.f;
     best.prim = 0;
     best.slot = 0;
-    int node = kNoNode, sp = 0;
+    int node = kNoNode;
     bool found = false;      // any-hit result
     uint32_t guard = 0;
 
-    auto push = [&](int v) {
-        if (sp < kLdsStack)
-            stack[sp * kBlock] = v;
-        else
-            spill[(size_t) (sp - kLdsStack) * n_threads] = v;
-        ++sp;
-    };
-    auto pop = [&]() -> int {
-        --sp;
-        return sp < kLdsStack ? stack[sp * kBlock] : spill[(size_t) (sp - kLdsStack) * n_threads];
-    };
     auto work_left = [&]() -> bool { return phase_shadow || !cursor_empty(cursor); };
 
     while (true) {
@@ -334,14 +325,9 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                         best.slot = __float_as_int(hq.w);
                         best.prim = wf.hit_prim[slot];
                     }
-                    // a zero direction component gives +-inf; clamp so that 0 * inf never appears in the fma form
-                    id = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-                    id.x = __builtin_fminf(__builtin_fmaxf(id.x, -3.0e38f), 3.0e38f);
-                    id.y = __builtin_fminf(__builtin_fmaxf(id.y, -3.0e38f), 3.0e38f);
-                    id.z = __builtin_fminf(__builtin_fmaxf(id.z, -3.0e38f), 3.0e38f);
-                    oid = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+                    ray_inverse(o, d, id, oid);
                     node = sc.root;
-                    sp = 0;
+                    st.sp = 0;
                 }
                 served += got;
                 want -= got;
@@ -368,49 +354,14 @@ __global__ __launch_bounds__(kBlock, 8) void wf_trace(DScene sc, WF wf, uint32_t
                 // progress guarantee: only postpone the stragglers if some lane has a leaf to intersect
                 if (__popcll(at_node) < kStragglers && __ballot(has && node < 0 && node != kNoNode)) break;
                 if (has && node >= 0) {
-                    const float4 *np = sc.nodes + 4u * (uint32_t) node;
-                    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     if (STATS) ++c_nodes;
-                    float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
-                    float tn0, tn1;
-                    bool h0 = slab_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, id, oid, mint, tmax, tn0);
-                    bool h1 = slab_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, id, oid, mint, tmax, tn1);
-                    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                    if (h0 && h1) {
-                        if (tn1 < tn0) {
-                            int tmp = c0;
-                            c0 = c1;
-                            c1 = tmp;
-                        }
-                        push(c1);
-                        node = c0;
-                    } else if (h0) {
-                        node = c0;
-                    } else if (h1) {
-                        node = c1;
-                    } else {
-                        node = sp ? pop() : kNoNode;
-                    }
+                    node = node4_step(sc.nodes, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
                 }
             }
             // (b) intersect the postponed leaves together
             if (has && node < 0 && node != kNoNode) {
-                uint32_t enc = ~(uint32_t) node;
-                uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 *tp = sc.tris + 3u * (first + i);
-                    float4 a = tp[0], b = tp[1], c = tp[2];
-                    if (STATS) ++c_tris;
-                    float t, u, v;
-                    if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
-                        if (any) {
-                            found = true;
-                            break;
-                        }
-                        consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
-                    }
-                }
-                node = ((any && found) || sp == 0) ? kNoNode : pop();
+                found = leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, c_tris);
+                node = found ? kNoNode : st.pop_or_none();
             }
             // (c) retire finished rays
             if (has && node == kNoNode) {
@@ -470,10 +421,21 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 }
 
 extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
-                                   hipStream_t stream) {
-    if (stats)
-        hipLaunchKernelGGL(bfd::wf_trace<true>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);
-    else
-        hipLaunchKernelGGL(bfd::wf_trace<false>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);
+                                   hipStream_t stream, int waves) {
+#define BF_TRACE_LAUNCH(W)                                                                                          \
+    if (stats)                                                                                                      \
+        hipLaunchKernelGGL((bfd::wf_trace<true, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);        \
+    else                                                                                                            \
+        hipLaunchKernelGGL((bfd::wf_trace<false, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
+    if (waves >= 8) {
+        BF_TRACE_LAUNCH(8);
+    } else if (waves >= 6) {
+        BF_TRACE_LAUNCH(6);
+    } else if (waves == 5) {
+        BF_TRACE_LAUNCH(5);
+    } else {
+        BF_TRACE_LAUNCH(4);
+    }
+#undef BF_TRACE_LAUNCH
     return hipGetLastError();
 }
