@@ -155,6 +155,17 @@ def main():
     else:
         rays_all, paths_all = float(rays), float(paths)
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+    # committed summary of the separate rocprofv3 --pmc passes over this workload supplies it
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt.get("kernel") == "wf_trace" and args.paths == (1 << 24) and args.tris == 200_000:
+            traffic = float(pt["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
+
     out = None
     if rank == 0:
         mrays = rays_all / dt / 1e6
@@ -198,7 +209,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "HBM bytes per wf_trace launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
+                                "profiles/r01_final_pmc.txt; algorithmic bytes per launch = %.3e" % (b_ray_tr * rays_per_launch),
                 "measured": "HIP events around every launch, instrumented serial pass over the timed region's steps",
                 "bytes_per_ray": round(b_ray_tr, 1),
                 "nodes_per_ray": round(v_n_tr, 2),
