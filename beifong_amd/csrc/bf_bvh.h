@@ -5,8 +5,9 @@
 // src/librender/scene_native.inl:3-10) or embree/OptiX.  Closest-hit results do
 // not depend on the accelerator (ties are resolved by primitive index, see
 // bf_kernels.hip), so the MI355X build uses a structure that suits wave64
-// pointer chasing instead: a binned-SAH BVH2 flattened into 64-byte nodes that
-// hold BOTH child boxes, so one 64-B fetch decides two subtrees.
+// pointer chasing instead: a binned-SAH binary BVH (64-byte nodes holding BOTH
+// child boxes), collapsed into four-wide 128-byte nodes (Node4) for the device,
+// so one L2-line fetch decides four subtrees.
 #pragma once
 #include <cstdint>
 #include <vector>

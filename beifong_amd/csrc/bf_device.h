@@ -2,7 +2,7 @@
 // kernels (bf_kernels.hip).  Everything is read-only during a render.
 //
 // HBM layout (DESIGN.md "Data layout"):
-//   nodes   : bf::Node[n_nodes]      64 B each, 16-B aligned, both child boxes
+//   nodes   : bf::Node4[n_nodes]     128 B each, four child boxes (SoA) + four child references
 //   tris    : float4[3 * n_tris]     48 B per triangle, BVH leaf order:
 //               q0 = (p0.xyz, bits(global prim index))
 //               q1 = (p1.xyz, bits(shape index))

@@ -5,7 +5,7 @@
 // from a device-wide queue head (wave-aggregated with __ballot/__popcll, one
 // returning atomic per refill) and starts over, so all 64 lanes enter every
 // BVH traversal.  Traversal keeps a per-lane stack in LDS (lane-strided, so a
-// wave's push/pop is bank-conflict free), reads 64-B two-child nodes and 48-B
+// wave's push/pop is bank-conflict free), reads 128-B four-child nodes and 48-B
 // triangles from HBM, and path-length returns are binned into an
 // LDS-privatised histogram that is flushed with one global atomic per
 // non-empty bin per workgroup.  No MFMA: the path is pointer chasing.

@@ -40,7 +40,7 @@ BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, uint32_t batc
 
 // Early resolution of a freshly spawned ray, done by the shading lane itself
 // while the whole wave is active: the analytic rectangles (rectangle.cpp:229-263)
-// are tested here, and if the ray misses both child boxes of the BVH root no
+// are tested here, and if the ray misses all child boxes of the BVH root no
 // triangle can be hit, so the query is already answered.  Only rays that enter
 // the mesh BVH are handed to wf_trace (with the best rectangle hit so far as
 // their starting point), which keeps that kernel's waves filled with comparable
