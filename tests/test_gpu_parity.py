@@ -280,3 +280,53 @@ def test_elementary_functions_bit_equal(hiplib):
         nan_o, nan_g = np.isnan(yo), np.isnan(yg)
         assert np.array_equal(nan_o, nan_g), op
         assert np.array_equal(yo[~nan_o].view(np.uint32), yg[~nan_g].view(np.uint32)), op
+
+
+def test_full_size_c3_car_bit_exact(hiplib):
+    """BASELINE configs[2] at full size: 1 M-triangle car body with vertex normals + ground, 1024 range
+    bins, 2^20 primary rays — every path's radiance / length / ray count against the oracle."""
+    sd, lp = scenes.car_radar(n_tris=1_000_000, n_paths=1 << 20, bins=1024, dr=0.03)
+    hg, ho, st = _render_compare(sd, lp)
+    assert (hg[5:] != 0).sum() > 50
+
+
+def test_full_size_c4_multi_mesh_sharded(hiplib):
+    """BASELINE configs[3] geometry (bus 200 k + car 1 M + motorbike 300 k triangles): one shard of the
+    8-way sample split against the oracle, and the 8 shards' histograms sum to the unsharded render."""
+    n = 1 << 19
+    sd, lp = scenes.multi_mesh_radar(n_paths=n)
+    shard = capi.make_launch(lp.mode, n // 8, seed=lp.seed, path_offset=3 * (n // 8), bins=lp.bins, bin_width=lp.bin_width,
+                             color_mode=lp.color_mode)
+    _render_compare(sd, shard)
+    g = capi.Scene(sd)
+    h_all, _, st_all = g.render(lp)
+    acc = np.zeros_like(h_all, dtype=np.float64)
+    rays = 0
+    for k in range(8):
+        lpk = capi.make_launch(lp.mode, n // 8, seed=lp.seed, path_offset=k * (n // 8), bins=lp.bins, bin_width=lp.bin_width,
+                               color_mode=lp.color_mode)
+        h, _, st = g.render(lpk)
+        acc += h
+        rays += st.n_rays_closest + st.n_rays_shadow
+    assert rays == st_all.n_rays_closest + st_all.n_rays_shadow
+    assert np.allclose(acc, h_all, rtol=1e-4, atol=1e-2)
+
+
+def test_concurrent_renders_on_two_streams(hiplib):
+    """bench.py issues consecutive steps on two HIP streams (one bf_scene handle each) so that one
+    render's deep-path tail overlaps the next one's head: results must not depend on that."""
+    torch = pytest.importorskip("torch")
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 18)
+    handles = [capi.Scene(sd), capi.Scene(sd)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    nch = handles[0].channels(lp)
+    ref, _, _ = handles[0].render(lp)
+    hists = [torch.zeros(nch, device="cuda") for _ in range(6)]
+    for k, h in enumerate(hists):
+        j = k & 1
+        with torch.cuda.stream(streams[j]):
+            h.zero_()
+            handles[j].render_device(lp, h.data_ptr(), stream=streams[j].cuda_stream)
+    torch.cuda.synchronize()
+    for h in hists:
+        assert np.allclose(h.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
