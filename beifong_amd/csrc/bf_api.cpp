@@ -108,6 +108,20 @@ struct bf_scene {
     mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only)
     mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render
     mutable uint32_t wf_iters = 0, wf_trace_launches = 0;
+    // Launch plan learned from the previous render of the same shape (wf_render): how many bounce
+    // iterations precede the tail and how many slots are then alive.  With a plan the whole render is
+    // enqueued without a host round trip; the live counts come back through a pinned buffer afterwards.
+    struct WfPlan {
+        bool valid = false;
+        uint64_t n_paths = 0;
+        uint32_t mode = 0, max_depth = 0, n_slots = 0, tail_max = 0;
+        uint32_t iters = 0, tail_live = 0;
+    };
+    mutable WfPlan wf_plan;
+    mutable uint32_t *wf_feedback = nullptr;     // pinned: n_live[0 .. wf_fb_iters) of the last planned render
+    mutable hipEvent_t wf_fb_event = nullptr;
+    mutable bool wf_fb_pending = false;
+    mutable uint32_t wf_fb_iters = 0;
 };
 
 extern "C" {
@@ -409,7 +423,7 @@ bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
 // ---------------------------------------------------------------------------
 static uint32_t wf_pool_capacity() {
     const char *e = getenv("BF_WF_POOL");
-    uint64_t v = e ? strtoull(e, nullptr, 10) : (1ull << 22);
+    uint64_t v = e ? strtoull(e, nullptr, 10) : (1ull << 24);
     v = std::max<uint64_t>(1024, std::min<uint64_t>(v, 1ull << 26));
     return (uint32_t) v;
 }
@@ -446,12 +460,16 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     wf.capacity = capacity;
     if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
     if (!scene->wf_event) HIP_TRY(hipEventCreateWithFlags(&scene->wf_event, hipEventDisableTiming));
+    if (!scene->wf_feedback) HIP_TRY(hipHostMalloc((void **) &scene->wf_feedback, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
+    if (!scene->wf_fb_event) HIP_TRY(hipEventCreateWithFlags(&scene->wf_fb_event, hipEventDisableTiming));
+    scene->wf_plan.valid = false;
+    scene->wf_fb_pending = false;
     return BF_OK;
 }
 
 static uint32_t wf_tail_threshold() {
     const char *e = getenv("BF_WF_TAIL");
-    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 19);
+    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 17);
 }
 
 // Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
@@ -526,6 +544,68 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         }
         return BF_OK;
     };
+    // ---- planned render: no host round trip ------------------------------------------------------
+    bf_scene::WfPlan &plan = scene->wf_plan;
+    const uint32_t depth_key = (uint32_t) lp.max_depth;
+    static const bool allow_plan = [] {
+        const char *e = getenv("BF_WF_SYNC");
+        return !(e && atoi(e) != 0);
+    }();
+    const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
+    (void) hipGetLastError();      // hipErrorNotReady from the query must not leak into the launch checks below
+    if (fb_ready) {
+        // live counts of the last planned render: move the switch to the tail to where it belongs
+        scene->wf_fb_pending = false;
+        const uint32_t *nl = scene->wf_feedback;
+        uint32_t k = 0;
+        while (k < scene->wf_fb_iters && nl[k] > plan.tail_max) ++k;
+        if (k < scene->wf_fb_iters) {
+            plan.iters = k + 1;
+            plan.tail_live = nl[k];
+        } else {                       // still above the threshold after the planned iterations: extend
+            plan.iters = std::min<uint32_t>(scene->wf_fb_iters + 2, bfd::kWfMaxIter - 1);
+            plan.tail_live = nl[scene->wf_fb_iters - 1];
+        }
+    }
+    if (allow_plan && plan.valid && plan.n_paths == lp.n_paths && plan.mode == lp.mode &&
+        plan.max_depth == depth_key && plan.n_slots == wf.n_slots && plan.tail_max == tail_max && plan.iters > 0) {
+        for (uint32_t it = 0; it < plan.iters; ++it) {
+            const int nxt = (it & 1) ^ 1;
+            HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, mask_bytes, stream));
+            HIP_TRY(tic(1));
+            HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev, grid_shade, lds_shade, stream,
+                                 shade_waves));
+            HIP_TRY(toc());
+            HIP_TRY(tic(0));
+            HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream, trace_waves));
+            HIP_TRY(toc());
+        }
+        // the tail kernel finishes whatever is alive, whatever the estimate: the estimate only sizes its grid
+        const uint32_t est = std::max<uint32_t>(plan.tail_live + plan.tail_live / 4, 64u * bfd::kBlock);
+        HIP_TRY(tic(2));
+        HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, plan.iters, est, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail, stream));
+        HIP_TRY(toc());
+        if (!scene->wf_fb_pending) {
+            HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live, plan.iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
+            scene->wf_fb_pending = true;
+            scene->wf_fb_iters = plan.iters;
+        }
+        return finish(plan.iters, plan.iters);
+    }
+    auto learn = [&](uint32_t iters, uint32_t live) {
+        plan.valid = true;
+        plan.n_paths = lp.n_paths;
+        plan.mode = lp.mode;
+        plan.max_depth = depth_key;
+        plan.n_slots = wf.n_slots;
+        plan.tail_max = tail_max;
+        plan.iters = iters;
+        plan.tail_live = live;
+        scene->wf_fb_pending = false;
+    };
+
+    // ---- synchronous render (first render of a shape, or per-kernel statistics requested) ----------
     for (uint32_t it = 0; it < bfd::kWfMaxIter; ++it) {
         const int nxt = (it & 1) ^ 1;
         HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, mask_bytes, stream));    // alive, trace, shadow are contiguous
@@ -540,8 +620,12 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         HIP_TRY(toc());
         HIP_TRY(hipEventSynchronize(scene->wf_event));
         uint32_t n_live = hq[0];
-        if (n_live == 0) return finish(it + 1, it + 1);
+        if (n_live == 0) {
+            learn(it + 1, 0);
+            return finish(it + 1, it + 1);
+        }
         if (n_live <= tail_max) {
+            learn(it + 1, n_live);
             HIP_TRY(tic(2));
             HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, it + 1, n_live, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail,
                                     stream));

@@ -330,3 +330,19 @@ def test_concurrent_renders_on_two_streams(hiplib):
     torch.cuda.synchronize()
     for h in hists:
         assert np.allclose(h.cpu().numpy(), ref, rtol=1e-4, atol=1e-2)
+
+
+def test_planned_render_matches_first_render(hiplib):
+    """The first wavefront render of a launch shape is driven bounce by bounce from the host and
+    records a plan; later renders of that shape are enqueued without a host round trip.  Both must
+    give every path the same result (and the oracle's)."""
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 16, bins=256, dr=0.1)
+    o = OracleScene(sd)
+    oracle_out = o.render(lp, records=True, threads=8)
+    g = capi.Scene(sd)
+    for _ in range(3):                       # 1st: synchronous, 2nd/3rd: planned (3rd after feedback)
+        _render_compare_one(g, lp, oracle_out, 2e-5)
+    lp2 = capi.make_launch(lp.mode, 1 << 16, seed=lp.seed + 17, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
+    _render_compare_one(g, lp2, o.render(lp2, records=True, threads=8), 2e-5)     # new seed, same plan
+    lp3 = capi.make_launch(lp.mode, 3000, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
+    _render_compare_one(g, lp3, o.render(lp3, records=True, threads=8), 2e-5)     # other shape: plan not applicable

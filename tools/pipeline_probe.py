@@ -12,7 +12,7 @@ flags = capi.BF_FLAG_MEGAKERNEL if os.environ.get("MODE", "megakernel") == "mega
 lp.flags = flags
 lib = capi.load_library()
 nch = lib.bf_launch_channels(lp)
-for n_streams in (1, 2, 3):
+for n_streams in [int(x) for x in os.environ.get("STREAMS", "1,2,3").split(",")]:
     sc = [capi.Scene(sd) for _ in range(n_streams)]
     st = [torch.cuda.Stream() for _ in range(n_streams)]
     hist = [torch.zeros(nch, device="cuda") for _ in range(K)]
