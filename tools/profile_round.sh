@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-timeout -k 10 170 rocprofv3 --kernel-trace --stats -d $O/prof_s2 -o s2 -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_s2.json 2> $O/bench_s2.err
-echo "s2 done"
+timeout -k 10 170 rocprofv3 --kernel-trace --stats -d $O/prof_def -o d -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_def.json 2> $O/bench_def.err
+echo "default done"
 timeout -k 10 170 rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o s1 -- python3 bench.py --steps 5 --warmup 1 --no-cpu --streams 1 > $O/bench_s1.json 2> $O/bench_s1.err
 echo "s1 done"
 export ONLY=wavefront
@@ -16,4 +16,4 @@ timeout -k 10 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_l2 -o c -- 
 echo "l2 done"
 timeout -k 10 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $O/pmc_sq -o c -- python3 tools/quick_bench.py > $O/pmc_sq.log 2>&1
 echo "sq done"
-ls $O/prof_s2 $O/pmc_fetch
+ls $O/prof_def $O/pmc_fetch
