@@ -102,6 +102,8 @@ struct bf_scene {
     // wavefront workspace, allocated on first use (mutable: lazily grown cache)
     mutable bfd::WF wf;
     mutable std::vector<void *> wf_owned;
+    uint32_t n_materials = 0;
+    float origin_scale_built = 0.f;        // ray-origin bound the BVH boxes were padded for (bf_bvh.h)
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
     mutable unsigned long long *wf_masks = nullptr;
@@ -157,33 +159,42 @@ bf_status bf_scene_destroy(bf_scene *s) {
     for (void *p : s->wf_owned) (void) hipFree(p);
     if (s->wf_host) (void) hipHostFree(s->wf_host);
     if (s->wf_event) (void) hipEventDestroy(s->wf_event);
+    if (s->wf_feedback) (void) hipHostFree(s->wf_feedback);
+    if (s->wf_fb_event) (void) hipEventDestroy(s->wf_fb_event);
     for (hipEvent_t e : s->wf_timing) (void) hipEventDestroy(e);
     if (s->counters) (void) hipFree(s->counters);
     delete s;
     return BF_OK;
 }
 
-bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
-    if (!desc || !out) return fail(BF_ERR_INVALID, "null argument");
-    *out = nullptr;
-    if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
-    if (desc->n_materials == 0 || !desc->materials) return fail(BF_ERR_INVALID, "at least one material is required");
-    if (desc->sensor.film_width != 1 || desc->sensor.film_height != 1)
-        return fail(BF_ERR_UNSUPPORTED, "only 1x1 films are supported (all radar scenes; fluxmeter.cpp:51-52)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(BF_ERR_DEVICE, "no HIP device available: the HIP path has no CPU fallback");
-
+namespace {
+struct TriMeta {
+    uint32_t prim, shape;
+    const float *n0, *n1, *n2;
+};
+// Everything of a scene description except the BVH: shape / rectangle / emitter tables and the sensor record.
+struct Flat {
     std::vector<bfd::DShape> shapes;
     std::vector<bfd::DRect> rects;
-    std::vector<bf::BuildTri> btris;
-    struct TriMeta {
-        uint32_t prim, shape;
-        const float *n0, *n1, *n2;
-    };
+    std::vector<bf::BuildTri> btris;      // filled only when with_meshes
     std::vector<TriMeta> meta;
     bool any_normals = false;
+    std::vector<bfd::DEmitter> emitters;
+    bfd::DSensor sensor;
+    uint32_t n_tris = 0;
+    float origin_scale = 0.f;             // largest |coordinate| of a rectangle corner, emitter or sensor position
+};
+}  // namespace
+
+static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
+    std::vector<bfd::DShape> &shapes = f.shapes;
+    std::vector<bfd::DRect> &rects = f.rects;
+    std::vector<bf::BuildTri> &btris = f.btris;
+    std::vector<TriMeta> &meta = f.meta;
+    bool &any_normals = f.any_normals;
+    any_normals = false;
     uint32_t prim = 0;
+    uint64_t n_tris_total = 0;
     for (uint32_t i = 0; i < desc->n_shapes; ++i) {
         const bf_shape &s = desc->shapes[i];
         if (s.material >= desc->n_materials) return fail(BF_ERR_INVALID, "shape %u: material index out of range", i);
@@ -216,7 +227,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             prim += 1;
         } else if (s.type == BF_SHAPE_MESH) {
             if (s.n_faces && (!s.positions || !s.indices)) return fail(BF_ERR_INVALID, "shape %u: null mesh arrays", i);
-            for (uint32_t f = 0; f < s.n_faces; ++f) {
+            n_tris_total += s.n_faces;
+            for (uint32_t f = 0; with_meshes && f < s.n_faces; ++f) {
                 uint32_t i0 = s.indices[3 * f], i1 = s.indices[3 * f + 1], i2 = s.indices[3 * f + 2];
                 if (i0 >= s.n_vertices || i1 >= s.n_vertices || i2 >= s.n_vertices)
                     return fail(BF_ERR_INVALID, "shape %u face %u: vertex index out of range", i, f);
@@ -240,9 +252,10 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         }
         shapes.push_back(ds);
     }
-    if (btris.size() >= (1u << 28)) return fail(BF_ERR_UNSUPPORTED, "too many triangles");
+    if (n_tris_total >= (1u << 28)) return fail(BF_ERR_UNSUPPORTED, "too many triangles");
+    f.n_tris = (uint32_t) n_tris_total;
 
-    std::vector<bfd::DEmitter> emitters;
+    std::vector<bfd::DEmitter> &emitters = f.emitters;
     for (uint32_t i = 0; i < desc->n_emitters; ++i) {
         const bf_emitter &e = desc->emitters[i];
         bfd::DEmitter de;
@@ -281,19 +294,14 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         emitters.push_back(de);
     }
 
-    bf_scene *sc = new (std::nothrow) bf_scene();
-    if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
-    std::memset(&sc->d, 0, sizeof(sc->d));
-    std::memset(&sc->info, 0, sizeof(sc->info));
-    std::memset(&sc->wf, 0, sizeof(sc->wf));
-    bfd::DSensor &sen = sc->d.sensor;
+    bfd::DSensor &sen = f.sensor;
+    std::memset(&sen, 0, sizeof(sen));
     sen.type = desc->sensor.type;
     sen.rect = -1;
     if (desc->sensor.type == BF_SENSOR_FLUXMETER || desc->sensor.type == BF_RECEIVER_OMNI ||
         desc->sensor.type == BF_RECEIVER_WIGNER) {
         int32_t sh = desc->sensor.shape;
         if (sh < 0 || sh >= (int32_t) desc->n_shapes || desc->shapes[sh].type != BF_SHAPE_RECTANGLE) {
-            delete sc;
             return fail(BF_ERR_UNSUPPORTED, "fluxmeter / receiver must sit on a rectangle");
         }
         sen.rect = shapes[sh].rect;
@@ -311,7 +319,6 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         m34(desc->sensor.to_world, sen.to_world);
         std::memcpy(sen.sample_to_camera, desc->sensor.sample_to_camera, 16 * sizeof(float));
     } else {
-        delete sc;
         return fail(BF_ERR_UNSUPPORTED, "sensor type %u not supported by this build", desc->sensor.type);
     }
     sen.near_clip = desc->sensor.near_clip;
@@ -321,7 +328,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
 
     // BVH over all mesh triangles; triangles stored in leaf order
     // rays start on scene surfaces, sensors or emitters: bound |origin| for the builder's padding
-    float origin_scale = 0.f;
+    float &origin_scale = f.origin_scale;
+    origin_scale = 0.f;
     auto grow_scale = [&](const float *m /* 3x4 */, float ex, float ey) {
         for (int r = 0; r < 3; ++r)
             origin_scale = std::max(origin_scale, std::fabs(m[4 * r + 3]) + std::fabs(m[4 * r + 0]) * ex + std::fabs(m[4 * r + 1]) * ey);
@@ -329,10 +337,46 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     for (const auto &r : rects) grow_scale(r.to_world, 1.f, 1.f);
     for (const auto &e : emitters) grow_scale(e.to_world, 0.f, 0.f);
     grow_scale(sen.to_world, 0.f, 0.f);
+    return BF_OK;
+}
+
+bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
+    if (!desc || !out) return fail(BF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
+    if (desc->n_materials == 0 || !desc->materials) return fail(BF_ERR_INVALID, "at least one material is required");
+    if (desc->sensor.film_width != 1 || desc->sensor.film_height != 1)
+        return fail(BF_ERR_UNSUPPORTED, "only 1x1 films are supported (all radar scenes; fluxmeter.cpp:51-52)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(BF_ERR_DEVICE, "no HIP device available: the HIP path has no CPU fallback");
+
+    Flat flat;
+    {
+        bf_status fst = flatten(desc, flat, true);
+        if (fst != BF_OK) return fst;
+    }
+    std::vector<bfd::DShape> &shapes = flat.shapes;
+    std::vector<bfd::DRect> &rects = flat.rects;
+    std::vector<bf::BuildTri> &btris = flat.btris;
+    std::vector<TriMeta> &meta = flat.meta;
+    const bool any_normals = flat.any_normals;
+    std::vector<bfd::DEmitter> &emitters = flat.emitters;
+    const float origin_scale = flat.origin_scale;
+
+    bf_scene *sc = new (std::nothrow) bf_scene();
+    if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
+    std::memset(&sc->d, 0, sizeof(sc->d));
+    std::memset(&sc->info, 0, sizeof(sc->info));
+    std::memset(&sc->wf, 0, sizeof(sc->wf));
+    sc->d.sensor = flat.sensor;
+    sc->origin_scale_built = origin_scale;
     bf::BVH bvh;
     bf::build_bvh(btris, bvh, origin_scale);
     bf::BVH4 bvh4;
     bf::collapse_bvh4(bvh, bvh4);
+    for (int k = 0; k < 3 && !btris.empty(); ++k)
+        sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
     if (any_normals) nrm_data.resize(3 * btris.size());
     for (size_t slot = 0; slot < btris.size(); ++slot) {
@@ -376,6 +420,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(mats, materials);
     UP(emitters, emitters);
 #undef UP
+    sc->n_materials = desc->n_materials;
     sc->d.n_tris = (uint32_t) btris.size();
     sc->d.n_rects = (uint32_t) rects.size();
     sc->d.n_emitters = (uint32_t) emitters.size();
@@ -408,6 +453,41 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         inf.bbox_max[k] = bvh.hi[k];
     }
     *out = sc;
+    return BF_OK;
+}
+
+bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, void *stream_) {
+    if (!scene || !desc) return fail(BF_ERR_INVALID, "null argument");
+    if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
+    Flat f;
+    bf_status st = flatten(desc, f, false);
+    if (st != BF_OK) return st;
+    if (f.shapes.size() != scene->info.n_shapes || f.rects.size() != scene->d.n_rects || f.emitters.size() != scene->d.n_emitters ||
+        f.n_tris != scene->d.n_tris || desc->n_materials != scene->n_materials)
+        return fail(BF_ERR_INVALID, "bf_scene_update_endpoints: the description has a different layout than the scene "
+                                    "(shapes %zu/%u, rectangles %zu/%u, emitters %zu/%u, triangles %u/%u)",
+                    f.shapes.size(), scene->info.n_shapes, f.rects.size(), scene->d.n_rects, f.emitters.size(),
+                    scene->d.n_emitters, f.n_tris, scene->d.n_tris);
+    if (scene->d.n_tris && f.origin_scale > scene->origin_scale_built)
+        return fail(BF_ERR_UNSUPPORTED, "bf_scene_update_endpoints: an endpoint moved to |coordinate| %g, outside the bound %g the "
+                                        "BVH boxes were padded for; create a new scene", (double) f.origin_scale,
+                    (double) scene->origin_scale_built);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    // small tables, copied in stream order (pageable sources are staged by the runtime before the call returns)
+    if (!f.rects.empty())
+        HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, f.rects.data(), f.rects.size() * sizeof(bfd::DRect), hipMemcpyHostToDevice, stream));
+    if (!f.shapes.empty())
+        HIP_TRY(hipMemcpyAsync((void *) scene->d.shapes, f.shapes.data(), f.shapes.size() * sizeof(bfd::DShape), hipMemcpyHostToDevice, stream));
+    if (!f.emitters.empty())
+        HIP_TRY(hipMemcpyAsync((void *) scene->d.emitters, f.emitters.data(), f.emitters.size() * sizeof(bfd::DEmitter), hipMemcpyHostToDevice, stream));
+    if (desc->n_materials)
+        HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, desc->materials, desc->n_materials * sizeof(bf_material), hipMemcpyHostToDevice, stream));
+    scene->d.sensor = f.sensor;          // passed to the kernels by value with every launch
+    scene->emitter_types.clear();
+    for (const auto &e : f.emitters) scene->emitter_types.push_back(e.type);
+    scene->d.c = desc->physics.c;
+    scene->d.lambda_min = desc->physics.lambda_min_nm;
+    scene->d.lambda_max = desc->physics.lambda_max_nm;
     return BF_OK;
 }
 

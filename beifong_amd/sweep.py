@@ -1,0 +1,69 @@
+"""Frame sweeps: the reference's radar scripts render one frame per radar pose or pulse in a Python
+loop that rebuilds the whole scene every time (python_scripts/animated_trans_rad.py:307-384,
+Receive.ipynb cell 30).  Here the frames of a sweep
+
+  * rotate over `n_streams` HIP streams, one device scene handle each, so that the latency-bound
+    deep-path tail of one frame overlaps the heads of the next ones;
+  * keep the BVH on the device while only endpoints move: a frame whose mesh arrays are the very
+    arrays of the handle's previous frame is applied with bf_scene_update_endpoints (rectangle
+    transforms, emitter / transmitter, sensor / receiver records — microseconds instead of a rebuild).
+
+Needs torch only for device buffers and streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def geometry_key(sd):
+    """Identity of a description's meshes: the addresses and sizes of the arrays it points to."""
+    key = []
+    for s in sd.shapes:
+        if s.type == capi.BF_SHAPE_MESH:
+            key.append((C.cast(s.positions, C.c_void_p).value, s.n_vertices, C.cast(s.indices, C.c_void_p).value, s.n_faces,
+                        C.cast(s.normals, C.c_void_p).value))
+        else:
+            key.append(None)
+    return tuple(key)
+
+
+def render_sweep(frames, n_streams=4, lib=None, device=None):
+    """Render `frames` — an iterable of (SceneDesc, bf_launch) — and return float32[n_frames, channels].
+
+    All frames must produce the same number of channels.  Frames are independent renders; their
+    order in the output is the input order."""
+    import torch
+    lib = lib or capi.load_library()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    handles = [None] * n_streams
+    keys = [None] * n_streams
+    hists = []
+    stats = {"created": 0, "updated": 0}
+    for k, (sd, lp) in enumerate(frames):
+        j = k % n_streams
+        key = geometry_key(sd)
+        with torch.cuda.stream(streams[j]):
+            if handles[j] is not None and keys[j] == key:
+                handles[j].update_endpoints(sd, stream=streams[j].cuda_stream)
+                stats["updated"] += 1
+            else:
+                if handles[j] is not None:
+                    streams[j].synchronize()          # the old handle's last render must be done before it goes
+                    handles[j].close()
+                handles[j] = capi.Scene(sd, lib)
+                keys[j] = key
+                stats["created"] += 1
+            h = torch.zeros(handles[j].channels(lp), dtype=torch.float32, device=dev)
+            handles[j].render_device(lp, h.data_ptr(), stream=streams[j].cuda_stream)
+            hists.append(h)
+    for s in streams:
+        s.synchronize()
+    out = np.stack([h.cpu().numpy() for h in hists]) if hists else np.zeros((0, 0), np.float32)
+    for h in handles:
+        if h is not None:
+            h.close()
+    render_sweep.last_stats = stats
+    return out

@@ -227,6 +227,19 @@ bf_status bf_set_device(int device);
 
 bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out);
 bf_status bf_scene_destroy(bf_scene *scene);
+
+/* Move / retune the endpoints of an existing scene WITHOUT rebuilding the BVH:
+ * `desc` must describe the same layout (shape, rectangle, emitter, material
+ * and triangle counts; the mesh arrays are not read) — rectangle transforms,
+ * emitters / transmitters, the sensor / receiver + ADC, materials and physics
+ * are replaced.  This is one frame of the reference's sweep loops, which
+ * rebuild the whole scene per frame just to rotate the radar
+ * (python_scripts/animated_trans_rad.py:307-373, Receive.ipynb cell 30).
+ * Stream-ordered: renders enqueued on `stream` afterwards see the new
+ * endpoints; renders of this scene on other streams must have completed.
+ * Fails with BF_ERR_UNSUPPORTED if an endpoint moves further from the origin
+ * than the bound the BVH boxes were padded for (recreate the scene then). */
+bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, void *stream);
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info);
 
 /* number of floats the given launch accumulates into: 5 (+bins | +3*bins) for

@@ -346,3 +346,51 @@ def test_planned_render_matches_first_render(hiplib):
     _render_compare_one(g, lp2, o.render(lp2, records=True, threads=8), 2e-5)     # new seed, same plan
     lp3 = capi.make_launch(lp.mode, 3000, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
     _render_compare_one(g, lp3, o.render(lp3, records=True, threads=8), 2e-5)     # other shape: plan not applicable
+
+
+def test_update_endpoints_equals_fresh_scene(hiplib):
+    """bf_scene_update_endpoints (radar turned, BVH kept) gives every path the result a freshly
+    created scene gives; a layout change or an endpoint outside the padded bound is refused."""
+    mesh = scenes.bus_mesh(20000)
+    sd0, lp = scenes.bus_radar(n_paths=20000, mesh=mesh)
+    g = capi.Scene(sd0)
+    for yaw in (12.5, -30.0):
+        sd1, _ = scenes.bus_radar(n_paths=20000, mesh=mesh, radar_yaw_deg=yaw)
+        g.update_endpoints(sd1)
+        h_u, r_u, st_u = g.render(lp, records=True)
+        h_f, r_f, st_f = capi.Scene(sd1).render(lp, records=True)
+        assert np.array_equal(r_u["L"].view(np.uint32), r_f["L"].view(np.uint32))
+        assert np.array_equal(r_u["aux"].view(np.uint32), r_f["aux"].view(np.uint32))
+        assert np.array_equal(r_u["n_rays"], r_f["n_rays"])
+        o = OracleScene(sd1)
+        _render_compare_one(g, lp, o.render(lp, records=True, threads=8), 2e-5)
+    h0, _, _ = capi.Scene(sd0).render(lp)
+    assert not np.allclose(h0, h_u)                       # the radar really moved
+    sd_other, _ = scenes.trans_rad(spp=16)
+    with pytest.raises(capi.BeifongError):
+        g.update_endpoints(sd_other)                      # different layout
+    sd_far = SceneDesc()
+    scenes._radar_frontend(sd_far)
+    scenes._ground(sd_far)
+    m = sd_far.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
+    sd_far.add_mesh(mesh[0], mesh[1], m)
+    sd_far.add_rectangle(Transform4f.translate([5000.0, 0, 0]), m)
+    sd_far.finalize()
+    with pytest.raises(capi.BeifongError):
+        g.update_endpoints(sd_far)
+
+
+def test_render_sweep_reuses_device_scenes(hiplib):
+    """The frame loop of animated_trans_rad.py: radar yaw sweep over a static scene, frames rotated
+    over HIP streams, BVH built once per stream handle."""
+    pytest.importorskip("torch")
+    from beifong_amd import sweep
+    mesh = scenes.bus_mesh(20000)
+    yaws = np.linspace(-20, 20, 9)
+    frames = [scenes.bus_radar(n_paths=1 << 14, mesh=mesh, radar_yaw_deg=float(y)) for y in yaws]
+    cube = sweep.render_sweep(frames, n_streams=3)
+    assert cube.shape == (9, 5 + 256)
+    assert sweep.render_sweep.last_stats == {"created": 3, "updated": 6}
+    for k in (0, 4, 8):
+        h, _, _ = capi.Scene(frames[k][0]).render(frames[k][1])
+        assert np.allclose(cube[k], h, rtol=1e-4, atol=1e-2)
