@@ -73,7 +73,7 @@ class bf_launch(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("color_mode", C.c_uint32), ("n_paths", C.c_uint64),
                 ("path_offset", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_int32),
                 ("rr_depth", C.c_int32), ("bins", C.c_uint32), ("bins_y", C.c_uint32), ("bin_width", C.c_float),
-                ("time_c", C.c_float), ("flags", C.c_uint32)]
+                ("time_c", C.c_float), ("flags", C.c_uint32), ("phase_bins", C.c_uint32)]
 
 
 class bf_path_record(C.Structure):
@@ -157,11 +157,12 @@ def _ptr(a):
 
 
 def make_launch(mode, n_paths, seed=0, path_offset=0, bins=0, bin_width=0.0, color_mode=BF_COLOR_RGB,
-                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0, bins_y=0):
+                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0, bins_y=0, phase_bins=0):
     lp = bf_launch()
     lp.mode, lp.color_mode, lp.n_paths, lp.path_offset, lp.seed = mode, color_mode, n_paths, path_offset, seed
     lp.max_depth, lp.rr_depth, lp.bins, lp.bin_width, lp.time_c, lp.flags = max_depth, rr_depth, bins, bin_width, time_c, flags
     lp.bins_y = bins_y
+    lp.phase_bins = phase_bins
     return lp
 
 

@@ -148,7 +148,7 @@ uint32_t bf_launch_channels(const bf_launch *lp) {
         case BF_MODE_PATH: return 5;
         case BF_MODE_RANGE: return 5 + lp->bins;
         case BF_MODE_TIME: return 5 + 3 * lp->bins;
-        case BF_MODE_RECEIVE_RAW: return 3 * lp->bins * lp->bins_y;
+        case BF_MODE_RECEIVE_RAW: return (3 + lp->phase_bins) * lp->bins * lp->bins_y;
     }
     return 0;
 }
@@ -735,6 +735,9 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
                 return fail(BF_ERR_INVALID, "render modes: emitter %u is a transmitter (use receive mode)", i);
     }
     if (launch->mode > BF_MODE_RECEIVE_RAW) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);
+    if (launch->mode != BF_MODE_RECEIVE_RAW && launch->phase_bins)
+        return fail(BF_ERR_INVALID, "phase_bins needs receive mode (PhaseIntegrator wraps pathtimefrequency)");
+    if (launch->phase_bins > 4096) return fail(BF_ERR_INVALID, "phase_bins %u out of range", launch->phase_bins);
     if ((launch->mode == BF_MODE_RANGE || launch->mode == BF_MODE_TIME) && (launch->bins == 0 || !(launch->bin_width > 0.f)))
         return fail(BF_ERR_INVALID, "range/time mode needs bins > 0 and bin_width > 0");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -749,6 +752,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     lp.rr_depth = launch->rr_depth;
     lp.bins = launch->bins;
     lp.bins_y = launch->bins_y;
+    lp.phase_bins = launch->mode == BF_MODE_RECEIVE_RAW ? launch->phase_bins : 0u;
     lp.bin_width = launch->bin_width;
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);

@@ -79,7 +79,7 @@ struct DLaunch {
     uint32_t mode, color_mode;
     uint64_t n_paths, path_offset, seed;
     int32_t max_depth, rr_depth;
-    uint32_t bins, bins_y;
+    uint32_t bins, bins_y, phase_bins;
     float bin_width, time_c;
     uint32_t n_chan;
     uint32_t lds_hist;        // 1: histogram privatised in LDS

@@ -38,6 +38,7 @@ struct PathState {
     float time;          // ray.time: retarded time carried along the path (ray.h:89-93)
     float t_rx;          // sampled receive time (integrator.cpp:1556-1561)
     float lambda0;       // ray.wavelengths[0] in nm
+    float phase;         // ray.phase of the working ray: last traced segment only (ray.h:89-93, interaction.h:61-64)
 };
 
 BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
@@ -58,12 +59,13 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     s.n_rays = c.z;
     s.rng.state = ((uint64_t) d.y << 32) | d.x;
     s.path_i = ((uint64_t) d.w << 32) | d.z;
-    s.time = s.t_rx = s.lambda0 = 0.f;
+    s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
     if (receive) {
         float4 e = wf.se[i];
         s.time = e.x;
         s.t_rx = e.y;
         s.lambda0 = e.z;
+        s.phase = e.w;
     }
 }
 BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState &s) {
@@ -74,7 +76,7 @@ BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState 
     wf.sc[j] = make_uint4(__float_as_uint(s.prev_p.z), s.flags, s.n_rays, 0u);
     wf.sd[j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
                           (uint32_t) (s.path_i >> 32));
-    if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, 0.f);
+    if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, s.phase);
 }
 
 // ---------------------------------------------------------------------------
@@ -148,6 +150,13 @@ BF_DEV uint32_t cursor_take(MaskCursor &c, uint32_t want, bool requesting, uint3
 // reference, so those products run in double here too.
 // ---------------------------------------------------------------------------
 BF_DEV float jabs(float x) { return x >= 0.f ? x : -x; }
+// Ray::update_state, phase part (ray.h:89-93): float product, double quotient and sum, float store;
+// the divisor is HALF THE BAND WIDTH in metres (Q4)
+BF_DEV float phase_update(float phase, float t, float lambda_min_nm, float lambda_max_nm) {
+    float num = 6.28318530717958647692f * t;
+    double den = (double) ((lambda_max_nm - lambda_min_nm) / 2.f) * 1e-9;
+    return (float) ((double) phase + (double) num / den);
+}
 BF_DEV float sinc_j(float x) { return jabs(x) > kEpsilon ? sin_cr(x) / x : 1.f; }
 BF_DEV float tri_j(float x) { return jabs(x) < 0.5f ? 1.f - 2.f * jabs(x) : 0.f; }
 BF_DEV float rect_j(float x) { return jabs(x) < 0.5f ? 1.f : 0.f; }
@@ -278,7 +287,7 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
     pcg_seed(s.rng, lp.seed + lp.path_offset + path_i);
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
     float ax = .5f, ay = .5f;
-    s.time = s.t_rx = s.lambda0 = 0.f;
+    s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
     bool film_ok = true;
     if (receive) {
         // receive_sample — integrator.cpp:1544-1572
@@ -352,11 +361,17 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         if (si_valid) s.flags |= kFlagValid;
         if (is_range) s.aux += si_valid ? si.t : 0.f;
         if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
-        if (receive && si_valid) s.time += -si.t / sc.c;          // ray.update_state(-si.t); si.time = ray.time
+        if (receive && si_valid) {                                 // ray.update_state(-si.t); si.time = ray.time
+            s.time += -si.t / sc.c;
+            if (lp.phase_bins) s.phase = phase_update(s.phase, -si.t, sc.lambda_min, sc.lambda_max);
+        }
         depth = 1;
     } else {
         // tail of the previous iteration — path.cpp:184-209, pathtimefrequency.cpp:363-399
-        if (receive) s.time += -hit.t / sc.c;                      // :368-371, also for a miss (Q3)
+        if (receive) {                                             // :368-371, also for a miss (Q3)
+            s.time += -hit.t / sc.c;
+            if (lp.phase_bins) s.phase = phase_update(0.f, -hit.t, sc.lambda_min, sc.lambda_max);   // spawn_ray: phase restarts at 0
+        }
         if (emitter >= 0) {
             const DEmitter &e = sc.emitters[emitter];
             float emitter_pdf = receive ? transmitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
@@ -485,13 +500,37 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         float a0 = valid ? 4.f * L : 0.f;                     // hsum over 4 identical spectral lanes
         float a1 = valid ? 1.f : 0.f;
         bool ok = __builtin_isfinite(a0);
+        // PhaseIntegrator::sample (phase.cpp:93-141): S{k}.Y takes hsum(L), before the receiver weight,
+        // iff rect((phase - centre_k) / width) > 0; evaluated exactly as written there for the (at most
+        // three) candidate bins around phase / width
+        const uint32_t P = lp.phase_bins;
+        const float pv = valid ? 4.f * s.result : 0.f;
+        int pk0 = 0;
+        uint32_t pmask = 0u;            // bit i: bin pk0 - 1 + i takes the sample
+        if (P) {
+            const float two_pi = 6.28318530717958647692f;
+            const float width = two_pi / (float) (int) P;
+            float phase = __builtin_fmodf(valid ? 0.f + s.phase : 0.f, two_pi);
+            phase += (phase < 0.f) ? two_pi : 0.f;
+            const float fk = __builtin_floorf(phase / width);             // NaN phases (a miss: -inf) select no bin
+            pk0 = (fk >= 0.f && fk < (float) P) ? (int) fk : ((fk >= (float) P) ? (int) P - 1 : 0);
+            for (int i = 0; i < 3; ++i) {
+                const int k = pk0 - 1 + i;
+                if (k < 0 || k >= (int) P) continue;
+                float centre = (float) ((double) width * ((double) k + 0.5));
+                if (jabs((phase - centre) / width) < 0.5f) pmask |= 1u << i;
+            }
+            ok = ok && __builtin_isfinite(pv);
+        }
         float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
         ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
         if (ok) {
-            uint32_t off = 3u * ((uint32_t) ly * lp.bins + (uint32_t) lx);
+            uint32_t off = (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
             if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 0u, a0);
             if (a1 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 1u, a1);
             hist_add(s_hist, g_hist, lds_hist, off + 2u, 1.f);
+            for (int i = 0; i < 3; ++i)
+                if ((pmask >> i & 1u) && pv != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 3u + (uint32_t) (pk0 - 1 + i), pv);
             acc.W += 1.f;
         } else {
             ++acc.invalid;

@@ -91,8 +91,8 @@ int bfh_integrator_launch(void *integrator, void *endpoint, bf_launch *out) {
         if (!in) Throw("object is not a SamplingIntegrator");
         std::memset(out, 0, sizeof(*out));
         out->color_mode = variant() == "scalar_rgb" ? BF_COLOR_RGB : BF_COLOR_MONO;
-        out->max_depth = -1;
-        out->rr_depth = 5;
+        out->max_depth = in->max_depth();
+        out->rr_depth = in->rr_depth();
         out->time_c = 3.0e8f;
         in->configure(*out);
         if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) {

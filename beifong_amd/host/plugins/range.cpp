@@ -26,6 +26,8 @@ public:
         lp.bins = (uint32_t) m_bins;
         lp.bin_width = m_dr;
     }
+    int max_depth() const override { return m_integrator->max_depth(); }
+    int rr_depth() const override { return m_integrator->rr_depth(); }
 private:
     ref<SamplingIntegrator> m_integrator;
     float m_dr;

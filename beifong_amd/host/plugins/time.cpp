@@ -25,6 +25,8 @@ public:
         lp.bin_width = 0.5e-9f;       // time.cpp:118
         lp.time_c = 3.0e8f;           // pathtime.cpp:140
     }
+    int max_depth() const override { return m_integrator->max_depth(); }
+    int rr_depth() const override { return m_integrator->rr_depth(); }
 private:
     ref<SamplingIntegrator> m_integrator;
 };

@@ -431,8 +431,8 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
     lp.color_mode = color_mode_of_variant();
     lp.n_paths = sensor->sampler()->sample_count();
     lp.seed = sensor->sampler()->base_seed();
-    lp.max_depth = m_max_depth;
-    lp.rr_depth = m_rr_depth;
+    lp.max_depth = max_depth();
+    lp.rr_depth = rr_depth();
     lp.time_c = 3.0e8f;
     configure(lp);
     if (lp.mode == BF_MODE_RECEIVE_RAW) Throw("this integrator only supports receive(), not render()");
@@ -453,14 +453,19 @@ bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
     std::vector<std::string> channels = {"Y", "A", "W"};
     for (auto &n : aov_names()) channels.push_back(n);
     adc->prepare(channels);
-    if (receiver->receive_type() != "raw") Throw("receive_type \"%s\" is not supported (only \"raw\")", receiver->receive_type().c_str());
+    // "raw" and "raw_resample" take the same branches everywhere at HEAD (integrator.cpp:1603-1623,
+    // wignerreceiver.cpp:64-71,174-178).  "mix_resample" bins |f_after - f_rx|, which is exactly 0 while
+    // the Doppler update is commented out (pathtimefrequency.cpp:440-445) and so lands outside the ADC
+    // (SignalBlock::put: ceil(0 - 1) = -1); "mixer" is an empty branch (:1624-1634).  Neither is built.
+    if (receiver->receive_type() != "raw" && receiver->receive_type() != "raw_resample")
+        Throw("receive_type \"%s\" is not supported (\"raw\" and \"raw_resample\" are)", receiver->receive_type().c_str());
     bf_launch lp;
     std::memset(&lp, 0, sizeof(lp));
     lp.color_mode = BF_COLOR_MONO;
     lp.n_paths = receiver->sampler()->sample_count();
     lp.seed = receiver->sampler()->base_seed();
-    lp.max_depth = m_max_depth;
-    lp.rr_depth = m_rr_depth;
+    lp.max_depth = max_depth();
+    lp.rr_depth = rr_depth();
     lp.time_c = 3.0e8f;
     configure(lp);
     if (lp.mode != BF_MODE_RECEIVE_RAW) Throw("this integrator does not implement receive()");

@@ -230,6 +230,9 @@ public:
     virtual std::vector<std::string> aov_names() const { return {}; }
     /// BF_MODE_* + binning parameters for bf_launch
     virtual void configure(bf_launch &launch) const = 0;
+    /// MonteCarloIntegrator parameters; AOV wrappers (range, time, phase) forward to their sub-integrator
+    virtual int max_depth() const { return m_max_depth; }
+    virtual int rr_depth() const { return m_rr_depth; }
     const Class *class_() const override;
 
 protected:

@@ -176,6 +176,8 @@ typedef struct bf_launch {
     float    bin_width;       /* dr [m] (range) or dt [s] (time)              */
     float    time_c;          /* gen-1 divides by (Float)3.0e8 (pathtime.cpp:140) */
     uint32_t flags;           /* BF_FLAG_*                                    */
+    uint32_t phase_bins;      /* receive mode: PhaseIntegrator AOVs S{k}.Y after Y,A,W
+                                 (phase.cpp:80-141); 0 = plain pathtimefrequency */
 } bf_launch;
 
 enum {

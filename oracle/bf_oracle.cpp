@@ -1186,6 +1186,7 @@ inline float mis_weight(float pdf_a, float pdf_b) {   // path.cpp:222-226
 
 struct PathResult {
     float L = 0, aux = 0;
+    float phase = 0;      // gen-3: what PathTimeFrequencyIntegrator adds to the caller's ray.phase (:453)
     bool valid = false;
     uint32_t n_closest = 0, n_shadow = 0, n_bounces = 0;
 };
@@ -1418,6 +1419,16 @@ static float scene_sample_transmitter_direction(const OScene &sc, const SI &ref,
     return spec;
 }
 
+// Ray::update_state's phase part — include/mitsuba/core/ray.h:89-93:
+//   phase += math::TwoPi<Float>*t/((MTS_WAVELENGTH_MAX-MTS_WAVELENGTH_MIN)/2*1e-9);
+// float * float, divided by (float half-difference * double 1e-9) in double, added in double,
+// stored back to the float member (Q4: half the band WIDTH, not the centre wavelength).
+inline float phase_update(float phase, float t, float lambda_min_nm, float lambda_max_nm) {
+    float num = (2.f * kPi) * t;
+    double den = (double) ((lambda_max_nm - lambda_min_nm) / 2.f) * 1e-9;
+    return (float) ((double) phase + (double) num / den);
+}
+
 // PathTimeFrequencyIntegrator::sample — src/integrators/pathtimefrequency.cpp:103-460
 static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, const RxCtx &cx) {
     PathResult r;
@@ -1428,9 +1439,14 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
     ++r.n_closest;
     bool valid_ray = si.valid();
     int tx = si.valid() ? sc.shapes[si.shape].emitter : -1;
+    // `ray.phase` of the reference's working ray: the receiver hands out phase 0
+    // (omnidirectional.cpp / wignerreceiver.cpp: Float phase = 0), spawn_ray() does not carry it
+    // (interaction.h:61-64), so it only ever holds the LAST traced segment's phase
+    float cur_phase = 0.f;
     if (si.valid()) {                    // :149-153 ray.update_state(-si.t)
         ray.time += -si.t / c;
         si.time = ray.time;
+        cur_phase = phase_update(cur_phase, -si.t, sc.physics.lambda_min_nm, sc.physics.lambda_max_nm);
     }
     for (int depth = 1;; ++depth) {
         if (tx >= 0 && active) result += emission_weight * throughput * transmitter_eval(sc, sc.emitters[tx], si, cx);
@@ -1474,6 +1490,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
         // :368-371 — executed even when si_bsdf.t is +inf (Q3)
         nray.time += -si_bsdf.t / c;
         si_bsdf.time = nray.time;
+        cur_phase = phase_update(0.f, -si_bsdf.t, sc.physics.lambda_min_nm, sc.physics.lambda_max_nm);
         tx = si_bsdf.valid() ? sc.shapes[si_bsdf.shape].emitter : -1;
         if (tx >= 0) {
             DirectionSample ds;
@@ -1490,6 +1507,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
     }
     r.L = result;
     r.valid = valid_ray;
+    r.phase = valid_ray ? 0.f + cur_phase : 0.f;      // :448-454 if (all(valid_ray)) ray_.phase += ray.phase
     return r;
 }
 
@@ -1547,7 +1565,7 @@ static uint32_t launch_channels(const bf_launch &lp) {
         case BF_MODE_PATH: return 5;
         case BF_MODE_RANGE: return 5 + lp.bins;
         case BF_MODE_TIME: return 5 + 3 * lp.bins;
-        case BF_MODE_RECEIVE_RAW: return 3 * lp.bins * lp.bins_y;
+        case BF_MODE_RECEIVE_RAW: return (3 + lp.phase_bins) * lp.bins * lp.bins_y;
     }
     return 0;
 }
@@ -1643,15 +1661,34 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     out.L = a0;
     out.pr.aux = time - s.adc_sampling_start;
     bool ok = std::isfinite(a0);
+    // PhaseIntegrator::sample — phase.cpp:93-141: AOVs aovs[3 + k] written BEFORE the receiver weight is
+    // applied; bin k takes hsum(L) iff rect((phase - centre_k) / width) > 0, phase = fmod(ray.phase, 2 pi)
+    const uint32_t P = lp.phase_bins;
+    std::vector<float> aov(P, 0.f);
+    if (P) {
+        const float two_pi = 2.f * kPi;
+        const float width = two_pi / (float) (int) P;                 // m_bin_width = TwoPi<float>/m_bins :81
+        float phase = std::fmod(out.pr.phase, two_pi);                 // :121
+        phase += (phase < 0.f) ? two_pi : 0.f;                         // :122
+        const float v = out.pr.valid ? 4.f * out.pr.L : 0.f;           // select(result.second, hsum(result.first), 0)
+        for (uint32_t k = 0; k < P; ++k) {
+            float centre = (float) ((double) width * ((double) (int) k + 0.5));   // m_bin_width*(k + 0.5) -> vector<float> :83
+            float x = (phase - centre) / width;
+            float ax = x >= 0.f ? x : -x;                              // math::jabs
+            aov[k] = (ax < 0.5f) ? v : 0.f;                            // math::rect(...) > 0
+            ok = ok && std::isfinite(aov[k]);
+        }
+    }
     // pos = tf - (offset - border + .5); lo = ceil(pos - .5)
     float lx = std::ceil((tf0 - .5f) - .5f), ly = std::ceil((tf1 - .5f) - .5f);
     ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
     out.put = ok;
     if (ok) {
-        size_t off = 3 * ((size_t) ly * lp.bins + (size_t) lx);
+        size_t off = (size_t) (3 + P) * ((size_t) ly * lp.bins + (size_t) lx);
         hist[off + 0] += (double) a0;
         hist[off + 1] += (double) a1;
         hist[off + 2] += (double) a2;
+        for (uint32_t k = 0; k < P; ++k) hist[off + 3 + k] += (double) aov[k];
     }
     return out;
 }

@@ -252,6 +252,23 @@ def test_mesh_scene_flattens_like_the_python_builder(mitsuba, tmp_path):
     assert h[4] == 3000 and h[3] > 0 and np.abs(h[5:]).sum() > 0
 
 
+MESH_SCENE_RECT = """
+<scene version="2.1.0">
+    <integrator type="range"><integrator type="pathlength"/><float name="dr" value="0.1"/><integer name="bins" value="64"/></integrator>
+    <sensor type="perspective">
+        <float name="fov" value="45"/><float name="near_clip" value="0.1"/><float name="far_clip" value="100"/>
+        <transform name="to_world"><lookat origin="0, 0, -3" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <film type="hdrfilm"><integer name="width" value="1"/><integer name="height" value="1"/><rfilter type="box"/></film>
+        <sampler type="independent"><integer name="sample_count" value="100"/></sampler>
+    </sensor>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.2" y="0.2"/><lookat origin="0.5, 0.5, -3" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <emitter type="area"><spectrum name="radiance" value="100"/></emitter>
+    </shape>
+    <shape type="rectangle"><bsdf type="diffuse"/></shape>
+</scene>
+"""
+
 RECEIVE_SCENE = """
 <scene version="2.1.0">
     <integrator type="pathtimefrequency"/>
@@ -294,6 +311,27 @@ def test_receive_scene_with_fork_plugins(mitsuba):
     d = scene.flat_desc(rx).desc
     assert d.n_emitters == 1 and d.emitters[0].type == capi.BF_TRANSMITTER_WIGNER and d.emitters[0].signal_type == capi.BF_SIGNAL_PULSE
     assert d.shapes[0].emitter == 0 and d.sensor.type == capi.BF_RECEIVER_OMNI and d.sensor.shape == 1
+
+
+def test_phase_integrator_plugin_and_nested_depths(mitsuba):
+    """phase.cpp (built at HEAD) wraps pathtimefrequency: `bins` S{k}.Y channels after Y, A, W; the
+    MonteCarloIntegrator parameters are those of the NESTED integrator (integrator.cpp:1713-1728)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    xml = RECEIVE_SCENE.replace('<integrator type="pathtimefrequency"/>',
+                                '<integrator type="phase"><integer name="bins" value="12"/>'
+                                '<integrator type="pathtimefrequency"><integer name="max_depth" value="3"/>'
+                                '<integer name="rr_depth" value="2"/></integrator></integrator>')
+    scene = load_string(xml)
+    rx = scene.receivers()[0]
+    lp, h, rec = _oracle_on_host_scene(scene, rx)
+    assert (lp.mode, lp.phase_bins, lp.max_depth, lp.rr_depth) == (capi.BF_MODE_RECEIVE_RAW, 12, 3, 2)
+    assert h.shape == (256 * (3 + 12),)
+    assert "phase" in {os.path.basename(p)[:-3] for p in glob.glob(os.path.join(HOST, "plugins", "*.so"))}
+    # same for the gen-2 wrapper
+    scene = load_string(MESH_SCENE_RECT.replace('<integrator type="pathlength"/>',
+                                                '<integrator type="pathlength"><integer name="max_depth" value="2"/></integrator>'))
+    lp = scene.integrator().launch_for(scene.sensors()[0])
+    assert (lp.mode, lp.max_depth) == (capi.BF_MODE_RANGE, 2)
 
 
 def test_load_dict_matches_load_string(mitsuba):

@@ -56,3 +56,41 @@ def test_serial_stream_matches_per_path_streams_statistically():
         sel = ra["L"][idx == k] / np.pi          # records hold the sensor-weighted radiance (x pi)
         var = (np.sum(sel.astype(np.float64) ** 2) / n - (np.sum(sel) / n) ** 2) / n
         assert abs(bins_a[k] - bins_b[k]) <= 6 * np.sqrt(2 * max(var, 0)) + 1e-9, k
+
+
+def test_phase_integrator_leaves_base_channels_alone_and_bins_by_last_segment():
+    """receive o phase o pathtimefrequency (phase.cpp is built at HEAD).  The S{k}.Y channels follow
+    Y, A, W; they never change those.  The phase a path reports is that of its LAST traced segment
+    (spawn_ray resets ray.phase, interaction.h:61-64), -2 pi t / K with K = half the band WIDTH
+    (ray.h:92, Q4): with a band so wide that K = 1 km every finite phase is a small negative number,
+    wraps to just under 2 pi and must land in the last bin; paths whose last ray escaped carry
+    phase -inf -> fmod = NaN -> no bin."""
+    P = 8
+    sd, lp = scenes.bus_receive(n_tris=2000, n_paths=60000)
+    base, _, _ = OracleScene(sd).render(lp, threads=8)
+    sd.physics.lambda_min_nm = 0.0
+    sd.physics.lambda_max_nm = 2.0e12            # (max - min) / 2 * 1e-9 = 1000 m
+    sd.finalize()
+    ref3, _, _ = OracleScene(sd).render(lp, threads=8)      # other band: other wavelengths, other paths
+    lp.phase_bins = P
+    h, _, st = OracleScene(sd).render(lp, threads=8)
+    h = h.reshape(256, 3 + P)
+    assert np.array_equal(h[:, :3], ref3.reshape(256, 3))
+    assert base.shape == ref3.shape
+    s = h[:, 3:]
+    assert np.all(s[:, :P - 1] == 0)
+    assert s[:, P - 1].sum() > 0
+    # only paths that ended on a surface (Russian roulette / absorbed) have a finite last segment:
+    # far fewer than the valid ones
+    assert s[:, P - 1].sum() < 4.0 * np.abs(h[:, 0]).sum() + 1e30
+
+
+def test_phase_bins_cover_the_circle_for_a_narrow_band():
+    """With the fork's default band K is ~1 mm, so segment lengths of metres spread the phases of the
+    paths that end on a surface over all bins."""
+    P = 16
+    sd, lp = scenes.bus_receive(n_tris=2000, n_paths=400000, transmitter="area")   # no signal gating: L > 0
+    lp.phase_bins = P
+    h, _, _ = OracleScene(sd).render(lp, threads=8)
+    s = h.reshape(256, 3 + P)[:, 3:].sum(0)
+    assert np.all(s > 0)            # few, heavy-tailed contributions: coverage only, no flatness claim
