@@ -413,3 +413,17 @@ def test_receive_phase_integrator(hiplib, tx, P):
     hg, ho, st = _render_compare(sd, lp)
     s = hg.reshape(256, 3 + P)[:, 3:]
     assert np.all(s[:, :P - 1] == 0) and np.count_nonzero(s[:, P - 1]) > 0
+
+
+def test_small_pool_regenerates_paths_into_freed_slots(hiplib, monkeypatch):
+    """More paths than wavefront slots: slot i renders paths i, i + n_slots, ... (static assignment),
+    in the host-driven first render, in planned renders and across the tail kernel."""
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=50000, bins=256, dr=0.1)
+    o = OracleScene(sd)
+    oracle_out = o.render(lp, records=True, threads=8)
+    for pool, tail in (("4096", "512"), ("8192", "100000"), ("1024", "0")):
+        monkeypatch.setenv("BF_WF_POOL", pool)
+        monkeypatch.setenv("BF_WF_TAIL", tail)
+        g = capi.Scene(sd)
+        for _ in range(3):
+            _render_compare_one(g, lp, oracle_out, 2e-5)
