@@ -565,6 +565,11 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     if (st != BF_OK) return st;
     bfd::WF &wf = scene->wf;
     wf.n_slots = (uint32_t) ((std::min<uint64_t>(wf.capacity, lp.n_paths) + 63) & ~uint64_t(63));
+    {
+        const char *e1 = getenv("BF_TRACE_REFILL"), *e2 = getenv("BF_TRACE_STRAGGLERS");
+        wf.trace_refill = e1 ? (uint32_t) atoi(e1) : bfd::kTraceRefill;
+        wf.trace_stragglers = e2 ? (uint32_t) atoi(e2) : bfd::kTraceStragglers;
+    }
     const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
         wf.m_alive[b] = scene->wf_masks + (3 * b + 0) * nb;

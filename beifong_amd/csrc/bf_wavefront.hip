@@ -247,8 +247,6 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 // deeper entries — rare: one entry per tree level where BOTH children are hit —
 // spill to a per-thread column in HBM.  16 KiB of LDS per workgroup instead of
 // 32 lifts the kernel from 5 to 8 waves/SIMD.
-constexpr int kRefill = 44;
-constexpr int kStragglers = 12;
 constexpr int kLdsStack = 16;
 
 template <bool STATS, int W>
@@ -352,7 +350,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 const unsigned long long at_node = __ballot(has && node >= 0);
                 if (!at_node) break;
                 // progress guarantee: only postpone the stragglers if some lane has a leaf to intersect
-                if (__popcll(at_node) < kStragglers && __ballot(has && node < 0 && node != kNoNode)) break;
+                if ((uint32_t) __popcll(at_node) < wf.trace_stragglers && __ballot(has && node < 0 && node != kNoNode)) break;
                 if (has && node >= 0) {
                     if (STATS) ++c_nodes;
                     node = node4_step(sc.nodes, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
             }
             unsigned long long act = __ballot(has);
             if (act == 0ull) break;
-            if (work_left() && __popcll(act) <= kRefill) break;
+            if (work_left() && (uint32_t) __popcll(act) <= wf.trace_refill) break;
         }
     }
     if (STATS) {
