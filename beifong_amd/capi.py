@@ -97,7 +97,8 @@ class bf_stats(C.Structure):
 class bf_scene_info(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("n_rects", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("n_bvh_nodes", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3)]
+                ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32)]
 
 
 # every symbol include/beifong_hip.h declares
@@ -119,7 +120,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("BF_HIP_LIB") or LIB_PATH      # BF_HIP_LIB: developer A/B builds
     if not os.path.exists(p):
         raise BeifongError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "

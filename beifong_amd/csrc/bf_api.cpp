@@ -405,8 +405,29 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     if (!bvh4.nodes.empty()) std::memcpy(node_data.data(), bvh4.nodes.data(), bvh4.nodes.size() * sizeof(bf::Node4));
     std::vector<bf_material> mats(desc->materials, desc->materials + desc->n_materials);
 
+    (void) hipGetDevice(&sc->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) sc->n_cus = prop.multiProcessorCount;
+
     uint64_t bytes = 0;
     bf_status st;
+    // traversal-stack overflow columns: kernels keep >= 16 entries in LDS and launch at most
+    // n_cus * kTraceBlocksPerCU workgroups
+    {
+        const uint32_t stride = (uint32_t) sc->n_cus * bfd::kTraceBlocksPerCU * bfd::kBlock;
+        const uint32_t depth = bvh4.stack_need > 16 ? bvh4.stack_need - 16 : 1;
+        void *p = nullptr;
+        hipError_t he = hipMalloc(&p, (size_t) stride * depth * sizeof(int));
+        if (he != hipSuccess) {
+            bf_scene_destroy(sc);
+            return fail(BF_ERR_NOMEM, "hipMalloc(traversal spill, %zu bytes): %s", (size_t) stride * depth * sizeof(int), hipGetErrorString(he));
+        }
+        sc->owned.push_back(p);
+        bytes += (uint64_t) stride * depth * sizeof(int);
+        sc->d.spill = (int *) p;
+        sc->d.spill_stride = stride;
+        sc->d.stack_need = bvh4.stack_need;
+    }
 #define UP(vec, field)                                              \
     if ((st = upload(vec, &sc->d.field, sc->owned, bytes)) != BF_OK) { \
         bf_scene_destroy(sc);                                       \
@@ -436,9 +457,6 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         bf_scene_destroy(sc);
         return fail(BF_ERR_DEVICE, "hipMalloc(counters): %s", hipGetErrorString(e));
     }
-    (void) hipGetDevice(&sc->device);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) sc->n_cus = prop.multiProcessorCount;
 
     bf_scene_info &inf = sc->info;
     inf.n_shapes = desc->n_shapes;
@@ -447,6 +465,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     inf.n_bvh_nodes = sc->d.n_nodes;
     inf.node_bytes = (uint32_t) sizeof(bf::Node4);
     inf.tri_bytes = 48;
+    inf.bvh_depth = bvh4.max_depth;
+    inf.bvh_stack_need = bvh4.stack_need;
     inf.device_bytes = bytes;
     for (int k = 0; k < 3; ++k) {
         inf.bbox_min[k] = bvh.lo[k];
@@ -533,8 +553,6 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
     HIP_TRY(alloc((void **) &wf.sh2, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
-    HIP_TRY(alloc((void **) &wf.spill,
-                  (size_t) scene->n_cus * bfd::kTraceBlocksPerCU * bfd::kBlock * bfd::kSpillDepth * sizeof(int)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.counters = scene->counters;
     wf.capacity = capacity;

@@ -288,19 +288,16 @@ struct Collapser {
 }  // namespace
 
 void collapse_bvh4(const BVH &in, BVH4 &out) {
-    for (int width = 4; width >= 2; width -= 2) {
-        out.nodes.clear();
-        out.root_child = in.root_child;
-        out.stack_need = 0;
-        out.max_depth = 0;
-        if (in.nodes.empty() || in.root_child < 0) return;
-        out.nodes.reserve(in.nodes.size() / 2 + 1);
-        out.nodes.emplace_back();
-        Collapser c{in, out, width};
-        out.root_child = 0;
-        out.stack_need = c.emit(in.root_child, 0, 1);
-        if (out.stack_need <= (uint32_t) kMaxDepth) return;      // else: stay two-wide (need <= binary depth)
-    }
+    out.nodes.clear();
+    out.root_child = in.root_child;
+    out.stack_need = 0;
+    out.max_depth = 0;
+    if (in.nodes.empty() || in.root_child < 0) return;
+    out.nodes.reserve(in.nodes.size() / 2 + 1);
+    out.nodes.emplace_back();
+    Collapser c{in, out, 4};
+    out.root_child = 0;
+    out.stack_need = c.emit(in.root_child, 0, 1);      // <= 3 * kMaxDepth (the binary depth bound)
 }
 
 }  // namespace bf

@@ -61,14 +61,14 @@ constexpr int32_t kEmptyChild = INT32_MIN;
 struct BVH4 {
     std::vector<Node4> nodes;         // nodes[0] is the root if root_child >= 0
     int32_t root_child;               // >= 0: node index, < 0: the whole mesh is one leaf
-    uint32_t stack_need;              // worst-case traversal stack entries (<= kMaxDepth by construction)
+    uint32_t stack_need;              // worst-case traversal stack entries: sum over levels of (children - 1) <= 3 * kMaxDepth
     uint32_t max_depth;
 };
 
 // Collapse the binary tree into four-wide nodes: a node adopts its grandchildren
 // (largest surface area first) until it has four children or only leaves.  Half
-// the dependent node fetches per ray.  If the worst-case traversal stack
-// (sum over levels of children - 1) would exceed kMaxDepth, nodes stay two-wide.
+// the dependent node fetches per ray.  The worst-case traversal stack (sum over
+// levels of children - 1) is reported so that the kernels' stacks can be sized.
 void collapse_bvh4(const BVH &in, BVH4 &out);
 
 // Binned SAH build (16 bins, leaf <= kMaxLeaf).  Boxes are padded by a few

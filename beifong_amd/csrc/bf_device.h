@@ -71,6 +71,11 @@ struct DScene {
     const DEmitter *emitters;
     uint32_t n_tris, n_rects, n_emitters, n_nodes;
     int32_t root;             // child reference of the BVH root
+    // traversal-stack overflow: entry k of thread g at spill[k * spill_stride + g]; every kernel launches at most
+    // spill_stride threads and keeps its first 16 (wavefront) or 32 entries in LDS
+    int *spill;
+    uint32_t spill_stride;
+    uint32_t stack_need;      // BVH4::stack_need: kernels whose LDS stack holds that many entries compile the overflow path out
     float c, lambda_min, lambda_max;   // MTS_C, MTS_WAVELENGTH_MIN/MAX as run-time physics
     DSensor sensor;
 };

@@ -113,10 +113,11 @@ BF_DEV int pick_child(float4 ch, uint32_t key) {
     return __float_as_int(i == 0u ? ch.x : (i == 1u ? ch.y : (i == 2u ? ch.z : ch.w)));
 }
 
-// Per-lane traversal stack: column `tid` of a lane-strided LDS array (entry k at
-// lds[k * kBlock]: bank = tid mod 32, conflict-free), optionally continued in a
-// per-thread HBM column (entry k at spill[k * spill_stride]).  Capacity
-// n_lds + spill entries >= 32 > BVH4::stack_need (bf_bvh.h).
+// Per-lane traversal stack: the first N_LDS entries in column `tid` of a lane-strided LDS array
+// (entry k at lds[k * kBlock]: bank = tid mod 32, conflict-free), deeper entries — rare: the worst
+// case of a four-wide tree is three per level — in a per-thread HBM column (DScene::spill, entry
+// k at spill[k * spill_stride]).  SPILL = false: the host guarantees BVH4::stack_need <= N_LDS
+// (bf_bvh.h) and the overflow path is compiled out.
 template <int N_LDS, bool SPILL>
 struct LaneStack {
     int *lds;
@@ -136,6 +137,15 @@ struct LaneStack {
     }
     BF_DEV int pop_or_none() { return sp ? pop() : kNoNode; }
 };
+template <int N_LDS, bool SPILL>
+BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
+    LaneStack<N_LDS, SPILL> st;
+    st.lds = lds_column;
+    st.spill = sc.spill + ((size_t) blockIdx.x * kBlock + threadIdx.x);
+    st.spill_stride = sc.spill_stride;
+    st.sp = 0;
+    return st;
+}
 
 // Visit internal node `node`: test its (up to) four child boxes against the ray segment
 // [mint, tmax], push the hit children far-to-near and return the nearest one (or the next
@@ -182,7 +192,7 @@ BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, flo
 // Scene::ray_intersect / ray_test — src/librender/scene.cpp:129-178.
 // `stack` points at this lane's column of the workgroup's LDS stack
 // (entry k at stack[k * kBlock], kStackDepth entries).
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool SPILL>
 BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
                      uint32_t &n_tris) {
     best.t = BF_INF;
@@ -202,7 +212,7 @@ BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *
 
     V3 id, oid;
     ray_inverse(o, d, id, oid);
-    LaneStack<kStackDepth, false> st = {stack, nullptr, 0u, 0};
+    LaneStack<kStackDepth, SPILL> st = make_stack<kStackDepth, SPILL>(sc, stack);
     int node = sc.root;
     while (node != kNoNode) {
         if (node >= 0) {

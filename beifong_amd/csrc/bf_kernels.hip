@@ -26,7 +26,7 @@ namespace bfd {
 // slot of the wavefront queue (state + the closest hit already traced for it)
 // and runs that path to completion here, instead of paying two launches per
 // bounce for a nearly empty chip.
-template <bool STATS, bool RESUME>
+template <bool STATS, bool RESUME, bool SPILL>
 __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
         if (RESUME && alive && resume_first) {
             hit = resume_hit;              // traced (and counted) by wf_trace already
         } else if (alive && !term_pending) {
-            traverse<false, STATS>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
+            traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
             ++c_closest;
         }
         if (alive) resume_first = false;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
         if (__ballot(sh.want)) {
             if (sh.want) {
                 Hit tmp;
-                bool occluded = traverse<true, STATS>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris);
+                bool occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris);
                 ++c_shadow;
                 if (!occluded) s.result += sh.c;
             }
@@ -207,23 +207,23 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
 }
 
 // Scene::ray_intersect / ray_test over a batch of rays (tests, tools)
+template <bool SPILL>
 __global__ __launch_bounds__(kBlock) void bf_trace_kernel(DScene sc, uint64_t n, const float *__restrict__ rays,
                                                           int any_hit, float *__restrict__ out_t,
                                                           uint32_t *__restrict__ out_prim, uint32_t *__restrict__ out_shape,
                                                           float *__restrict__ out_uv, uint8_t *__restrict__ out_hit) {
     __shared__ int s_stack[kStackDepth * kBlock];
     int *stack = s_stack + threadIdx.x;
-    uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
     const float *r = rays + 8 * i;
     V3 o = mk(r[0], r[1], r[2]), d = mk(r[4], r[5], r[6]);
     float mint = r[3], maxt = r[7];
     Hit h;
     uint32_t a = 0, b = 0;
     if (any_hit) {
-        out_hit[i] = traverse<true, false>(sc, o, d, mint, maxt, stack, h, a, b) ? 1 : 0;
+        out_hit[i] = traverse<true, false, SPILL>(sc, o, d, mint, maxt, stack, h, a, b) ? 1 : 0;
     } else {
-        bool valid = traverse<false, false>(sc, o, d, mint, maxt, stack, h, a, b);
+        bool valid = traverse<false, false, SPILL>(sc, o, d, mint, maxt, stack, h, a, b);
         if (out_t) out_t[i] = h.t;
         if (out_prim) out_prim[i] = valid ? h.prim : 0xffffffffu;
         if (out_shape) {
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void bf_trace_kernel(DScene sc, uint64_t n,
             out_uv[2 * i + 1] = h.v;
         }
     }
+    }
 }
 
 }  // namespace bfd
@@ -246,12 +247,17 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
                                         hipStream_t stream) {
     bfd::WF none;
     memset(&none, 0, sizeof(none));
-    if (stats)
-        hipLaunchKernelGGL((bfd::bf_render_kernel<true, false>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,
-                           g_hist, records, counters, none, 0u);
-    else
-        hipLaunchKernelGGL((bfd::bf_render_kernel<false, false>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,
-                           g_hist, records, counters, none, 0u);
+    const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
+#define BF_RENDER_LAUNCH(S, R, P, WF_, IT_)                                                                                  \
+    hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
+                       records, counters, WF_, IT_)
+    if (stats) {
+        if (spill) BF_RENDER_LAUNCH(true, false, true, none, 0u);
+        else BF_RENDER_LAUNCH(true, false, false, none, 0u);
+    } else {
+        if (spill) BF_RENDER_LAUNCH(false, false, true, none, 0u);
+        else BF_RENDER_LAUNCH(false, false, false, none, 0u);
+    }
     return hipGetLastError();
 }
 
@@ -260,14 +266,20 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
                                       hipStream_t stream) {
     // one lane per live slot (gathered from the alive masks), at most one thread per pool slot
+    // (any grid finishes the job: waves loop over their segment of the alive masks; the cap keeps the
+    // launch within the scene's traversal-spill columns)
     unsigned grid = (std::min(n_slots, wf->n_slots) + bfd::kBlock - 1) / bfd::kBlock;
+    grid = std::min(grid, sc->spill_stride / bfd::kBlock);
     if (grid == 0) return hipSuccess;
-    if (stats)
-        hipLaunchKernelGGL((bfd::bf_render_kernel<true, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,
-                           g_hist, records, wf->counters, *wf, it);
-    else
-        hipLaunchKernelGGL((bfd::bf_render_kernel<false, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,
-                           g_hist, records, wf->counters, *wf, it);
+    const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
+    unsigned long long *counters = wf->counters;
+    if (stats) {
+        if (spill) BF_RENDER_LAUNCH(true, true, true, *wf, it);
+        else BF_RENDER_LAUNCH(true, true, false, *wf, it);
+    } else {
+        if (spill) BF_RENDER_LAUNCH(false, true, true, *wf, it);
+        else BF_RENDER_LAUNCH(false, true, false, *wf, it);
+    }
     return hipGetLastError();
 }
 
@@ -302,9 +314,13 @@ extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, 
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
                                        hipStream_t stream) {
-    unsigned grid = (unsigned) ((n + bfd::kBlock - 1) / bfd::kBlock);
+    unsigned grid = (unsigned) std::min<uint64_t>((n + bfd::kBlock - 1) / bfd::kBlock, sc->spill_stride / bfd::kBlock);
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(bfd::bf_trace_kernel, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, n, rays, any_hit, out_t,
+    if (sc->stack_need > (uint32_t) bfd::kStackDepth)
+        hipLaunchKernelGGL(bfd::bf_trace_kernel<true>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, n, rays, any_hit, out_t,
+                           out_prim, out_shape, out_uv, out_hit);
+    else
+        hipLaunchKernelGGL(bfd::bf_trace_kernel<false>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, n, rays, any_hit, out_t,
                        out_prim, out_shape, out_uv, out_hit);
     return hipGetLastError();
 }

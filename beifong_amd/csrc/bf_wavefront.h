@@ -23,7 +23,6 @@ namespace bfd {
 constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce live counters
 constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
-constexpr uint32_t kSpillDepth = 16;    // stack entries beyond the 16 kept in LDS (tree depth <= 31)
 constexpr uint32_t kTraceBlocksPerCU = 8;
 
 struct WF {
@@ -45,7 +44,6 @@ struct WF {
     unsigned long long *m_alive[2];
     unsigned long long *m_trace[2];
     unsigned long long *m_shadow[2];
-    int *spill;                     // traversal-stack overflow: [kSpillDepth][max trace threads]
     uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)

@@ -256,9 +256,8 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
     const int lane = threadIdx.x & 63;
     const int nxt = (it & 1) ^ 1;
     uint32_t c_nodes = 0, c_tris = 0;
-    const uint32_t n_threads = gridDim.x * kBlock;
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    LaneStack<kLdsStack, true> st = {stack, wf.spill + (blockIdx.x * kBlock + threadIdx.x), n_threads, 0};
+    LaneStack<kLdsStack, true> st = make_stack<kLdsStack, true>(sc, stack);
     const uint32_t n_batches = wf.n_slots >> 6;
     const uint32_t per = (n_batches + n_waves - 1) / n_waves;
     const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);

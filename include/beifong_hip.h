@@ -219,6 +219,8 @@ typedef struct bf_scene_info {
     uint32_t node_bytes, tri_bytes;
     uint64_t device_bytes;
     float bbox_min[3], bbox_max[3];
+    uint32_t bvh_depth;       /* levels of the four-wide tree                  */
+    uint32_t bvh_stack_need;  /* worst-case traversal stack entries (<= 31)    */
 } bf_scene_info;
 
 /* ---------------- entry points --------------------------------------------- */

@@ -24,4 +24,6 @@ for name, flags in (("wavefront", 0), ("megakernel", capi.BF_FLAG_MEGAKERNEL)):
         t = time.time(); h, _, st = g.render(lp); dt = time.time() - t
         best = min(best, st.kernel_ms)
     rays = st.n_rays_closest + st.n_rays_shadow
+    if os.environ.get("SPLIT"):
+        print(f"           shade {st.shade_ms:6.2f}  trace {st.trace_ms:6.2f}  tail {st.tail_ms:6.2f}  iters {st.n_bounce_iters}")
     print(f"{name:10s} kernel {best:8.2f} ms  wall {dt*1e3:8.2f} ms  rays {rays}  {rays/best/1e3:8.1f} Mrays/s  {n_paths/best/1e3:8.1f} Mpaths/s", flush=True)
