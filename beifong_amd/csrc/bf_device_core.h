@@ -191,10 +191,11 @@ BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, flo
 
 // Scene::ray_intersect / ray_test — src/librender/scene.cpp:129-178.
 // `stack` points at this lane's column of the workgroup's LDS stack
-// (entry k at stack[k * kBlock], kStackDepth entries).
-template <bool ANY, bool STATS, bool SPILL>
-BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
-                     uint32_t &n_tris) {
+// (entry k at stack[k * kBlock], kStackDepth entries).  `any` may differ between the lanes of a
+// wave (closest-hit and any-hit queries share the traversal loop).
+template <bool STATS, bool SPILL>
+BF_DEV bool traverse_dyn(const DScene &sc, bool any, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
+                         uint32_t &n_tris) {
     best.t = BF_INF;
     best.u = best.v = 0.f;
     best.prim = 0;
@@ -204,7 +205,7 @@ BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *
         const DRect &rc = sc.rects[i];
         float t, lx, ly;
         if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
-            if (ANY) return true;
+            if (any) return true;
             consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
         }
     }
@@ -217,13 +218,18 @@ BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *
     while (node != kNoNode) {
         if (node >= 0) {
             if (STATS) ++n_nodes;
-            node = node4_step(sc.nodes, node, id, oid, mint, ANY ? maxt : __builtin_fminf(maxt, best.t), st);
+            node = node4_step(sc.nodes, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
         } else {
-            if (leaf_intersect<STATS>(sc, node, ANY, o, d, mint, maxt, best, n_tris)) return true;
+            if (leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, n_tris)) return true;
             node = st.pop_or_none();
         }
     }
     return best.t != BF_INF;
+}
+template <bool ANY, bool STATS, bool SPILL>
+BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
+                     uint32_t &n_tris) {
+    return traverse_dyn<STATS, SPILL>(sc, ANY, o, d, mint, maxt, stack, best, n_nodes, n_tris);
 }
 
 // ---------------------------------------------------------------------------

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
     const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
 
     bool alive = false, done = false;
+    bool need_closest = false;     // s holds a ray whose hit is not known yet
+    bool film = false;             // the path ended at the last shaded vertex; binned after its shadow ray
+    ShadowReq sh;
+    sh.want = false;
+    Hit hit;
+    hit.t = BF_INF;
+    hit.u = hit.v = 0.f;
+    hit.prim = 0;
+    hit.slot = 0;
     PathState s;
     s.flags = 0;
     s.rmint = 0.f;
@@ -53,12 +62,6 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
     // wave-local pool of path indices (uniform across the wave)
     uint64_t pool_next = 0, pool_end = 0;
 
-    Hit resume_hit;
-    resume_hit.t = BF_INF;
-    resume_hit.u = resume_hit.v = 0.f;
-    resume_hit.prim = 0;
-    resume_hit.slot = 0;
-    bool resume_first = false;
     // RESUME: this wave's segment of the pool's alive mask; lanes adopt live slots
     // from it whenever they are free (same on-the-fly compaction as wf_shade)
     uint32_t resume_slots = 0;
@@ -86,14 +89,15 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
                 if (rank < got) {
                     load_state(wf, slot, receive, s);
                     alive = true;
-                    resume_first = false;
+                    need_closest = false;          // traced (and counted) by wf_trace already
+                    film = false;
                     if (!(s.flags & kFlagTermPending)) {
                         float4 hq = wf.hit[slot];
-                        resume_hit.t = hq.x;
-                        resume_hit.u = hq.y;
-                        resume_hit.v = hq.z;
-                        resume_hit.slot = __float_as_int(hq.w);
-                        resume_first = true;
+                        hit.t = hq.x;
+                        hit.u = hq.y;
+                        hit.v = hq.z;
+                        hit.slot = __float_as_int(hq.w);
+                        hit.prim = 0;
                     }
                 } else {
                     done = true;       // the segment has no live slot left for this lane
@@ -123,59 +127,99 @@ __global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch
                 } else {
                     generate_path(sc, lp, path_i, s);
                     alive = true;
+                    need_closest = true;
+                    film = false;
                 }
             }
         }
         if (__ballot(alive) == 0ull) break;
 
-        // ---- 2. closest-hit traversal for every live lane ------------------
-        Hit hit;
-        hit.t = BF_INF;
-        hit.u = hit.v = 0.f;
-        hit.prim = 0;
-        hit.slot = 0;
-        const bool term_pending = alive && (s.flags & kFlagTermPending);
-        if (RESUME && alive && resume_first) {
-            hit = resume_hit;              // traced (and counted) by wf_trace already
-        } else if (alive && !term_pending) {
-            traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
-            ++c_closest;
-        }
-        if (alive) resume_first = false;
-
-        // ---- 3. vertex logic --------------------------------------------------
-        ShadowReq sh;
-        sh.want = false;
-        bool film = false;
-        if (alive) {
-            if (term_pending) {
-                film = true;
-            } else if (!shade_vertex(sc, lp, s, hit, sh, c_bounces)) {
-                film = true;
+        // ---- 2. traversal phase ------------------------------------------------------
+        // Every lane may hold a closest-hit ray (new path, or the continuation ray of the vertex it
+        // shaded last iteration) and a shadow ray (NEE of that same vertex).  The two are independent,
+        // so lanes that have nothing to trace (their path is over, or the wave's paths have run out —
+        // the normal state of the latency-bound tail) take over shadow rays of busy lanes: the wave
+        // walks the BVH once per bounce instead of twice.
+        const bool term_pending = alive && (s.flags & kFlagTermPending) != 0;
+        const bool trace_closest = alive && need_closest && !term_pending;
+        const unsigned long long want_mask = __ballot(sh.want);
+        bool occluded = false;
+        if (want_mask) {
+            const unsigned long long free_mask = __ballot(!trace_closest && !sh.want);
+            const uint32_t n_del = min((uint32_t) __popcll(want_mask), (uint32_t) __popcll(free_mask));
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t want_rank = (uint32_t) __popcll(want_mask & below), free_rank = (uint32_t) __popcll(free_mask & below);
+            const bool delegated = sh.want && want_rank < n_del;
+            const bool helper = !trace_closest && !sh.want && free_rank < n_del;
+            // helper f serves the f-th requester; requester r is served by the r-th free lane
+            const int src = helper ? (int) nth_set_bit(want_mask, free_rank) : lane;
+            V3 ho = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
+            V3 hd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
+            const float hmint = __shfl(sh.mint, src), hmaxt = __shfl(sh.maxt, src);
+            // first walk: closest-hit rays, delegated shadow rays (on their helpers), and the own shadow
+            // ray of a lane that has no closest-hit ray to trace
+            const bool own_first = sh.want && !delegated && !trace_closest;
+            const bool any1 = helper || own_first;
+            bool r1 = false;
+            if (trace_closest || any1) {
+                V3 o1 = trace_closest ? s.ro : ho, d1 = trace_closest ? s.rd : hd;
+                float mint1 = trace_closest ? s.rmint : hmint, maxt1 = trace_closest ? s.rmaxt : hmaxt;
+                Hit h1;
+                r1 = traverse_dyn<STATS, SPILL>(sc, any1, o1, d1, mint1, maxt1, stack, h1, c_nodes, c_tris);
+                if (trace_closest) {
+                    hit = h1;
+                    ++c_closest;
+                } else {
+                    ++c_shadow;
+                }
+            }
+            const unsigned long long helper_occluded = __ballot(helper && r1);
+            if (delegated) occluded = (helper_occluded >> nth_set_bit(free_mask, want_rank)) & 1ull;
+            if (own_first) occluded = r1;
+            // second walk: lanes that had both rays and found no helper
+            const bool own_second = sh.want && !delegated && trace_closest;
+            if (__ballot(own_second)) {
+                if (own_second) {
+                    Hit tmp;
+                    occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris);
+                    ++c_shadow;
+                }
+            }
+            if (sh.want && !occluded) s.result += sh.c;     // Scene::ray_test == false (scene.cpp:220-224)
+            sh.want = false;
+        } else if (__ballot(trace_closest)) {
+            if (trace_closest) {
+                traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
+                ++c_closest;
             }
         }
+        if (trace_closest) need_closest = false;
 
-        // ---- 4. shadow (any-hit) traversal -------------------------------------
-        if (__ballot(sh.want)) {
-            if (sh.want) {
-                Hit tmp;
-                bool occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris);
-                ++c_shadow;
-                if (!occluded) s.result += sh.c;
-            }
-        }
-
-        // ---- 5. film -----------------------------------------------------------------
-        if (alive && (film || (s.flags & kFlagTermPending))) {
+        // ---- 3. film: paths that ended at the vertex shaded last iteration (their last shadow ray
+        //         has resolved by now) ---------------------------------------------------------------
+        if (alive && (film || term_pending)) {
             film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
             alive = false;
+            film = false;
             if (RESUME) {
                 // the slot's static path sequence: i, i + n_slots, i + 2 n_slots, ...
                 uint64_t next_path = s.path_i + resume_slots;
                 if (next_path < lp.n_paths) {
                     generate_path(sc, lp, next_path, s);
                     alive = true;
+                    need_closest = true;
                 }
+            }
+        }
+
+        // ---- 4. vertex logic for the lanes that hold a fresh hit ---------------------------------
+        if (alive && !need_closest) {
+            if (!shade_vertex(sc, lp, s, hit, sh, c_bounces)) {
+                film = true;                                   // ended at the head of the iteration: no new rays
+            } else if (s.flags & kFlagTermPending) {
+                film = true;                                   // ended by the BSDF sample: its NEE ray is still to trace
+            } else {
+                need_closest = true;
             }
         }
     }
