@@ -27,7 +27,7 @@ namespace bfd {
 // and runs that path to completion here, instead of paying two launches per
 // bounce for a nearly empty chip.
 template <bool STATS, bool RESUME, bool SPILL>
-__global__ __launch_bounds__(kBlock, 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
+__global__ __launch_bounds__(kBlock, RESUME ? 2 : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
     extern __shared__ __align__(16) unsigned char s_raw[];
