@@ -223,6 +223,32 @@ def motorbike(n_tris=300_000, seed=5):
     return v, f
 
 
+def vertex_normals(verts, faces):
+    """Angle-weighted vertex normals (Thuermer & Wuethrich) — what Mesh::recompute_vertex_normals
+    (mesh.cpp:201-249) gives an OBJ / PLY file that carries none, e.g. a raw 3-D scan."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    p = [v[f[:, k]] for k in range(3)]
+    fn = np.cross(p[1] - p[0], p[2] - p[0])
+    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+    ok = ln[:, 0] > 0
+    fn[ok] /= ln[ok]
+    n = np.zeros_like(v)
+    for j in range(3):
+        a = p[(j + 1) % 3] - p[j]
+        b = p[(j + 2) % 3] - p[j]
+        c = np.einsum("ij,ij->i", a, b) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
+        ang = np.arccos(np.clip(c, -1.0, 1.0))
+        ang[~ok] = 0.0
+        np.add.at(n, f[:, j], fn * ang[:, None])
+    l = np.linalg.norm(n, axis=1, keepdims=True)
+    bad = l[:, 0] == 0
+    l[bad] = 1.0
+    n /= l
+    n[bad] = (1.0, 0.0, 0.0)
+    return n.astype(f32)
+
+
 def place(v, yaw_deg=0.0, translate=(0, 0, 0), scale=1.0):
     return _transform(v.astype(np.float64), yaw_deg, translate, scale)
 

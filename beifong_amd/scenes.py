@@ -32,16 +32,16 @@ def trans_rad(spp=16):
     return sd, launch
 
 
-def _radar_frontend(sd, radiance=1000.0, yaw_deg=0.0):
+def _radar_frontend(sd, radiance=1000.0, yaw_deg=0.0, position=(0.0, 0.0, 0.3)):
     """Monostatic front end of Render.py:196-271: a 20 x 50 mm TX aperture at
     (0,0,0.3) looking +x carrying an area emitter (gen-2 stand-in for the
     wignertransmitter), and a perspective RX at the same position.  `yaw_deg` turns the radar about
     the vertical axis like the frame loop of animated_trans_rad.py:307-373 turns sensor and emitter."""
     d0 = T.rotate([0, 0, 1], yaw_deg) * T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)        # txa_d0 = align_x * align_z
     tx_mat = sd.add_diffuse(0.0)                                  # emitter shape: rho = 0 (shape.cpp:89-98)
-    txa = sd.add_rectangle(T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1]), tx_mat)
+    txa = sd.add_rectangle(T.translate(list(position)) * d0 * T.scale([20e-3, 50e-3, 1]), tx_mat)
     sd.add_area_emitter(txa, radiance)
-    sd.set_perspective(T.translate([0, 0, 0.3]) * d0, fov=45.0, near_clip=0.1, far_clip=100.0)
+    sd.set_perspective(T.translate(list(position)) * d0, fov=45.0, near_clip=0.1, far_clip=100.0)
 
 
 def _ground(sd):
@@ -50,21 +50,26 @@ def _ground(sd):
 
 
 def bus_mesh(n_tris=200_000):
-    """The placed bus mesh of C2 as contiguous arrays (reusable across the frames of a sweep)."""
+    """The placed bus mesh of C2 as contiguous arrays (reusable across the frames of a sweep):
+    positions, faces and the vertex normals the `obj` loader computes for a scan without `vn` lines
+    (Render.py:386-392 loads Bus.obj through src/shapes/obj.cpp; mesh.cpp:201-249)."""
     v, f = meshgen.bus(n_tris, seed=1)
     # car_trafo Render.py:305-316: translate(10,3,1) * yaw(-20) (scan-axis alignment folded into the generator)
     v = meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7))
-    return np.ascontiguousarray(v, dtype=np.float32), np.ascontiguousarray(f, dtype=np.uint32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    return v, f, np.ascontiguousarray(meshgen.vertex_normals(v, f))
 
 
-def bus_radar(n_tris=200_000, n_paths=64, bins=256, dr=0.1, seed=1, radar_yaw_deg=0.0, mesh=None):
+def bus_radar(n_tris=200_000, n_paths=64, bins=256, dr=0.1, seed=1, radar_yaw_deg=0.0, mesh=None,
+              radar_position=(0.0, 0.0, 0.3)):
     """C2: Bus.obj-class monostatic radar scene, gen-2 `range` o `pathlength`."""
     sd = SceneDesc()
-    _radar_frontend(sd, yaw_deg=radar_yaw_deg)
+    _radar_frontend(sd, yaw_deg=radar_yaw_deg, position=radar_position)
     _ground(sd)
     car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)   # B_CAR :353-363
-    v, f = mesh if mesh is not None else bus_mesh(n_tris)
-    sd.add_mesh(v, f, car)
+    v, f, n = mesh if mesh is not None else bus_mesh(n_tris)
+    sd.add_mesh(v, f, car, normals=n)
     sd.finalize()
     launch = capi.make_launch(capi.BF_MODE_RANGE, n_paths, seed=seed, bins=bins, bin_width=dr, color_mode=capi.BF_COLOR_RGB)
     return sd, launch

@@ -370,15 +370,9 @@ def test_update_endpoints_equals_fresh_scene(hiplib):
     sd_other, _ = scenes.trans_rad(spp=16)
     with pytest.raises(capi.BeifongError):
         g.update_endpoints(sd_other)                      # different layout
-    sd_far = SceneDesc()
-    scenes._radar_frontend(sd_far)
-    scenes._ground(sd_far)
-    m = sd_far.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
-    sd_far.add_mesh(mesh[0], mesh[1], m)
-    sd_far.add_rectangle(Transform4f.translate([5000.0, 0, 0]), m)
-    sd_far.finalize()
-    with pytest.raises(capi.BeifongError):
-        g.update_endpoints(sd_far)
+    sd_far, _ = scenes.bus_radar(n_paths=20000, mesh=mesh, radar_position=(5000.0, 0.0, 0.3))
+    with pytest.raises(capi.BeifongError, match="padded"):
+        g.update_endpoints(sd_far)                        # same layout, but outside the bound the boxes allow for
 
 
 def test_render_sweep_reuses_device_scenes(hiplib):

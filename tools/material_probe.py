@@ -11,7 +11,7 @@ for name, gnd_kind, bus_kind in (("mixed", "d", "c"), ("all diffuse", "d", "d"),
     def mat(kind):
         return sd.add_diffuse(0.5, twosided=True) if kind == "d" else sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
     sd.add_rectangle(T.translate([0, 0, 0]) * T.scale([20, 20, 1]), mat(gnd_kind))
-    sd.add_mesh(mesh[0], mesh[1], mat(bus_kind))
+    sd.add_mesh(mesh[0], mesh[1], mat(bus_kind), normals=mesh[2])
     sd.finalize()
     lp = capi.make_launch(capi.BF_MODE_RANGE, 1 << 24, seed=1, bins=256, bin_width=0.1, color_mode=capi.BF_COLOR_RGB)
     g = capi.Scene(sd)
