@@ -103,6 +103,7 @@ struct bf_scene {
     mutable bfd::WF wf;
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
+    bfd::DSensor sensor_host;              // host copy of the device sensor record
     float origin_scale_built = 0.f;        // ray-origin bound the BVH boxes were padded for (bf_bvh.h)
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
@@ -369,7 +370,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     std::memset(&sc->d, 0, sizeof(sc->d));
     std::memset(&sc->info, 0, sizeof(sc->info));
     std::memset(&sc->wf, 0, sizeof(sc->wf));
-    sc->d.sensor = flat.sensor;
+    sc->sensor_host = flat.sensor;
     sc->origin_scale_built = origin_scale;
     bf::BVH bvh;
     bf::build_bvh(btris, bvh, origin_scale);
@@ -440,6 +441,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(shapes, shapes);
     UP(mats, materials);
     UP(emitters, emitters);
+    std::vector<bfd::DSensor> sensor_vec(1, flat.sensor);
+    UP(sensor_vec, sensor);
 #undef UP
     sc->n_materials = desc->n_materials;
     sc->d.n_tris = (uint32_t) btris.size();
@@ -502,7 +505,8 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         HIP_TRY(hipMemcpyAsync((void *) scene->d.emitters, f.emitters.data(), f.emitters.size() * sizeof(bfd::DEmitter), hipMemcpyHostToDevice, stream));
     if (desc->n_materials)
         HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, desc->materials, desc->n_materials * sizeof(bf_material), hipMemcpyHostToDevice, stream));
-    scene->d.sensor = f.sensor;          // passed to the kernels by value with every launch
+    HIP_TRY(hipMemcpyAsync((void *) scene->d.sensor, &f.sensor, sizeof(bfd::DSensor), hipMemcpyHostToDevice, stream));
+    scene->sensor_host = f.sensor;
     scene->emitter_types.clear();
     for (const auto &e : f.emitters) scene->emitter_types.push_back(e.type);
     scene->d.c = desc->physics.c;
@@ -742,12 +746,12 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
                            void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
-    const bool is_rx = scene->d.sensor.type == BF_RECEIVER_OMNI || scene->d.sensor.type == BF_RECEIVER_WIGNER;
+    const bool is_rx = scene->sensor_host.type == BF_RECEIVER_OMNI || scene->sensor_host.type == BF_RECEIVER_WIGNER;
     if (launch->mode == BF_MODE_RECEIVE_RAW) {
         if (!is_rx) return fail(BF_ERR_INVALID, "receive mode needs a receiver (omnidirectional / wigner)");
-        if (launch->bins != scene->d.sensor.t_bins || launch->bins_y != scene->d.sensor.f_bins)
+        if (launch->bins != scene->sensor_host.t_bins || launch->bins_y != scene->sensor_host.f_bins)
             return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size (%u x %u)", launch->bins,
-                        launch->bins_y, scene->d.sensor.t_bins, scene->d.sensor.f_bins);
+                        launch->bins_y, scene->sensor_host.t_bins, scene->sensor_host.f_bins);
         for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
             if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER)
                 return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);

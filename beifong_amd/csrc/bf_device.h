@@ -77,7 +77,7 @@ struct DScene {
     uint32_t spill_stride;
     uint32_t stack_need;      // BVH4::stack_need: kernels whose LDS stack holds that many entries compile the overflow path out
     float c, lambda_min, lambda_max;   // MTS_C, MTS_WAVELENGTH_MIN/MAX as run-time physics
-    DSensor sensor;
+    const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
 };
 
 struct DLaunch {

@@ -598,7 +598,7 @@ BF_DEV void srgb_to_xyz_grey(float l, float &X, float &Y, float &Z) {
 // sensor rays: fluxmeter.cpp:63-85, perspective.cpp:172-199
 BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, float ay, V3 &o, V3 &d, float &mint,
                                float &maxt) {
-    const DSensor &s = sc.sensor;
+    const DSensor &s = *sc.sensor;
     if (s.type == BF_SENSOR_FLUXMETER) {
         const DRect &rc = sc.rects[s.rect];
         o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));

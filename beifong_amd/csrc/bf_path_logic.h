@@ -253,7 +253,7 @@ BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p
 // Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
 BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
                                  float &mint, float &maxt, float &lambda0) {
-    const DSensor &s = sc.sensor;
+    const DSensor &s = *sc.sensor;
     const DRect &rc = sc.rects[s.rect];
     o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
     V3 local = square_to_cosine_hemisphere(ax, ay);
@@ -293,9 +293,9 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
         // receive_sample — integrator.cpp:1544-1572
         ax = next_1d(s.rng);
         ay = next_1d(s.rng);
-        float time = sc.sensor.adc_sampling_start;
-        if (sc.sensor.adc_sampling_time > 0.f)
-            time += next_1d(s.rng) * sc.sensor.adc_sampling_time;
+        float time = sc.sensor->adc_sampling_start;
+        if (sc.sensor->adc_sampling_time > 0.f)
+            time += next_1d(s.rng) * sc.sensor->adc_sampling_time;
         else
             time = 0.f;
         float wl = next_1d(s.rng);
@@ -305,11 +305,11 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
     } else {
         // render_sample — integrator.cpp:263-283
-        if (sc.sensor.type != BF_SENSOR_PERSPECTIVE) {   // endpoint.h:241, perspective.cpp:130
+        if (sc.sensor->type != BF_SENSOR_PERSPECTIVE) {   // endpoint.h:241, perspective.cpp:130
             ax = next_1d(s.rng);
             ay = next_1d(s.rng);
         }
-        if (sc.sensor.shutter_open_time > 0.f) (void) next_1d(s.rng);
+        if (sc.sensor->shutter_open_time > 0.f) (void) next_1d(s.rng);
         (void) next_1d(s.rng);     // wavelength sample (consumed in RGB mode too)
         (void) sensor_sample_ray(sc, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
         // ImageBlock::put box branch: lo = ceil(pos - .5 - .5) must be 0 for the 1x1 film
@@ -491,7 +491,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
     float rec_L, rec_aux;
     if (lp.mode == BF_MODE_RECEIVE_RAW) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
-        const DSensor &se = sc.sensor;
+        const DSensor &se = *sc.sensor;
         float tf0 = s.t_rx - se.adc_sampling_start;
         float tf1 = freq_of(sc.c, s.lambda0);
         tf0 *= (float) se.t_bins / se.t_bandwidth;
@@ -539,7 +539,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         rec_aux = s.t_rx - se.adc_sampling_start;
     } else {
         const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
-        const float sensor_w = sc.sensor.type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
+        const float sensor_w = sc.sensor->type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
         float L = sensor_w * s.result;                        // integrator.cpp:286
         float X, Y, Z;
         if (lp.color_mode == BF_COLOR_RGB)
