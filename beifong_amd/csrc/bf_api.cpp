@@ -591,6 +591,8 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         const char *e1 = getenv("BF_TRACE_REFILL"), *e2 = getenv("BF_TRACE_STRAGGLERS");
         wf.trace_refill = e1 ? (uint32_t) atoi(e1) : bfd::kTraceRefill;
         wf.trace_stragglers = e2 ? (uint32_t) atoi(e2) : bfd::kTraceStragglers;
+        const char *e3 = getenv("BF_SHADE_CHAIN");
+        wf.shade_chain = std::max(1, e3 ? atoi(e3) : (int) bfd::kShadeChain);
     }
     const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce

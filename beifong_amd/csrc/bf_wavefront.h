@@ -21,6 +21,7 @@
 namespace bfd {
 
 constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce live counters
+constexpr uint32_t kShadeChain = 3;
 constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
 constexpr uint32_t kTraceBlocksPerCU = 8;
@@ -47,6 +48,7 @@ struct WF {
     uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)
+    uint32_t shade_chain;                      // wf_shade: vertices a lane may shade per visit while its rays resolve early
     uint32_t n_slots;               // slots in use this render (multiple of 64)
     uint32_t capacity;              // slots allocated
 };

@@ -131,68 +131,107 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         PathState s;
         ShadowReq sh;
         sh.want = false;
-        bool need_gen = false, cont = false;
-        uint64_t prev_path = 0;
+        bool need_gen = false, cont = false, have_hit = false;
+        Hit hit;
+        hit.t = BF_INF;
+        hit.u = hit.v = 0.f;
+        hit.prim = 0;
+        hit.slot = 0;
 
         if (has) {
             if (FIRST) {
                 need_gen = true;
             } else {
                 load_state(wf, slot, receive, s);
-                prev_path = s.path_i;
                 if (s.flags & kFlagTermPending) {
                     // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
                     film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else {
                     float4 hq = wf.hit[slot];
-                    Hit hit;
                     hit.t = hq.x;
                     hit.u = hq.y;
                     hit.v = hq.z;
                     hit.slot = __float_as_int(hq.w);
-                    hit.prim = 0;
-                    cont = shade_vertex(sc, lp, s, hit, sh, c_bounces);
-                    if (!cont) {
-                        film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
-                        need_gen = true;
-                    } else if (!(s.flags & kFlagTermPending)) {
-                        ++c_closest;
-                    }
-                    if (sh.want) ++c_shadow;
+                    have_hit = true;
                 }
             }
         }
-        // ---- regeneration: slot i renders paths i, i + n_slots, i + 2 n_slots, ... --------
-        // (static assignment: no device-wide path counter to serialise on)
-        if (need_gen) {
-            uint64_t path_i = FIRST ? (uint64_t) slot : prev_path + wf.n_slots;
-            if (path_i < lp.n_paths) {
-                generate_path(sc, lp, path_i, s);
-                ++c_closest;
-                cont = true;
+        // Chained shading: a lane whose new rays are both answered by the early resolution below
+        // (rectangle hit or miss of the mesh, NEE ray clear of the mesh) needs no trace launch, so it
+        // shades its next vertex — or starts its next path — right away, up to wf.shade_chain rounds per
+        // visit.  Two thirds of all rays resolve that way; each chained round saves a state round trip
+        // through HBM and, for paths that leave the scene, a whole bounce iteration.
+        bool settled = !has;          // this lane's outcome for the launch is final
+        bool tracing = false, shadowing = false;
+        for (uint32_t round = 0;; ++round) {
+            // ---- vertex logic ---------------------------------------------------------------
+            if (!settled && have_hit) {
+                have_hit = false;
+                cont = shade_vertex(sc, lp, s, hit, sh, c_bounces);
+                if (!cont) {
+                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+                    need_gen = true;
+                } else if (!(s.flags & kFlagTermPending)) {
+                    ++c_closest;
+                }
+                if (sh.want) ++c_shadow;
+            }
+            // ---- regeneration: slot i renders paths i, i + n_slots, i + 2 n_slots, ... --------
+            // (static assignment: no device-wide path counter to serialise on)
+            if (!settled && need_gen) {
+                need_gen = false;
+                cont = false;
+                uint64_t path_i = (FIRST && round == 0) ? (uint64_t) slot : s.path_i + wf.n_slots;
+                if (path_i < lp.n_paths) {
+                    generate_path(sc, lp, path_i, s);
+                    sh.want = false;
+                    ++c_closest;
+                    cont = true;
+                }
+            }
+            // ---- early resolution of the new rays ---------------------------------------------
+            if (!settled) {
+                tracing = cont && !(s.flags & kFlagTermPending);
+                shadowing = cont && sh.want;
+                if (shadowing) {
+                    Hit tmp;
+                    bool found;
+                    if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
+                        if (!found) s.result += sh.c;        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
+                        shadowing = false;
+                    }
+                    sh.want = shadowing;
+                }
+                if (tracing) {
+                    bool found;
+                    tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found);
+                }
+            }
+            // ---- chain or settle ----------------------------------------------------------------
+            const bool resolved = !settled && cont && !tracing && !shadowing;
+            const bool chain = resolved && round + 1u < wf.shade_chain;
+            if (!__any(chain)) break;
+            if (chain) {
+                if (s.flags & kFlagTermPending) {
+                    // the path ended at its last BSDF sample and its NEE ray is answered: bin it now
+                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+                    need_gen = true;
+                    cont = false;
+                } else {
+                    have_hit = true;                    // `hit` is the final answer of the continuation ray
+                }
+            } else {
+                settled = true;
             }
         }
-        // ---- early resolution of the new rays, write back in place -----------------------
-        bool tracing = cont && !(s.flags & kFlagTermPending);
-        bool shadowing = cont && sh.want;
-        if (shadowing) {
-            Hit tmp;
-            bool found;
-            if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
-                if (!found) s.result += sh.c;        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
-                shadowing = false;
+        // ---- write back in place ----------------------------------------------------------------
+        if (has && cont) {
+            if (!(s.flags & kFlagTermPending)) {
+                // resolved rays carry their final hit; the others start wf_trace from the rectangle hit
+                wf.hit[slot] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
+                wf.hit_prim[slot] = hit.prim;
             }
-        }
-        if (tracing) {
-            Hit best;
-            bool found;
-            tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, best, found);
-            // resolved rays get their final hit here; the others start wf_trace from the rectangle hit
-            wf.hit[slot] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
-            wf.hit_prim[slot] = best.prim;
-        }
-        if (cont) {
             store_state(wf, slot, receive, s);
             ++c_live;
             if (shadowing) {
@@ -201,6 +240,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 wf.sh2[slot] = sh.c;
             }
         }
+        cont = has && cont;
+        tracing = cont && tracing;
+        shadowing = cont && shadowing;
         publish_masks(m_alive, aligned, batch0, slot, has, cont);
         publish_masks(m_trace, aligned, batch0, slot, has, tracing);
         publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
@@ -398,13 +440,12 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
 extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
                                    hipStream_t stream, int waves) {
-    // `waves`: register budget of the shading kernel (waves per SIMD): 1 = no spills, 2..4 trade
-    // scratch spills of the fp64 transcendental code for occupancy
+    // `waves`: register budget of the shading kernel (waves per SIMD); 3 is the sweet spot (168 VGPRs)
 #define BF_SHADE_LAUNCH(F, W)                                                                                             \
     hipLaunchKernelGGL((bfd::wf_shade<F, W>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
                        records)
     if (first) {
-        BF_SHADE_LAUNCH(true, 1);
+        BF_SHADE_LAUNCH(true, 3);
     } else {
         switch (waves) {
             case 2: BF_SHADE_LAUNCH(false, 2); break;
