@@ -13,7 +13,7 @@ bf_launch.path_offset, so the union is one sample set.
 
 Consecutive steps are independent renders (successive coherent processing
 intervals of a pulse sweep), so they are issued round-robin on `--streams`
-HIP streams (default 2, one bf_scene handle each): the latency-bound deep-path
+HIP streams (default 3, one bf_scene handle each): the latency-bound deep-path
 tail of one step overlaps the head of the next.  The timed region carries no
 instrumentation; ray counts and per-kernel HIP-event durations come from an
 instrumented serial pass over the SAME steps (same seeds => same rays), which
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--tris", type=int, default=200_000)
     ap.add_argument("--cpu-paths", type=int, default=1 << 26, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams (scene handles) the steps rotate over")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams (scene handles) the steps rotate over")
     return ap.parse_args()
 
 
