@@ -67,15 +67,15 @@ __global__ __launch_bounds__(kBlock, RESUME ? 2 : 3) void bf_render_kernel(DScen
     uint32_t resume_slots = 0;
     MaskCursor rcur;
     rcur.masks = nullptr;
-    rcur.b = rcur.b_end = 0;
-    rcur.m = 0ull;
+    rcur.b = rcur.b_end = rcur.win = 0;
+    rcur.m = rcur.w = rcur.nz = 0ull;
     if (RESUME) {
         resume_slots = wf.n_slots;
         const uint32_t n_batches = wf.n_slots >> 6;
         const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
         const uint32_t per = (n_batches + n_waves - 1) / n_waves;
         const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
-        cursor_init(rcur, wf.m_alive[wf_it & 1], b0, b1);
+        cursor_init(rcur, wf.m_alive[wf_it & 1], b0, b1, lane);
     }
 
     while (true) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? 2 : 3) void bf_render_kernel(DScen
         if (need && RESUME) {
             uint32_t slot = 0;
             const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
-            const uint32_t got = cursor_take(rcur, (uint32_t) __popcll(need), !alive && !done, rank, slot);
+            const uint32_t got = cursor_take(rcur, (uint32_t) __popcll(need), !alive && !done, rank, slot, lane);
             if (!alive && !done) {
                 if (rank < got) {
                     load_state(wf, slot, receive, s);

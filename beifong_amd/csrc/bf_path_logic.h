@@ -101,32 +101,70 @@ BF_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
     return pos;
 }
 
+// Walks the set bits of a wave's segment of a batch-mask array.  The words are fetched 64 at a
+// time — lane l holds masks[win + l] — so skipping the empty words of a sparse pool costs one
+// coalesced load and a few scalar bit operations per 64 batches instead of one dependent
+// memory round trip per word (which made every late, nearly empty bounce iteration cost
+// 200-400 us whatever little work it held).
 struct MaskCursor {
     const unsigned long long *masks;
     uint32_t b, b_end;          // current / end batch of the segment (wave-uniform)
     unsigned long long m;       // unconsumed bits of batch b (wave-uniform)
+    uint32_t win;               // first batch of the fetched window (wave-uniform)
+    unsigned long long w;       // this lane's word of the window: masks[win + lane]
+    unsigned long long nz;      // wave-uniform: window words that are non-zero and not consumed yet
 };
-BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t b0, uint32_t b1) {
+BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
+    unsigned lo = (unsigned) __shfl((int) (unsigned) v, src), hi = (unsigned) __shfl((int) (unsigned) (v >> 32), src);
+    return ((unsigned long long) hi << 32) | lo;
+}
+// position the cursor on the next non-empty batch at or after the window start (or at the end)
+BF_DEV void cursor_seek(MaskCursor &c, int lane) {
+    while (true) {
+        if (c.nz) {
+            const int k = __ffsll((unsigned long long) c.nz) - 1;
+            c.nz &= c.nz - 1ull;
+            c.b = c.win + (uint32_t) k;
+            c.m = wave_read_u64(c.w, k);
+            return;
+        }
+        c.win += 64u;
+        if (c.win >= c.b_end) {
+            c.b = c.b_end;
+            c.m = 0ull;
+            return;
+        }
+        c.w = (c.win + (uint32_t) lane < c.b_end) ? c.masks[c.win + (uint32_t) lane] : 0ull;
+        c.nz = __ballot(c.w != 0ull);
+    }
+}
+BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t b0, uint32_t b1, int lane) {
     c.masks = masks;
-    c.b = b0;
     c.b_end = b1;
-    c.m = b0 < b1 ? masks[b0] : 0ull;
+    c.win = b0;
+    c.b = b0;
+    c.m = 0ull;
+    c.w = 0ull;
+    c.nz = 0ull;
+    if (b0 >= b1) {
+        c.b = b1;
+        return;
+    }
+    c.w = (b0 + (uint32_t) lane < b1) ? masks[b0 + (uint32_t) lane] : 0ull;
+    c.nz = __ballot(c.w != 0ull);
+    cursor_seek(c, lane);
 }
 BF_DEV bool cursor_empty(const MaskCursor &c) { return c.b >= c.b_end; }
-BF_DEV void cursor_skip_empty(MaskCursor &c) {
-    while (c.b < c.b_end && c.m == 0ull) {
-        ++c.b;
-        c.m = c.b < c.b_end ? c.masks[c.b] : 0ull;
-    }
+BF_DEV void cursor_skip_empty(MaskCursor &c, int lane) {
+    if (c.b < c.b_end && c.m == 0ull) cursor_seek(c, lane);
 }
 // Hands out up to `want` slots: the requesting lane of rank r (0-based among the
 // requesters) receives a slot iff r < return value.  All control flow is uniform.
-BF_DEV uint32_t cursor_take(MaskCursor &c, uint32_t want, bool requesting, uint32_t rank, uint32_t &slot) {
+BF_DEV uint32_t cursor_take(MaskCursor &c, uint32_t want, bool requesting, uint32_t rank, uint32_t &slot, int lane) {
     uint32_t taken = 0;
     while (taken < want && c.b < c.b_end) {
         if (c.m == 0ull) {
-            ++c.b;
-            c.m = c.b < c.b_end ? c.masks[c.b] : 0ull;
+            cursor_seek(c, lane);
             continue;
         }
         uint32_t cnt = (uint32_t) __popcll(c.m);

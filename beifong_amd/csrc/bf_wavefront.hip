@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     const uint32_t per = (n_batches + n_waves - 1) / n_waves;
     const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
     MaskCursor cur_alive;
-    if (!FIRST) cursor_init(cur_alive, wf.m_alive[cur], b0, b1);
+    if (!FIRST) cursor_init(cur_alive, wf.m_alive[cur], b0, b1, lane);
     uint32_t first_b = b0;
 
     while (true) {
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             aligned = true;
             ++first_b;
         } else {
-            cursor_skip_empty(cur_alive);
+            cursor_skip_empty(cur_alive, lane);
             if (cursor_empty(cur_alive)) break;
             const uint32_t batch_before = cur_alive.b;
             const bool whole = __popcll(cur_alive.m) == 64;
-            got = cursor_take(cur_alive, 64u, true, (uint32_t) lane, slot);
+            got = cursor_take(cur_alive, 64u, true, (uint32_t) lane, slot, lane);
             if (got == 0) break;
             aligned = whole && got == 64 && slot == batch_before * 64u + (uint32_t) lane;
             aligned = __all(aligned);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
     const uint32_t per = (n_batches + n_waves - 1) / n_waves;
     const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
     MaskCursor cursor;
-    cursor_init(cursor, wf.m_shadow[nxt], b0, b1);
+    cursor_init(cursor, wf.m_shadow[nxt], b0, b1, lane);
     bool phase_shadow = true;       // wave-uniform: which job list the cursor walks
 
     bool has = false, any = false;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
             while (want && work_left()) {
                 uint32_t slot = 0;
                 const bool req = !has && rank >= served;
-                uint32_t got = cursor_take(cursor, want, req, rank - served, slot);
+                uint32_t got = cursor_take(cursor, want, req, rank - served, slot, lane);
                 if (req && rank - served < got) {
                     job = slot;
                     float4 r0, r1;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 want -= got;
                 if (want && cursor_empty(cursor) && phase_shadow) {
                     phase_shadow = false;                       // shadow rays done: closest-hit rays next
-                    cursor_init(cursor, wf.m_trace[nxt], b0, b1);
+                    cursor_init(cursor, wf.m_trace[nxt], b0, b1, lane);
                 }
             }
         }
