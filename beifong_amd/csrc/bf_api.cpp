@@ -150,6 +150,7 @@ uint32_t bf_launch_channels(const bf_launch *lp) {
         case BF_MODE_RANGE: return 5 + lp->bins;
         case BF_MODE_TIME: return 5 + 3 * lp->bins;
         case BF_MODE_RECEIVE_RAW: return (3 + lp->phase_bins) * lp->bins * lp->bins_y;
+        case BF_MODE_RECEIVE_IQ: return 3 * lp->bins * lp->bins_y;
     }
     return 0;
 }
@@ -556,6 +557,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sh0, n * 16));
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
     HIP_TRY(alloc((void **) &wf.sh2, n * 4));
+    HIP_TRY(alloc((void **) &wf.sh3, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.counters = scene->counters;
@@ -593,6 +595,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         wf.trace_stragglers = e2 ? (uint32_t) atoi(e2) : bfd::kTraceStragglers;
         const char *e3 = getenv("BF_SHADE_CHAIN");
         wf.shade_chain = std::max(1, e3 ? atoi(e3) : (int) bfd::kShadeChain);
+        wf.iq = lp.iq;
     }
     const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
@@ -749,7 +752,8 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
                            void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
     const bool is_rx = scene->sensor_host.type == BF_RECEIVER_OMNI || scene->sensor_host.type == BF_RECEIVER_WIGNER;
-    if (launch->mode == BF_MODE_RECEIVE_RAW) {
+    const bool receive_mode = launch->mode == BF_MODE_RECEIVE_RAW || launch->mode == BF_MODE_RECEIVE_IQ;
+    if (receive_mode) {
         if (!is_rx) return fail(BF_ERR_INVALID, "receive mode needs a receiver (omnidirectional / wigner)");
         if (launch->bins != scene->sensor_host.t_bins || launch->bins_y != scene->sensor_host.f_bins)
             return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size (%u x %u)", launch->bins,
@@ -763,7 +767,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
             if (scene->emitter_types[i] != BF_EMITTER_SPOT && scene->emitter_types[i] != BF_EMITTER_AREA)
                 return fail(BF_ERR_INVALID, "render modes: emitter %u is a transmitter (use receive mode)", i);
     }
-    if (launch->mode > BF_MODE_RECEIVE_RAW) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);
+    if (launch->mode > BF_MODE_RECEIVE_IQ) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);
     if (launch->mode != BF_MODE_RECEIVE_RAW && launch->phase_bins)
         return fail(BF_ERR_INVALID, "phase_bins needs receive mode (PhaseIntegrator wraps pathtimefrequency)");
     if (launch->phase_bins > 4096) return fail(BF_ERR_INVALID, "phase_bins %u out of range", launch->phase_bins);
@@ -782,6 +786,8 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     lp.bins = launch->bins;
     lp.bins_y = launch->bins_y;
     lp.phase_bins = launch->mode == BF_MODE_RECEIVE_RAW ? launch->phase_bins : 0u;
+    lp.iq = launch->mode == BF_MODE_RECEIVE_IQ ? 1u : 0u;
+    if (lp.iq) lp.mode = BF_MODE_RECEIVE_RAW;          // the kernels see receive mode + the iq flag
     lp.bin_width = launch->bin_width;
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);

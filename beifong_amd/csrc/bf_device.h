@@ -88,7 +88,7 @@ struct DLaunch {
     float bin_width, time_c;
     uint32_t n_chan;
     uint32_t lds_hist;        // 1: histogram privatised in LDS
-    uint32_t pad;
+    uint32_t iq;              // 1: BF_MODE_RECEIVE_IQ (mode is RECEIVE_RAW inside the kernels): contributions are phasors
 };
 
 // device counters (uint64 each)

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(kBlock, RESUME ? 2 : 3) void bf_render_kernel(DScen
                     ++c_shadow;
                 }
             }
-            if (sh.want && !occluded) s.result += sh.c;     // Scene::ray_test == false (scene.cpp:220-224)
+            if (sh.want && !occluded) {                     // Scene::ray_test == false (scene.cpp:220-224)
+                s.result += sh.c;
+                if (lp.iq) s.phase += sh.c_im;
+            }
             sh.want = false;
         } else if (__ballot(trace_closest)) {
             if (trace_closest) {

@@ -372,7 +372,19 @@ struct ShadowReq {
     V3 o, d;
     float mint, maxt;
     float c;             // NEE contribution released by an unoccluded shadow ray
+    float c_im;          // BF_MODE_RECEIVE_IQ: its imaginary part (c is the real part)
 };
+
+// BF_MODE_RECEIVE_IQ: unit phasor exp(-j 2 pi L / lambda) of an optical path of `length` metres at
+// wavelength `lambda_nm`; the cycle count is reduced to its fractional part before the sine / cosine.
+BF_DEV void path_phasor(float length, float lambda_nm, float &re, float &im) {
+    float cycles = length / (lambda_nm * 1e-9f);
+    float frac = cycles - __builtin_floorf(cycles);
+    float s, c;
+    bf_sincos(-6.28318530717958647692f * frac, s, c);
+    re = c;
+    im = s;
+}
 
 // Returns true if the path continues with a new closest-hit ray (s.ro/rd/...),
 // false if it ended at the head of the iteration (film_put is due now).  When
@@ -430,7 +442,16 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
             ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
         else
             ev = (e.type == BF_EMITTER_SPOT) ? 0.f : ((si.wi.z > 0.f) ? e.radiance : 0.f);
-        s.result += s.emission_weight * s.throughput * ev;
+        float contrib = s.emission_weight * s.throughput * ev;
+        if (lp.iq) {
+            // optical length receiver -> ... -> this transmitter point: c * (t_rx - retarded time)
+            float re, im;
+            path_phasor((s.t_rx - s.time) * sc.c, s.lambda0, re, im);
+            s.result += contrib * re;
+            s.phase += contrib * im;                               // imaginary accumulator (phase bins are off in IQ mode)
+        } else {
+            s.result += contrib;
+        }
         if (is_range) s.aux += si_valid ? si.t : 0.f;              // pathlength.cpp:161
     }
     bool active = si_valid;
@@ -476,6 +497,13 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
             bsdf_eval_pdf(mat, si.wi, wo, bsdf_val, bsdf_pdf);
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf);
             sh.c = mis * s.throughput * bsdf_val * emitter_val;
+            sh.c_im = 0.f;
+            if (lp.iq) {
+                float re, im;
+                path_phasor((s.t_rx - s.time) * sc.c + ds.dist, s.lambda0, re, im);
+                sh.c_im = sh.c * im;
+                sh.c = sh.c * re;
+            }
             sh.o = si.p;
             sh.d = ds.d;
             sh.mint = kRayEpsilon * (1.f + hmax_abs(si.p));
@@ -537,7 +565,8 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode
         float a0 = valid ? 4.f * L : 0.f;                     // hsum over 4 identical spectral lanes
         float a1 = valid ? 1.f : 0.f;
-        bool ok = __builtin_isfinite(a0);
+        if (lp.iq) a1 = valid ? 4.f * (__builtin_fabsf(s.aux) * s.phase) : 0.f;   // I, Q, W instead of Y, A, W
+        bool ok = __builtin_isfinite(a0) && __builtin_isfinite(a1);
         // PhaseIntegrator::sample (phase.cpp:93-141): S{k}.Y takes hsum(L), before the receiver weight,
         // iff rect((phase - centre_k) / width) > 0; evaluated exactly as written there for the (at most
         // three) candidate bins around phase / width
@@ -574,7 +603,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
             ++acc.invalid;
         }
         rec_L = a0;
-        rec_aux = s.t_rx - se.adc_sampling_start;
+        rec_aux = lp.iq ? a1 : s.t_rx - se.adc_sampling_start;
     } else {
         const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
         const float sensor_w = sc.sensor->type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198

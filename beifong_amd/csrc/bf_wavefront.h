@@ -41,6 +41,7 @@ struct WF {
     float4 *sh0;        // o.xyz, mint
     float4 *sh1;        // d.xyz, maxt
     float *sh2;         // contribution released when unoccluded
+    float *sh3;         // BF_MODE_RECEIVE_IQ: its imaginary part
     // batch masks, double buffered by bounce parity: [2][n_slots / 64]
     unsigned long long *m_alive[2];
     unsigned long long *m_trace[2];
@@ -48,6 +49,7 @@ struct WF {
     uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)
+    uint32_t iq;                               // BF_MODE_RECEIVE_IQ
     uint32_t shade_chain;                      // wf_shade: vertices a lane may shade per visit while its rays resolve early
     uint32_t n_slots;               // slots in use this render (multiple of 64)
     uint32_t capacity;              // slots allocated

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                     Hit tmp;
                     bool found;
                     if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
-                        if (!found) s.result += sh.c;        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
+                        if (!found) {                        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
+                            s.result += sh.c;
+                            if (lp.iq) s.phase += sh.c_im;
+                        }
                         shadowing = false;
                     }
                     sh.want = shadowing;
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 wf.sh0[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
                 wf.sh1[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
                 wf.sh2[slot] = sh.c;
+                if (lp.iq) wf.sh3[slot] = sh.c_im;
             }
         }
         cont = has && cont;
@@ -410,6 +414,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                         float4 a = wf.sa[job];
                         a.w += wf.sh2[job];
                         wf.sa[job] = a;
+                        if (wf.iq) {                 // BF_MODE_RECEIVE_IQ: imaginary accumulator lives in se.w
+                            float4 e = wf.se[job];
+                            e.w += wf.sh3[job];
+                            wf.se[job] = e;
+                        }
                     }
                 } else {
                     wf.hit[job] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));

@@ -159,7 +159,12 @@ enum {
     BF_MODE_PATH = 0,         /* path.cpp; channels X,Y,Z,A,W                 */
     BF_MODE_RANGE = 1,        /* range.cpp o pathlength.cpp; +bins channels   */
     BF_MODE_TIME = 2,         /* time.cpp o pathtime.cpp; +3*bins channels    */
-    BF_MODE_RECEIVE_RAW = 3   /* receive() o pathtimefrequency.cpp; Y,A,W     */
+    BF_MODE_RECEIVE_RAW = 3,  /* receive() o pathtimefrequency.cpp; Y,A,W     */
+    BF_MODE_RECEIVE_IQ = 4    /* as RECEIVE_RAW, but every contribution is a phasor
+                                 c * exp(-j 2 pi L / lambda) of its own optical length L
+                                 (receiver -> ... -> transmitter); ADC cells hold I, Q, W.
+                                 Coherent pulse sweeps (range-Doppler); the
+                                 reference has no counterpart: parity is to the oracle */
 };
 enum { BF_COLOR_RGB = 0, BF_COLOR_MONO = 1 };
 

@@ -1187,6 +1187,7 @@ inline float mis_weight(float pdf_a, float pdf_b) {   // path.cpp:222-226
 struct PathResult {
     float L = 0, aux = 0;
     float phase = 0;      // gen-3: what PathTimeFrequencyIntegrator adds to the caller's ray.phase (:453)
+    float L_im = 0;       // BF_MODE_RECEIVE_IQ: imaginary part of the phasor sum (L is the real part)
     bool valid = false;
     uint32_t n_closest = 0, n_shadow = 0, n_bounces = 0;
 };
@@ -1429,12 +1430,25 @@ inline float phase_update(float phase, float t, float lambda_min_nm, float lambd
     return (float) ((double) phase + (double) num / den);
 }
 
+// BF_MODE_RECEIVE_IQ (physical mode, no reference counterpart): unit phasor exp(-j 2 pi L / lambda) of
+// an optical path of `length` metres; the cycle count is reduced to its fractional part first.
+inline void path_phasor(float length, float lambda_nm, float &re, float &im) {
+    float cycles = length / (lambda_nm * 1e-9f);
+    float frac = cycles - std::floor(cycles);
+    float sn, cs;
+    bf_sincos(-6.28318530717958647692f * frac, sn, cs);
+    re = cs;
+    im = sn;
+}
+
 // PathTimeFrequencyIntegrator::sample — src/integrators/pathtimefrequency.cpp:103-460
 static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, const RxCtx &cx) {
     PathResult r;
-    float eta = 1.f, emission_weight = 1.f, throughput = 1.f, result = 0.f;
+    float eta = 1.f, emission_weight = 1.f, throughput = 1.f, result = 0.f, result_im = 0.f;
     bool active = true;
     const float c = sc.physics.c;
+    const bool iq = lp.mode == BF_MODE_RECEIVE_IQ;
+    const float t_rx = ray.time;
     SI si = ray_intersect(sc, ray);
     ++r.n_closest;
     bool valid_ray = si.valid();
@@ -1449,7 +1463,17 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
         cur_phase = phase_update(cur_phase, -si.t, sc.physics.lambda_min_nm, sc.physics.lambda_max_nm);
     }
     for (int depth = 1;; ++depth) {
-        if (tx >= 0 && active) result += emission_weight * throughput * transmitter_eval(sc, sc.emitters[tx], si, cx);
+        if (tx >= 0 && active) {
+            float contrib = emission_weight * throughput * transmitter_eval(sc, sc.emitters[tx], si, cx);
+            if (iq) {
+                float re, im;
+                path_phasor((t_rx - si.time) * c, cx.lambda0, re, im);
+                result += contrib * re;
+                result_im += contrib * im;
+            } else {
+                result += contrib;
+            }
+        }
         active = active && si.valid();
         if (depth > lp.rr_depth) {
             float q = std::min(throughput * sqr(eta), .95f);
@@ -1469,7 +1493,17 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
             float bsdf_val = bsdf_eval(mat, si.wi, wo);
             float bsdf_pdf_ = bsdf_pdf(mat, si.wi, wo);
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf_);
-            if (active_e) result += mis * throughput * bsdf_val * tv;
+            if (active_e) {
+                float contrib = mis * throughput * bsdf_val * tv;
+                if (iq) {
+                    float re, im;
+                    path_phasor((t_rx - si.time) * c + ds.dist, cx.lambda0, re, im);
+                    result += contrib * re;
+                    result_im += contrib * im;
+                } else {
+                    result += contrib;
+                }
+            }
         }
         float s1 = smp.next_1d(), s2x, s2y;
         smp.next_2d(s2x, s2y);
@@ -1506,6 +1540,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
         si = si_bsdf;
     }
     r.L = result;
+    r.L_im = result_im;
     r.valid = valid_ray;
     r.phase = valid_ray ? 0.f + cur_phase : 0.f;      // :448-454 if (all(valid_ray)) ray_.phase += ray.phase
     return r;
@@ -1566,6 +1601,7 @@ static uint32_t launch_channels(const bf_launch &lp) {
         case BF_MODE_RANGE: return 5 + lp.bins;
         case BF_MODE_TIME: return 5 + 3 * lp.bins;
         case BF_MODE_RECEIVE_RAW: return (3 + lp.phase_bins) * lp.bins * lp.bins_y;
+        case BF_MODE_RECEIVE_IQ: return 3 * lp.bins * lp.bins_y;
     }
     return 0;
 }
@@ -1658,12 +1694,14 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     float L = std::fabs(w) * out.pr.L;                      // :1643
     float a0 = out.pr.valid ? 4.f * L : 0.f;                // hsum over the 4 identical spectral lanes :1661
     float a1 = out.pr.valid ? 1.f : 0.f, a2 = 1.f;
+    const bool iq = lp.mode == BF_MODE_RECEIVE_IQ;
+    if (iq) a1 = out.pr.valid ? 4.f * (std::fabs(w) * out.pr.L_im) : 0.f;      // I, Q, W instead of Y, A, W
     out.L = a0;
-    out.pr.aux = time - s.adc_sampling_start;
-    bool ok = std::isfinite(a0);
+    out.pr.aux = iq ? a1 : time - s.adc_sampling_start;
+    bool ok = std::isfinite(a0) && std::isfinite(a1);
     // PhaseIntegrator::sample — phase.cpp:93-141: AOVs aovs[3 + k] written BEFORE the receiver weight is
     // applied; bin k takes hsum(L) iff rect((phase - centre_k) / width) > 0, phase = fmod(ray.phase, 2 pi)
-    const uint32_t P = lp.phase_bins;
+    const uint32_t P = iq ? 0u : lp.phase_bins;
     std::vector<float> aov(P, 0.f);
     if (P) {
         const float two_pi = 2.f * kPi;
@@ -1821,7 +1859,7 @@ uint32_t bfo_launch_channels(const bf_launch *lp) { return launch_channels(*lp);
 bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int n_threads, float *hist_out,
                      bf_path_record *records_out, bf_stats *stats_out) {
     if (!s || !lp || !hist_out) return BF_ERR_INVALID;
-    const bool is_receive = lp->mode == BF_MODE_RECEIVE_RAW;
+    const bool is_receive = lp->mode == BF_MODE_RECEIVE_RAW || lp->mode == BF_MODE_RECEIVE_IQ;
     if (is_receive && (s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.type != BF_RECEIVER_WIGNER)) {
         g_err = "receive mode needs a receiver";
         return BF_ERR_INVALID;

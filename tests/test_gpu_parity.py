@@ -129,7 +129,7 @@ def _render_compare_one(g, lp, oracle_out, hist_rtol):
     rmse = float(np.sqrt(np.mean((hg / n - ho / n) ** 2)))
     # BASELINE.json target: per-range-bin RMSE < 1e-4 (relative to the largest bin when bins exceed 1)
     assert rmse < 1e-4 * max(1.0, float(np.abs(ho / n).max()))
-    if lp.mode == capi.BF_MODE_RECEIVE_RAW:
+    if lp.mode in (capi.BF_MODE_RECEIVE_RAW, capi.BF_MODE_RECEIVE_IQ):
         assert hg.reshape(-1, 3 + lp.phase_bins)[:, 2].sum() == n - sg.n_invalid
     else:
         assert hg[4] == n - sg.n_invalid      # weight channel counts the samples put
@@ -421,3 +421,20 @@ def test_small_pool_regenerates_paths_into_freed_slots(hiplib, monkeypatch):
         g = capi.Scene(sd)
         for _ in range(3):
             _render_compare_one(g, lp, oracle_out, 2e-5)
+
+
+@pytest.mark.parametrize("tx", ["wigner", "area"])
+def test_receive_iq_mode(hiplib, tx):
+    """BF_MODE_RECEIVE_IQ: per-contribution phasors, I / Q / W per ADC cell — every path's (I, Q) bit-identical
+    to the oracle, in the wavefront pipeline (deferred NEE contributions released by wf_trace), its planned
+    renders, the tail kernel and the one-kernel variant."""
+    sd, lp = scenes.bus_receive(n_tris=20000, n_paths=40000, transmitter=tx)
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    hg, ho, st = _render_compare(sd, lp)
+    cells = hg.reshape(256, 3)
+    assert np.count_nonzero(cells[:, 0]) > 5 and np.count_nonzero(cells[:, 1]) > 5
+    g = capi.Scene(sd)
+    o = OracleScene(sd)
+    out = o.render(lp, records=True, threads=8)
+    for _ in range(2):
+        _render_compare_one(g, lp, out, 2e-5)              # second render: planned

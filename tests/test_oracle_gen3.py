@@ -94,3 +94,40 @@ def test_phase_bins_cover_the_circle_for_a_narrow_band():
     h, _, _ = OracleScene(sd).render(lp, threads=8)
     s = h.reshape(256, 3 + P)[:, 3:].sum(0)
     assert np.all(s > 0)            # few, heavy-tailed contributions: coverage only, no flatness claim
+
+
+def test_iq_mode_is_a_phasor_sum_of_the_raw_contributions():
+    """BF_MODE_RECEIVE_IQ (physical mode; no reference counterpart): every contribution c of a path becomes
+    c * exp(-j 2 pi L / lambda) with L its own optical length.  (1) The weight channel and the sample
+    bookkeeping are those of RECEIVE_RAW.  (2) |I + jQ| <= Y per path, with equality when the path
+    has a single contribution (depth limit 2, tiny transmitter: almost every path).  (3) As lambda
+    grows beyond every path length the phasors align: I -> Y, Q -> 0."""
+    sd, lp = scenes.bus_receive(n_tris=2000, n_paths=40000, transmitter="area")
+    lp.max_depth = 2
+    o = OracleScene(sd)
+    raw, rr, _ = o.render(lp, records=True, threads=8)
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    iq, ri, st = o.render(lp, records=True, threads=8)
+    raw, iq = raw.reshape(256, 3), iq.reshape(256, 3)
+    assert np.array_equal(raw[:, 2], iq[:, 2])
+    y = rr["L"].astype(np.float64)
+    mag = np.hypot(ri["L"].astype(np.float64), ri["aux"].astype(np.float64))
+    lit = y > 0
+    assert lit.sum() > 1000
+    assert np.all(mag[lit] <= y[lit] * (1 + 1e-5))
+    assert np.mean(np.abs(mag[lit] - y[lit]) <= 1e-5 * y[lit]) > 0.99
+    assert np.all(mag[~lit] == 0)
+    # the phases are spread: the coherent sum per bin is well below the incoherent one
+    assert np.hypot(iq[:, 0], iq[:, 1]).sum() < 0.5 * raw[:, 0].sum()
+    # lambda -> infinity
+    sd.physics.lambda_min_nm = 0.9e18
+    sd.physics.lambda_max_nm = 1.1e18
+    sd.finalize()
+    o = OracleScene(sd)
+    lp.mode = capi.BF_MODE_RECEIVE_RAW
+    raw, _, _ = o.render(lp, threads=8)
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    iq, _, _ = o.render(lp, threads=8)
+    raw, iq = raw.reshape(256, 3), iq.reshape(256, 3)
+    assert np.allclose(iq[:, 0], raw[:, 0], rtol=1e-5, atol=1e-9 * raw[:, 0].max())
+    assert np.abs(iq[:, 1]).max() <= 1e-5 * raw[:, 0].max()
