@@ -104,7 +104,7 @@ class bf_scene_info(C.Structure):
 # every symbol include/beifong_hip.h declares
 EXPORTED_SYMBOLS = [
     "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
-    "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
+    "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
     "bf_trace_closest", "bf_trace_any", "bf_eval_elementary",
 ]
 
@@ -135,6 +135,7 @@ def load_library(path=None):
     lib.bf_scene_destroy.argtypes = [vp]
     lib.bf_scene_get_info.argtypes = [vp, C.POINTER(bf_scene_info)]
     lib.bf_scene_update_endpoints.argtypes = [vp, C.POINTER(bf_scene_desc), vp]
+    lib.bf_scene_translate_meshes.argtypes = [vp, C.POINTER(C.c_float * 3), vp]
     lib.bf_launch_channels.argtypes = [C.POINTER(bf_launch)]
     lib.bf_launch_channels.restype = C.c_uint32
     lib.bf_render_device.argtypes = [vp, C.POINTER(bf_launch), vp, vp, vp, C.POINTER(bf_stats)]
@@ -194,6 +195,12 @@ class Scene:
                                                            C.c_void_p(stream) if stream else None),
               "bf_scene_update_endpoints")
         self.holder = desc_holder
+
+    def translate_meshes(self, offset, stream=0):
+        """bf_scene_translate_meshes: all triangles to fl(p0 + offset), BVH re-fitted in place."""
+        off = (C.c_float * 3)(*[float(x) for x in offset])
+        check(self.lib, self.lib.bf_scene_translate_meshes(self.handle, C.byref(off), C.c_void_p(stream) if stream else None),
+              "bf_scene_translate_meshes")
 
     def info(self):
         i = bf_scene_info()

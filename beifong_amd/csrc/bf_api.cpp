@@ -20,6 +20,8 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
                                         unsigned long long *counters, int stats, unsigned grid, size_t lds_bytes,
                                         hipStream_t stream);
 extern "C" float bfk_host_cos(float x);
+extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
+                                           float4 *nodes, uint32_t n_nodes, const float *d, hipStream_t stream);
 extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y);
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
@@ -104,6 +106,7 @@ struct bf_scene {
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
     bfd::DSensor sensor_host;              // host copy of the device sensor record
+    float4 *tris0 = nullptr, *nodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     float origin_scale_built = 0.f;        // ray-origin bound the BVH boxes were padded for (bf_bvh.h)
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
@@ -513,6 +516,32 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
     scene->d.c = desc->physics.c;
     scene->d.lambda_min = desc->physics.lambda_min_nm;
     scene->d.lambda_max = desc->physics.lambda_max_nm;
+    return BF_OK;
+}
+
+bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void *stream_) {
+    if (!scene || !offset) return fail(BF_ERR_INVALID, "null argument");
+    if (!(std::isfinite(offset[0]) && std::isfinite(offset[1]) && std::isfinite(offset[2])))
+        return fail(BF_ERR_INVALID, "bf_scene_translate_meshes: non-finite offset");
+    if (scene->d.n_tris == 0) return BF_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const size_t tri_bytes = (size_t) scene->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
+    if (!scene->tris0) {
+        // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, tri_bytes));
+        scene->owned.push_back(p);
+        scene->tris0 = (float4 *) p;
+        HIP_TRY(hipMemcpyAsync(scene->tris0, scene->d.tris, tri_bytes, hipMemcpyDeviceToDevice, stream));
+        if (node_bytes) {
+            HIP_TRY(hipMalloc(&p, node_bytes));
+            scene->owned.push_back(p);
+            scene->nodes0 = (float4 *) p;
+            HIP_TRY(hipMemcpyAsync(scene->nodes0, scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
+                                 const_cast<float4 *>(scene->d.nodes), scene->d.n_nodes, offset, stream));
     return BF_OK;
 }
 

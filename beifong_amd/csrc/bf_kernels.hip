@@ -330,6 +330,49 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     return hipGetLastError();
 }
 
+namespace bfd {
+// bf_scene_translate_meshes: triangles and node boxes of the pristine copies shifted by `d`.
+__global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__restrict__ tris, uint32_t n_tri_rows,
+                                    const float4 *__restrict__ nodes0, float4 *__restrict__ nodes, uint32_t n_nodes, float dx,
+                                    float dy, float dz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tri_rows) {                       // one float4 row (a vertex + tag) per thread
+        float4 v = tris0[i];
+        tris[i] = make_float4(v.x + dx, v.y + dy, v.z + dz, v.w);
+    }
+    if (i < n_nodes) {
+        const float4 *s = nodes0 + 8u * i;
+        float4 *o = nodes + 8u * i;
+        float4 lx = s[0], ly = s[1], lz = s[2], hx = s[3], hy = s[4], hz = s[5];
+        // shifted vertices are rounded to fp32 again (half an ulp each) and the fma slab test allows for
+        // 2^-24 |origin| (bf_bvh.h): re-pad every box by 2.4e-7 of its largest shifted coordinate
+#define BF_SHIFT(L, H, D, K)                                                                                  \
+    {                                                                                                         \
+        float lo = L.K + D, hi = H.K + D;                                                                     \
+        float e = 2.4e-7f * __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));                        \
+        L.K = lo - e;                                                                                         \
+        H.K = hi + e;                                                                                         \
+    }
+        BF_SHIFT(lx, hx, dx, x) BF_SHIFT(lx, hx, dx, y) BF_SHIFT(lx, hx, dx, z) BF_SHIFT(lx, hx, dx, w)
+        BF_SHIFT(ly, hy, dy, x) BF_SHIFT(ly, hy, dy, y) BF_SHIFT(ly, hy, dy, z) BF_SHIFT(ly, hy, dy, w)
+        BF_SHIFT(lz, hz, dz, x) BF_SHIFT(lz, hz, dz, y) BF_SHIFT(lz, hz, dz, z) BF_SHIFT(lz, hz, dz, w)
+#undef BF_SHIFT
+        o[0] = lx; o[1] = ly; o[2] = lz; o[3] = hx; o[4] = hy; o[5] = hz;
+        o[6] = s[6];
+        o[7] = s[7];
+    }
+}
+}  // namespace bfd
+
+extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
+                                           float4 *nodes, uint32_t n_nodes, const float *d, hipStream_t stream) {
+    uint32_t n = n_tri_rows > n_nodes ? n_tri_rows : n_nodes;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bfd::bf_translate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tris0, tris, n_tri_rows, nodes0, nodes,
+                       n_nodes, d[0], d[1], d[2]);
+    return hipGetLastError();
+}
+
 /* Host-side evaluation of the engine's fp32 cosine (bf_device_math.h), used by scene setup so that
  * precomputed emitter constants follow the same specification as the kernels. */
 extern "C" float bfk_host_cos(float x) { return bfd::bf_cos(x); }

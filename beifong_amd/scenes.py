@@ -143,6 +143,41 @@ def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmit
     return sd, launch
 
 
+def plate_doppler(wavelength_m=0.1, n_paths=1 << 16, t_bins=1, plate_x=5.0, plate_size=0.5, n_grid=8, seed=4,
+                  ground=False):
+    """Narrow-band coherent scene for pulse sweeps: coincident 20 x 50 mm TX / RX apertures at (0,0,0.3) looking
+    +x, an area transmitter (no signal gating) and an omnidirectional receiver, a diffuse mesh plate facing
+    them at x = plate_x (the moving target), optionally the 20 x 20 m ground.  The band is +-1e-6 around
+    `wavelength_m`, so every ray carries that wavelength."""
+    sd = SceneDesc()
+    lam_nm = wavelength_m * 1e9
+    sd.physics.lambda_min_nm = lam_nm * (1 - 1e-6)
+    sd.physics.lambda_max_nm = lam_nm * (1 + 1e-6)
+    c = sd.physics.c
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
+    aperture = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
+    txa = sd.add_rectangle(aperture, sd.add_diffuse(0.0))
+    rxa = sd.add_rectangle(aperture, sd.add_diffuse(0.5))
+    sd.add_area_transmitter(txa, 1.0)
+    t_total = 2.0e-7
+    f_c = c / wavelength_m
+    sd.set_receiver(rxa, kind="omnidirectional", adc_sampling_start=0.0, adc_sampling_end=t_total, t_bins=t_bins, f_bins=1,
+                    t_bandwidth=t_total, f_bandwidth=2.0 * f_c, freq_centre=f_c, freq_ext=f_c * 2e-6)
+    if ground:
+        _ground(sd)
+    # plate in the y-z plane, normal -x, n_grid x n_grid quads
+    g = np.linspace(-0.5 * plate_size, 0.5 * plate_size, n_grid + 1)
+    yy, zz = np.meshgrid(g, g, indexing="ij")
+    v = np.stack([np.full(yy.size, plate_x), yy.ravel(), zz.ravel() + 0.3], -1).astype(np.float32)
+    idx = np.arange((n_grid + 1) ** 2).reshape(n_grid + 1, n_grid + 1)
+    a, b, cc, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, cc], -1), np.stack([a, cc, d], -1)]).astype(np.uint32)
+    sd.add_mesh(np.ascontiguousarray(v), np.ascontiguousarray(f), sd.add_diffuse(0.8, twosided=True))
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RECEIVE_IQ, n_paths, seed=seed, bins=t_bins, bins_y=1)
+    return sd, launch
+
+
 def single_mesh(v, f, normals=None):
     """Bare mesh scene for Scene::ray_intersect tests (test_kdtrees.py style)."""
     sd = SceneDesc()

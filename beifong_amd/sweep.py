@@ -67,3 +67,44 @@ def render_sweep(frames, n_streams=4, lib=None, device=None):
             h.close()
     render_sweep.last_stats = stats
     return out
+
+
+def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None):
+    """Coherent pulse sweep over a rigidly moving target (BASELINE configs[4]).
+
+    `sd`      scene description whose meshes are the target (rectangles — ground, antennas — stay put);
+    `launch`  a BF_MODE_RECEIVE_IQ launch; every pulse uses the SAME seed (common random numbers), so a
+              path keeps its geometry from pulse to pulse and only its optical length — its phase — moves;
+    `offsets` float[n_pulses, 3]: target offset of each pulse, relative to the scene as built.
+
+    The BVH is built once per stream handle and re-fitted per pulse on the device
+    (bf_scene_translate_meshes); pulses rotate over the streams.  Returns the slow-time x fast-time
+    cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W)."""
+    import torch
+    lib = lib or capi.load_library()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    offsets = np.asarray(offsets, dtype=np.float32).reshape(-1, 3)
+    n_streams = max(1, min(n_streams, len(offsets)))
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    handles = [capi.Scene(sd, lib) for _ in range(n_streams)]
+    n_chan = handles[0].channels(launch)
+    cube = torch.zeros((len(offsets), n_chan), dtype=torch.float32, device=dev)
+    for k, off in enumerate(offsets):
+        j = k % n_streams
+        with torch.cuda.stream(streams[j]):
+            handles[j].translate_meshes(off, stream=streams[j].cuda_stream)
+            handles[j].render_device(launch, cube[k].data_ptr(), stream=streams[j].cuda_stream)
+    for s in streams:
+        s.synchronize()
+    out = cube.cpu().numpy().reshape(len(offsets), -1, 3)
+    for h in handles:
+        h.close()
+    return out
+
+
+def range_doppler(cube, window=True):
+    """Slow-time FFT of a pulse-sweep cube: complex64[n_doppler, cells], zero Doppler at row 0 (numpy.fft order)."""
+    z = cube[:, :, 0].astype(np.complex64) + 1j * cube[:, :, 1].astype(np.complex64)
+    if window:
+        z = z * np.hanning(z.shape[0])[:, None].astype(np.float32)
+    return np.fft.fft(z, axis=0)

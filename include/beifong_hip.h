@@ -249,6 +249,15 @@ bf_status bf_scene_destroy(bf_scene *scene);
  * Fails with BF_ERR_UNSUPPORTED if an endpoint moves further from the origin
  * than the bound the BVH boxes were padded for (recreate the scene then). */
 bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, void *stream);
+
+/* Rigidly translate ALL mesh triangles of the scene to `offset` (metres, relative
+ * to the positions the scene was created with — absolute, so a sweep does not
+ * accumulate rounding): vertices become fl(p0 + offset), the four-wide BVH is
+ * re-fitted in place (boxes shifted and re-padded), rectangles and endpoints
+ * stay.  A moving target between the pulses of a coherent sweep (SURVEY 8f-1;
+ * the reference rebuilds the scene per frame, animated_trans_rad.py:307-373).
+ * Stream-ordered like bf_scene_update_endpoints. */
+bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void *stream);
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info);
 
 /* number of floats the given launch accumulates into: 5 (+bins | +3*bins) for
