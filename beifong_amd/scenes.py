@@ -110,12 +110,14 @@ def multi_mesh_radar(n_paths=4096 << 10, bins=4096, dr=0.01, seed=3, scale=1.0):
 
 
 def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmitter="wigner", receiver="omnidirectional",
-                signaltype="pulse"):
+                signaltype="pulse", lambda_band_nm=None):
     """C2-recv: C2 geometry through gen-3 receive():
     wignertransmitter (pulse tau = 2 dr / c, prf = 1/T) on the TX aperture,
     omnidirectional receiver on a coincident RX aperture, ADC t_bins x 1 with
     t_bandwidth = T = t_bins * tau, f_bandwidth = 2 c / lambda_min (one frequency row)."""
     sd = SceneDesc()
+    if lambda_band_nm is not None:      # MTS_WAVELENGTH_MIN / MAX are compile-time choices of the fork (spectrum.h:15-30)
+        sd.physics.lambda_min_nm, sd.physics.lambda_max_nm = lambda_band_nm
     c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
     d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
     aperture = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
