@@ -33,7 +33,12 @@ struct alignas(16) Node {
 };
 static_assert(sizeof(Node) == 64, "node must be 64 bytes");
 
-constexpr int kMaxLeaf = 4;
+// triangles per leaf: 2 measured best on MI355X (wf_trace 5.0 ms per C2 step; 1: 5.4, 4: 5.3, 8: 6.2) — a triangle
+// test costs ~100 lane-instructions for every lane of the wave, a four-box node step ~170
+#ifndef BF_MAX_LEAF
+#define BF_MAX_LEAF 2
+#endif
+constexpr int kMaxLeaf = BF_MAX_LEAF;
 constexpr int kMaxDepth = 31;   // tree depth bound == traversal stack bound (kStackDepth 32)
 
 struct BVH {
@@ -71,7 +76,7 @@ struct BVH4 {
 // levels of children - 1) is reported so that the kernels' stacks can be sized.
 void collapse_bvh4(const BVH &in, BVH4 &out);
 
-// Binned SAH build (16 bins, leaf <= kMaxLeaf).  Boxes are padded by a few
+// Binned SAH build (16 bins, leaf <= kMaxLeaf triangles).  Boxes are padded by a few
 // ulps so that a fp32 Moeller-Trumbore hit distance never falls outside the
 // box that holds its triangle.  `origin_scale`: largest |coordinate| a ray origin
 // can have (scene geometry, sensors, emitters); the kernels' slab test folds the
