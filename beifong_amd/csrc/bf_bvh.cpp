@@ -77,7 +77,10 @@ struct Builder {
         cb.reset();
         for (uint32_t i = 0; i < count; ++i) cb.grow(&cent[3 * order[first + i]]);
 
-        constexpr int NB = 16;
+#ifndef BF_SAH_BINS
+#define BF_SAH_BINS 16
+#endif
+        constexpr int NB = BF_SAH_BINS;
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_bin = -1;
         // The traversal kernels keep a kStackDepth-entry stack per lane in LDS:
