@@ -491,3 +491,55 @@ def test_pulse_sweep_range_doppler_peak(hiplib):
     g.translate_meshes(offsets[k])
     h_k, _, _ = g.render(lp)
     assert np.allclose(h_k.reshape(1, 3), cube[k], rtol=1e-4, atol=1e-6 * np.abs(cube[k]).max())
+
+
+def _zoo_scene(two_emitters=True, receive=False):
+    """Small scene exercising the branches the radar configs do not: several emitters (uniform emitter
+    selection, scene.cpp:180-230 / 249-299), one-sided materials, a mesh with and a mesh without normals."""
+    sd = SceneDesc()
+    T = Transform4f
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
+    ap = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
+    c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
+    if receive:
+        txa = sd.add_rectangle(ap, sd.add_diffuse(0.0))
+        rxa = sd.add_rectangle(ap, sd.add_diffuse(0.5))
+        tau = 2.0 * 0.1 / c
+        f_c = c / (0.5 * (lmin + lmax) * 1e-9)
+        sd.add_wigner_transmitter(txa, signaltype="pulse", amplitude=1.0, freq_centre=f_c, freq_ext=1.0 / tau, pulse_len=tau,
+                                  prf=1.0 / (64 * tau), gain=1.0)
+        if two_emitters:
+            tx2 = sd.add_rectangle(T.translate([0.0, 1.0, 0.6]) * d0 * T.scale([0.1, 0.1, 1]), sd.add_diffuse(0.0))
+            sd.add_area_transmitter(tx2, 0.5)
+        sd.set_receiver(rxa, kind="omnidirectional", adc_sampling_start=0.0, adc_sampling_end=64 * tau, t_bins=64, f_bins=1,
+                        t_bandwidth=64 * tau, f_bandwidth=2.0 * c / (lmin * 1e-9), freq_centre=f_c,
+                        freq_ext=c / (lmin * 1e-9) - c / (lmax * 1e-9))
+        lp = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, 30000, seed=9, bins=64, bins_y=1)
+    else:
+        txa = sd.add_rectangle(ap, sd.add_diffuse(0.0))
+        sd.add_area_emitter(txa, 500.0)
+        if two_emitters:
+            sd.add_spot(T.look_at([0.5, -1.0, 2.0], [4.0, 0.0, 0.0], [0, 0, 1]), intensity=30.0, cutoff_angle=30.0, beam_width=20.0)
+            tx3 = sd.add_rectangle(T.translate([2.0, 2.0, 2.5]) * T.rotate([1, 0, 0], 180) * T.scale([0.3, 0.3, 1]), sd.add_diffuse(0.0))
+            sd.add_area_emitter(tx3, 20.0)
+        sd.set_perspective(T.translate([0, 0, 0.3]) * d0, fov=60.0, near_clip=0.1, far_clip=100.0)
+        lp = capi.make_launch(capi.BF_MODE_RANGE, 30000, seed=9, bins=128, bin_width=0.1, color_mode=capi.BF_COLOR_RGB)
+    sd.add_rectangle(T.scale([20, 20, 1]), sd.add_diffuse(0.4, twosided=False))
+    v, f, n = meshgen.car_body(6000, seed=3)
+    sd.add_mesh(meshgen.place(v, 25.0, (4.0, 0.5, 0.8)), f, sd.add_roughconductor(alpha=0.3, twosided=False, specular_reflectance=0.7),
+                normals=meshgen.vertex_normals(meshgen.place(v, 25.0, (4.0, 0.5, 0.8)), f))
+    v, f = meshgen.bus(4000, seed=6)
+    sd.add_mesh(meshgen.place(v, -40.0, (7.0, -3.0, 1.7), scale=0.5), f, sd.add_diffuse(0.9, twosided=True))
+    sd.finalize()
+    return sd, lp
+
+
+@pytest.mark.parametrize("receive", [False, True])
+@pytest.mark.parametrize("two", [False, True])
+def test_zoo_multi_emitter_one_sided(hiplib, receive, two):
+    sd, lp = _zoo_scene(two_emitters=two, receive=receive)
+    for max_depth, rr_depth in ((-1, 5), (3, 5), (-1, 1), (1, 5)):
+        lp.max_depth, lp.rr_depth = max_depth, rr_depth
+        hg, ho, st = _render_compare(sd, lp)
+        if max_depth == -1:
+            assert np.count_nonzero(hg) > 3
