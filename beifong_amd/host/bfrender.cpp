@@ -1,7 +1,8 @@
 // bfrender — command line front end with the reference CLI's flags
 // (src/mitsuba/mitsuba.cpp:173-183): -m variant, -D name=value, -o output,
 // -r (call receive() instead of render()), -v verbose.  Writes the raw
-// film / ADC storage as a little-endian float32 .npy (EXR output is out of scope).
+// film / ADC storage as OpenEXR (like `mitsuba scene.xml -o out.exr`, mitsuba.cpp:283-290) or, for `-o x.npy`, as a
+// little-endian float32 .npy.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -45,7 +46,7 @@ int main(int argc, char **argv) {
             }
             params.emplace_back(kv.substr(0, k), kv.substr(k + 1));
         } else if (a == "-h" || a == "--help") {
-            printf("usage: bfrender [-m variant] [-D name=value]... [-r] [-o out.npy] [-v] scene.xml\n");
+            printf("usage: bfrender [-m variant] [-D name=value]... [-r] [-o out.exr|out.npy] [-v] scene.xml\n");
             return 0;
         } else {
             scene_file = a;
@@ -64,6 +65,7 @@ int main(int argc, char **argv) {
         const float *data;
         unsigned rows, cols, ch;
         const bf_stats *st;
+        const std::vector<std::string> *names;
         if (do_receive) {
             if (scene->receivers().empty()) Throw("-r given but the scene has no receiver");
             Receiver *r = scene->receivers()[0].get();
@@ -72,6 +74,7 @@ int main(int argc, char **argv) {
             rows = r->adc()->f_bins();
             cols = r->adc()->t_bins();
             ch = (unsigned) r->adc()->channels().size();
+            names = &r->adc()->channels();
         } else {
             if (scene->sensors().empty()) Throw("the scene has no sensor");
             Sensor *s = scene->sensors()[0].get();
@@ -80,6 +83,7 @@ int main(int argc, char **argv) {
             rows = s->film()->height();
             cols = s->film()->width();
             ch = (unsigned) s->film()->channels().size();
+            names = &s->film()->channels();
         }
         st = &in->last_stats().stats;
         printf("rendered %llu paths, %llu rays in %.3f ms (kernels %.3f ms) -> [%u, %u, %u]\n",
@@ -87,9 +91,12 @@ int main(int argc, char **argv) {
                in->last_stats().wall_ms, st->kernel_ms, rows, cols, ch);
         if (output.empty()) {
             size_t k = scene_file.find_last_of('.');
-            output = (k == std::string::npos ? scene_file : scene_file.substr(0, k)) + ".npy";
+            output = (k == std::string::npos ? scene_file : scene_file.substr(0, k)) + ".exr";
         }
-        save_npy(output, data, rows, cols, ch);
+        if (output.size() > 4 && output.compare(output.size() - 4, 4, ".npy") == 0)
+            save_npy(output, data, rows, cols, ch);
+        else
+            write_exr(output, cols, rows, *names, data);
         printf("wrote %s\n", output.c_str());
     } catch (const std::exception &e) {
         fprintf(stderr, "bfrender: %s\n", e.what());

@@ -159,6 +159,26 @@ int bfh_bitmap(void *endpoint, const float **data, unsigned *rows, unsigned *col
         if (*channels == 0) Throw("bitmap(): nothing has been rendered yet");
     })
 }
+int bfh_write_exr(const char *path, unsigned width, unsigned height, unsigned n_channels, const char *const *names, const float *data) {
+    BFH_TRY({
+        std::vector<std::string> nm;
+        for (unsigned i = 0; i < n_channels; ++i) nm.emplace_back(names[i]);
+        write_exr(path, width, height, nm, data);
+    })
+}
+int bfh_develop(void *endpoint, const char *path) {
+    BFH_TRY({
+        if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) {
+            if (path) se->film()->set_destination_file(path);
+            se->film()->develop();
+        } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
+            if (path) re->adc()->set_destination_file(path);
+            re->adc()->develop();
+        } else {
+            Throw("object is neither a Sensor nor a Receiver");
+        }
+    })
+}
 const char *bfh_channel_name(void *endpoint, unsigned i) {
     if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) return se->film()->channels().at(i).c_str();
     if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) return re->adc()->channels().at(i).c_str();

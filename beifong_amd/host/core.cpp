@@ -326,4 +326,89 @@ std::vector<std::string> PluginManager::loaded_plugins() const {
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// OpenEXR 2.0 single-part scanline writer (NO_COMPRESSION, FLOAT channels)
+// ---------------------------------------------------------------------------
+namespace {
+struct ExrOut {
+    std::string buf;
+    void bytes(const void *p, size_t n) { buf.append((const char *) p, n); }
+    void str(const std::string &s) { buf.append(s.c_str(), s.size() + 1); }
+    void i32(int32_t v) { bytes(&v, 4); }
+    void u64(uint64_t v) { bytes(&v, 8); }
+    void f32(float v) { bytes(&v, 4); }
+    void u8(uint8_t v) { bytes(&v, 1); }
+    void attr(const char *name, const char *type, const std::string &value) {
+        str(name);
+        str(type);
+        i32((int32_t) value.size());
+        buf.append(value);
+    }
+};
+}  // namespace
+
+void write_exr(const std::string &path, uint32_t width, uint32_t height, const std::vector<std::string> &names,
+               const float *data) {
+    const size_t nc = names.size();
+    if (nc == 0 || width == 0 || height == 0) Throw("write_exr(\"%s\"): empty image", path.c_str());
+    std::vector<size_t> order(nc);
+    for (size_t i = 0; i < nc; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return names[a] < names[b]; });
+    for (size_t i = 1; i < nc; ++i)
+        if (names[order[i]] == names[order[i - 1]]) Throw("write_exr(\"%s\"): duplicate channel \"%s\"", path.c_str(), names[order[i]].c_str());
+
+    ExrOut o;
+    const unsigned char magic[4] = {0x76, 0x2f, 0x31, 0x01};
+    o.bytes(magic, 4);
+    o.i32(2);                                           // version 2, single-part scanline, short names
+    {
+        ExrOut ch;
+        for (size_t k : order) {
+            if (names[k].size() > 31) Throw("write_exr: channel name \"%s\" longer than 31 characters", names[k].c_str());
+            ch.str(names[k]);
+            ch.i32(2);                                  // FLOAT
+            ch.u8(0);                                   // pLinear
+            ch.u8(0); ch.u8(0); ch.u8(0);
+            ch.i32(1);                                  // x, y sampling
+            ch.i32(1);
+        }
+        ch.u8(0);
+        o.attr("channels", "chlist", ch.buf);
+    }
+    o.attr("compression", "compression", std::string(1, '\0'));
+    {
+        ExrOut b;
+        b.i32(0); b.i32(0); b.i32((int32_t) width - 1); b.i32((int32_t) height - 1);
+        o.attr("dataWindow", "box2i", b.buf);
+        o.attr("displayWindow", "box2i", b.buf);
+    }
+    o.attr("lineOrder", "lineOrder", std::string(1, '\0'));
+    {
+        ExrOut f;
+        f.f32(1.f);
+        o.attr("pixelAspectRatio", "float", f.buf);
+        o.attr("screenWindowWidth", "float", f.buf);
+        ExrOut v;
+        v.f32(0.f); v.f32(0.f);
+        o.attr("screenWindowCenter", "v2f", v.buf);
+    }
+    o.u8(0);                                            // end of header
+    const uint64_t line_bytes = (uint64_t) width * nc * 4, block = 8 + line_bytes;
+    const uint64_t first = o.buf.size() + (uint64_t) height * 8;
+    for (uint32_t y = 0; y < height; ++y) o.u64(first + y * block);
+    std::vector<float> line((size_t) width * nc);
+    for (uint32_t y = 0; y < height; ++y) {
+        o.i32((int32_t) y);
+        o.i32((int32_t) line_bytes);
+        for (size_t c = 0; c < nc; ++c)
+            for (uint32_t x = 0; x < width; ++x) line[c * width + x] = data[((size_t) y * width + x) * nc + order[c]];
+        o.bytes(line.data(), line_bytes);
+    }
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) Throw("write_exr: cannot open \"%s\" for writing", path.c_str());
+    size_t w = fwrite(o.buf.data(), 1, o.buf.size(), f);
+    fclose(f);
+    if (w != o.buf.size()) Throw("write_exr: short write to \"%s\"", path.c_str());
+}
+
 }  // namespace bfh

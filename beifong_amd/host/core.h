@@ -235,4 +235,10 @@ void set_variant(const std::string &v);
     static ::bfh::Object *bf_construct_##ClassName(const ::bfh::Properties &p) { return new ClassName(p); }  \
     static ::bfh::Class bf_class_##ClassName(PluginName, ParentName, "", bf_construct_##ClassName);
 
+/// Multi-channel float32 OpenEXR 2 scanline file, uncompressed — what Bitmap::write(OpenEXR) produces for the
+/// raw film / ADC storage (hdrfilm.cpp:213-249, hdradc.cpp:276-295), minus the compression.  `data` is
+/// [height][width][channels] interleaved; channels are stored under `names` (EXR keeps them in alphabetical order).
+void write_exr(const std::string &path, uint32_t width, uint32_t height, const std::vector<std::string> &names,
+               const float *data);
+
 }  // namespace bfh

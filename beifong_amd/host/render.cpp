@@ -88,6 +88,20 @@ void Film::put(const float *data, size_t n) {
     for (size_t i = 0; i < n; ++i) m_storage[i] += data[i];
 }
 
+static std::string exr_path(const std::string &dest) {
+    if (dest.empty()) Throw("develop(): no destination file set");
+    size_t slash = dest.find_last_of('/'), dot = dest.find_last_of('.');
+    return (dot == std::string::npos || (slash != std::string::npos && dot < slash)) ? dest + ".exr" : dest;
+}
+void Film::develop() const {
+    if (m_channels.empty()) Throw("develop(): nothing has been rendered yet");
+    write_exr(exr_path(m_dest), m_width, m_height, m_channels, m_storage.data());
+}
+void ADC::develop() const {
+    if (m_channels.empty()) Throw("develop(): nothing has been received yet");
+    write_exr(exr_path(m_dest), m_t_bins, m_f_bins, m_channels, m_storage.data());
+}
+
 ADC::ADC(const Properties &props) {
     m_t_bins = (uint32_t) props.int_("t_bins", 1024);           // adc.cpp:9-13
     m_f_bins = (uint32_t) props.int_("f_bins", 1024);

@@ -63,9 +63,13 @@ public:
     void put(const float *data, size_t n);
     const std::vector<float> &bitmap() const { return m_storage; }
     const std::vector<std::string> &channels() const { return m_channels; }
+    /// HDRFilm::set_destination_file / develop — hdrfilm.cpp:213-249 (".exr" is appended if there is no extension)
+    void set_destination_file(const std::string &path) { m_dest = path; }
+    void develop() const;
     const Class *class_() const override;
 
 protected:
+    std::string m_dest;
     uint32_t m_width, m_height;
     ref<ReconstructionFilter> m_filter;
     std::vector<std::string> m_channels;
@@ -85,6 +89,9 @@ public:
     void put(const float *data, size_t n);
     const std::vector<float> &bitmap() const { return m_storage; }   // [f][t][C]
     const std::vector<std::string> &channels() const { return m_channels; }
+    /// HDRADC::set_destination_file / develop — hdradc.cpp:259-295
+    void set_destination_file(const std::string &path) { m_dest = path; }
+    void develop() const;
     const Class *class_() const override;
 
 protected:
@@ -93,6 +100,7 @@ protected:
     ref<ReconstructionFilter> m_filter;
     std::vector<std::string> m_channels;
     std::vector<float> m_storage;
+    std::string m_dest;
 };
 
 class Shape;

@@ -47,6 +47,8 @@ def lib():
     l.bfh_integrator_receive.argtypes = [vp, vp, vp]
     l.bfh_integrator_stats.argtypes = [vp, C.POINTER(capi.bf_stats), C.POINTER(C.c_double)]
     l.bfh_sensor_sample_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    l.bfh_develop.argtypes = [vp, cp]
+    l.bfh_write_exr.argtypes = [cp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(cp), C.POINTER(C.c_float)]
     l.bfh_bitmap.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     l.bfh_channel_name.argtypes = [vp, C.c_uint]
     l.bfh_channel_name.restype = cp
@@ -129,6 +131,16 @@ class _Storage:
         arr = np.ctypeslib.as_array(data, shape=(r.value, c.value, ch.value)).copy()
         names = [lib().bfh_channel_name(self._e._ptr, i).decode() for i in range(ch.value)]
         return Bitmap(arr, names)
+
+    def set_destination_file(self, path):
+        self._dest = str(path)
+
+    def develop(self):
+        """Write the raw storage as a multi-channel float32 OpenEXR file (hdrfilm.cpp:213-249, hdradc.cpp:259-295)."""
+        dest = getattr(self, "_dest", None)
+        if dest is None:
+            raise RuntimeError("develop(): call set_destination_file() first")
+        check(lib().bfh_develop(self._e._ptr, dest.encode()))
 
     def size(self):
         b = self.bitmap()
@@ -226,3 +238,49 @@ def wrap(ptr, dict_src=None):
     o = cls(ptr, owned=True)
     o._dict = dict_src
     return o
+
+
+def write_exr(path, array, channel_names):
+    """Write float32 [rows, cols, channels] as an uncompressed multi-channel OpenEXR file."""
+    a = np.ascontiguousarray(array, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != len(channel_names):
+        raise ValueError("write_exr: array must be [rows, cols, len(channel_names)]")
+    names = (C.c_char_p * len(channel_names))(*[n.encode() for n in channel_names])
+    check(lib().bfh_write_exr(str(path).encode(), a.shape[1], a.shape[0], a.shape[2], names,
+                              a.ctypes.data_as(C.POINTER(C.c_float))))
+
+
+def read_exr(path):
+    """Minimal reader for the files write_exr produces (single part, scanline, no compression, FLOAT channels):
+    returns (float32 [rows, cols, channels], channel names in file order)."""
+    import struct
+    b = open(path, "rb").read()
+    if b[:4] != b"\x76\x2f\x31\x01" or struct.unpack_from("<i", b, 4)[0] != 2:
+        raise ValueError("not a plain OpenEXR 2 scanline file")
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos)
+        name = b[pos:e].decode()
+        e2 = b.index(b"\0", e + 1)
+        size = struct.unpack_from("<i", b, e2 + 1)[0]
+        attrs[name] = b[e2 + 5:e2 + 5 + size]
+        pos = e2 + 5 + size
+    pos += 1
+    if attrs["compression"] != b"\0":
+        raise ValueError("compressed EXR not supported")
+    names, p, ch = [], 0, attrs["channels"]
+    while ch[p] != 0:
+        e = ch.index(b"\0", p)
+        names.append(ch[p:e].decode())
+        if struct.unpack_from("<i", ch, e + 1)[0] != 2:
+            raise ValueError("only FLOAT channels supported")
+        p = e + 1 + 16
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    offs = struct.unpack_from("<%dQ" % h, b, pos)
+    out = np.empty((h, w, len(names)), np.float32)
+    for y in range(h):
+        yy, nbytes = struct.unpack_from("<2i", b, offs[y])
+        line = np.frombuffer(b, np.float32, w * len(names), offs[y] + 8).reshape(len(names), w)
+        out[yy - y0] = line.T
+    return out, names

@@ -73,3 +73,27 @@ def test_bfrender_cli(hiplib, tmp_path):
     assert r.returncode == 0, r.stderr
     a = np.load(out)
     assert a.shape == (1, 1, 155) and a[0, 0, 4] == 5000
+    # default output: <scene>.exr next to the scene file (mitsuba.cpp:283-290), same numbers
+    r = subprocess.run([os.path.join(HOST, "bfrender"), "-m", "scalar_rgb", "-Dspp=5000", str(p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from beifong_amd.mitsuba import _host
+    img, names = _host.read_exr(str(tmp_path / "scene.exr"))
+    assert img.shape == (1, 1, 155) and sorted(names) == names and "S49.B" in names
+    assert img[0, 0, names.index("W")] == 5000
+    assert np.allclose(sorted(img.ravel()), sorted(a.ravel()), rtol=1e-4, atol=1e-3)
+
+
+def test_film_develop_through_the_python_layer(mitsuba, hiplib, tmp_path):
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba import _host
+    scene = load_string(TRANS_RAD_LIKE, spp=2000)
+    sensor = scene.sensors()[0]
+    scene.integrator().render(scene, sensor)
+    film = sensor.film()
+    film.set_destination_file(str(tmp_path / "transient"))          # ".exr" is appended
+    film.develop()
+    img, names = _host.read_exr(str(tmp_path / "transient.exr"))
+    bmp = film.bitmap(raw=True)
+    ref = np.array(bmp)
+    for k, n in enumerate(names):
+        assert np.array_equal(img[:, :, k], ref[:, :, bmp.channel_names().index(n)])

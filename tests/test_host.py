@@ -334,6 +334,25 @@ def test_phase_integrator_plugin_and_nested_depths(mitsuba):
     assert (lp.mode, lp.max_depth) == (capi.BF_MODE_RANGE, 2)
 
 
+def test_exr_writer_round_trip(mitsuba, tmp_path):
+    """Film / ADC develop(): multi-channel float32 OpenEXR (hdrfilm.cpp:213-249, hdradc.cpp:259-295), uncompressed.
+    Channels are stored alphabetically, as the format requires."""
+    from beifong_amd.mitsuba import _host
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((3, 5, 6)).astype(np.float32)
+    names = ["Y", "A", "W", "S0.Y", "S1.Y", "S10.Y"]
+    path = str(tmp_path / "adc.exr")
+    _host.write_exr(path, a, names)
+    back, order = _host.read_exr(path)
+    assert order == sorted(names) and back.shape == a.shape
+    for k, n in enumerate(order):
+        assert np.array_equal(back[:, :, k].view(np.uint32), a[:, :, names.index(n)].view(np.uint32))
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"\x76\x2f\x31\x01" and len(raw) > a.nbytes
+    with pytest.raises(_host.HostError):
+        _host.write_exr(path, a[:, :, :2], ["Y", "Y"])
+
+
 def test_load_dict_matches_load_string(mitsuba):
     """animated_trans_rad.py-style dictionaries (python_scripts/animated_trans_rad.py:100-230)."""
     from beifong_amd.mitsuba.core import Transform4f
