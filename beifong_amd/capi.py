@@ -15,9 +15,10 @@ BF_OK, BF_ERR_INVALID, BF_ERR_DEVICE, BF_ERR_NOMEM, BF_ERR_UNSUPPORTED = range(5
 BF_BSDF_DIFFUSE, BF_BSDF_ROUGHCONDUCTOR, BF_BSDF_NULL = range(3)
 BF_MF_BECKMANN, BF_MF_GGX = range(2)
 BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
-BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER = range(4)
+BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED = range(5)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
-BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER = range(4)
+BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED = range(5)
+BF_VELEM_FLOATS = 32
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
 BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL = 1, 2, 4
@@ -39,12 +40,16 @@ class bf_shape(C.Structure):
                 ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
 
 
+class bf_phased_array(C.Structure):
+    _fields_ = [("velems", C.POINTER(C.c_float)), ("n_velems", C.c_uint32), ("elem_dims", C.c_float * 3)]
+
+
 class bf_emitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("to_world", M16), ("to_object", M16),
                 ("radiance", C.c_float), ("cutoff_angle_deg", C.c_float), ("beam_width_deg", C.c_float),
                 ("signal_type", C.c_uint32), ("amplitude", C.c_float), ("freq_centre", C.c_float),
                 ("freq_ext", C.c_float), ("pulse_len", C.c_float), ("prf", C.c_float), ("gain", C.c_float),
-                ("resample_freq", C.c_uint32)]
+                ("resample_freq", C.c_uint32), ("array", bf_phased_array)]
 
 
 class bf_sensor(C.Structure):
@@ -55,7 +60,8 @@ class bf_sensor(C.Structure):
                 ("adc_sampling_start", C.c_float), ("adc_sampling_time", C.c_float),
                 ("t_bins", C.c_uint32), ("f_bins", C.c_uint32),
                 ("t_bandwidth", C.c_float), ("f_bandwidth", C.c_float),
-                ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32)]
+                ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32),
+                ("array", bf_phased_array)]
 
 
 class bf_physics(C.Structure):

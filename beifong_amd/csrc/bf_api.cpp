@@ -107,6 +107,11 @@ struct bf_scene {
     uint32_t n_materials = 0;
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     float4 *tris0 = nullptr, *nodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
+    // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
+    std::vector<float *> array_dev;
+    std::vector<uint32_t> array_n;
+    float *sensor_array_dev = nullptr;
+    uint32_t sensor_array_n = 0;
     float origin_scale_built = 0.f;        // ray-origin bound the BVH boxes were padded for (bf_bvh.h)
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
@@ -190,6 +195,43 @@ struct Flat {
     float origin_scale = 0.f;             // largest |coordinate| of a rectangle corner, emitter or sensor position
 };
 }  // namespace
+
+// Phased-array tables arrive as host pointers inside the flattened records: copy them to the device (allocating on
+// scene creation, in place — same sizes required — on bf_scene_update_endpoints: beam steering between frames) and
+// patch the records with the device addresses.
+static bf_status bind_arrays(bf_scene *sc, Flat &f, hipStream_t stream, bool creating) {
+    auto put = [&](const float *host, uint32_t n, float *&dev, uint32_t &dev_n) -> bf_status {
+        const size_t bytes = (size_t) n * BF_VELEM_FLOATS * sizeof(float);
+        if (creating) {
+            void *p = nullptr;
+            HIP_TRY(hipMalloc(&p, bytes));
+            sc->owned.push_back(p);
+            dev = (float *) p;
+            dev_n = n;
+        } else if (!dev || dev_n != n) {
+            return fail(BF_ERR_INVALID, "bf_scene_update_endpoints: phased array size changed (%u -> %u virtual elements)", dev_n, n);
+        }
+        HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
+        return BF_OK;
+    };
+    if (creating) {
+        sc->array_dev.assign(f.emitters.size(), nullptr);
+        sc->array_n.assign(f.emitters.size(), 0u);
+    }
+    for (size_t i = 0; i < f.emitters.size(); ++i) {
+        if (f.emitters[i].type != BF_TRANSMITTER_PHASED) continue;
+        if (i >= sc->array_dev.size()) return fail(BF_ERR_INVALID, "emitter layout changed");
+        bf_status st = put(f.emitters[i].velems, f.emitters[i].n_velems, sc->array_dev[i], sc->array_n[i]);
+        if (st != BF_OK) return st;
+        f.emitters[i].velems = sc->array_dev[i];
+    }
+    if (f.sensor.type == BF_RECEIVER_PHASED) {
+        bf_status st = put(f.sensor.velems, f.sensor.n_velems, sc->sensor_array_dev, sc->sensor_array_n);
+        if (st != BF_OK) return st;
+        f.sensor.velems = sc->sensor_array_dev;
+    }
+    return BF_OK;
+}
 
 static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
     std::vector<bfd::DShape> &shapes = f.shapes;
@@ -278,11 +320,18 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
             de.inv_transition = 1.0f / (de.cutoff - de.beam);
             de.cos_cutoff = bfk_host_cos(de.cutoff);
             de.cos_beam = bfk_host_cos(de.beam);
-        } else if (e.type == BF_EMITTER_AREA || e.type == BF_TRANSMITTER_AREA || e.type == BF_TRANSMITTER_WIGNER) {
+        } else if (e.type == BF_EMITTER_AREA || e.type == BF_TRANSMITTER_AREA || e.type == BF_TRANSMITTER_WIGNER ||
+                   e.type == BF_TRANSMITTER_PHASED) {
             if (e.shape < 0 || e.shape >= (int32_t) desc->n_shapes || desc->shapes[e.shape].type != BF_SHAPE_RECTANGLE)
                 return fail(BF_ERR_UNSUPPORTED, "emitter %u: area emitters / transmitters must sit on a rectangle", i);
             de.rect = shapes[e.shape].rect;
-            if (e.type == BF_TRANSMITTER_WIGNER) {
+            if (e.type == BF_TRANSMITTER_PHASED) {
+                if (!e.array.velems || e.array.n_velems == 0) return fail(BF_ERR_INVALID, "emitter %u: phased transmitter without array elements", i);
+                de.velems = e.array.velems;          // host pointer for now; replaced by the device copy on upload
+                de.n_velems = e.array.n_velems;
+                for (int k = 0; k < 3; ++k) de.wid[k] = e.array.elem_dims[k];
+            }
+            if (e.type == BF_TRANSMITTER_WIGNER || e.type == BF_TRANSMITTER_PHASED) {
                 if (e.resample_freq) return fail(BF_ERR_UNSUPPORTED, "emitter %u: resample_freq=true is not supported", i);
                 if (e.signal_type > BF_SIGNAL_LINFMCW) return fail(BF_ERR_INVALID, "emitter %u: unknown signal type", i);
                 de.signal_type = e.signal_type;
@@ -304,7 +353,7 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
     sen.type = desc->sensor.type;
     sen.rect = -1;
     if (desc->sensor.type == BF_SENSOR_FLUXMETER || desc->sensor.type == BF_RECEIVER_OMNI ||
-        desc->sensor.type == BF_RECEIVER_WIGNER) {
+        desc->sensor.type == BF_RECEIVER_WIGNER || desc->sensor.type == BF_RECEIVER_PHASED) {
         int32_t sh = desc->sensor.shape;
         if (sh < 0 || sh >= (int32_t) desc->n_shapes || desc->shapes[sh].type != BF_SHAPE_RECTANGLE) {
             return fail(BF_ERR_UNSUPPORTED, "fluxmeter / receiver must sit on a rectangle");
@@ -320,6 +369,13 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         sen.freq_ext = desc->sensor.freq_ext;
         sen.gain = desc->sensor.gain;
         sen.rx_sig_is_delta = desc->sensor.rx_sig_is_delta;
+        if (desc->sensor.type == BF_RECEIVER_PHASED) {
+            if (!desc->sensor.array.velems || desc->sensor.array.n_velems == 0)
+                return fail(BF_ERR_INVALID, "phased receiver without array elements");
+            sen.velems = desc->sensor.array.velems;      // host pointer for now (see bind_arrays)
+            sen.n_velems = desc->sensor.array.n_velems;
+            for (int k = 0; k < 3; ++k) sen.wid[k] = desc->sensor.array.elem_dims[k];
+        }
     } else if (desc->sensor.type == BF_SENSOR_PERSPECTIVE) {
         m34(desc->sensor.to_world, sen.to_world);
         std::memcpy(sen.sample_to_camera, desc->sensor.sample_to_camera, 16 * sizeof(float));
@@ -374,6 +430,13 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     std::memset(&sc->d, 0, sizeof(sc->d));
     std::memset(&sc->info, 0, sizeof(sc->info));
     std::memset(&sc->wf, 0, sizeof(sc->wf));
+    {
+        bf_status ast = bind_arrays(sc, flat, nullptr, true);
+        if (ast != BF_OK) {
+            bf_scene_destroy(sc);
+            return ast;
+        }
+    }
     sc->sensor_host = flat.sensor;
     sc->origin_scale_built = origin_scale;
     bf::BVH bvh;
@@ -500,6 +563,10 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
                                         "BVH boxes were padded for; create a new scene", (double) f.origin_scale,
                     (double) scene->origin_scale_built);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    {
+        bf_status ast = bind_arrays(scene, f, stream, false);
+        if (ast != BF_OK) return ast;
+    }
     // small tables, copied in stream order (pageable sources are staged by the runtime before the call returns)
     if (!f.rects.empty())
         HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, f.rects.data(), f.rects.size() * sizeof(bfd::DRect), hipMemcpyHostToDevice, stream));
@@ -780,7 +847,8 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
                            void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
-    const bool is_rx = scene->sensor_host.type == BF_RECEIVER_OMNI || scene->sensor_host.type == BF_RECEIVER_WIGNER;
+    const bool is_rx = scene->sensor_host.type == BF_RECEIVER_OMNI || scene->sensor_host.type == BF_RECEIVER_WIGNER ||
+                       scene->sensor_host.type == BF_RECEIVER_PHASED;
     const bool receive_mode = launch->mode == BF_MODE_RECEIVE_RAW || launch->mode == BF_MODE_RECEIVE_IQ;
     if (receive_mode) {
         if (!is_rx) return fail(BF_ERR_INVALID, "receive mode needs a receiver (omnidirectional / wigner)");
@@ -788,7 +856,8 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
             return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size (%u x %u)", launch->bins,
                         launch->bins_y, scene->sensor_host.t_bins, scene->sensor_host.f_bins);
         for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
-            if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER)
+            if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER &&
+                scene->emitter_types[i] != BF_TRANSMITTER_PHASED)
                 return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);
     } else {
         if (is_rx) return fail(BF_ERR_INVALID, "render modes need a sensor (fluxmeter / perspective), not a receiver");

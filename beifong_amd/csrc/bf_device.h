@@ -45,6 +45,10 @@ struct DEmitter {
     // wigner transmitter signal model (wignertransmitter.cpp:53-110)
     uint32_t signal_type;
     float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
+    // phased array (phasedtransmitter.cpp:108-165): n_velems virtual elements, BF_VELEM_FLOATS floats each (device copy)
+    const float *velems;
+    uint32_t n_velems;
+    float wid[3];
 };
 
 struct DSensor {
@@ -59,6 +63,9 @@ struct DSensor {
     float t_bandwidth, f_bandwidth;
     float freq_centre, freq_ext, gain;
     uint32_t rx_sig_is_delta;
+    const float *velems;      // BF_RECEIVER_PHASED (phasedreceiver.cpp:115-172)
+    uint32_t n_velems;
+    float wid[3];
 };
 
 struct DScene {

@@ -222,6 +222,30 @@ BF_DEV float rect_sample_wigner(const DRect &rc, V3 p, V3 d, float lambda_nm) {
     return 4 * tri_j(r_hat.x) * tri_j(r_hat.y) * sinc_j(kTwoPi * nu_x * wid_x * tri_j(r_hat.x)) *
            sinc_j(kTwoPi * nu_y * wid_y * tri_j(r_hat.y));
 }
+// PhasedTransmitter / Phasedreceiver::sample_wigner — phasedtransmitter.cpp:273-291, phasedreceiver.cpp:279-297:
+// real part of the sum over the n^2 virtual elements of
+//   W_rect_2D(r, nu, wid) * exp(j 2 pi nu . r') * psi',   r = velem_to_object * p / 2 (only |r.x|, |r.y| <= 0.5),
+//   nu = dir_to_local * d / (lambda 1e-9)
+BF_DEV float phased_sample_wigner(const float *__restrict__ tab, uint32_t n, const float *wid, V3 p, V3 d, float lambda_nm) {
+    const float kTwoPi = 6.28318530717958647692f;
+    const double inv = 1.0 / ((double) lambda_nm * 1e-9);
+    float w_re = 0.f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *e = tab + (size_t) BF_VELEM_FLOATS * i;
+        V3 r_hat = xf_point(e, p) / 2.f;
+        if (jabs(r_hat.x) <= 0.5f && jabs(r_hat.y) <= 0.5f) {
+            V3 md = xf_vector(e + 12, d);
+            V3 nu = mk((float) ((double) md.x * inv), (float) ((double) md.y * inv), (float) ((double) md.z * inv));
+            float tx = tri_j(r_hat.x), ty = tri_j(r_hat.y);
+            float wr = 4 * wid[0] * wid[1] * tx * ty * sinc_j(kTwoPi * nu.x * wid[0] * tx) * sinc_j(kTwoPi * nu.y * wid[1] * ty);
+            float sn, cs;
+            bf_sincos(kTwoPi * dot(nu, mk(e[24], e[25], e[26])), sn, cs);
+            float a = wr * cs, b = wr * sn;                       // W_rect * exp(j ...)
+            w_re += a * e[28] - b * e[29];                        // ... * psi', real part
+        }
+    }
+    return w_re;
+}
 BF_DEV float tx_eval_signal(const DEmitter &e, float time, float frequency) {
     if (e.signal_type == BF_SIGNAL_LINFMCW) {
         float t = fmodulo_j(time, rcp(e.prf));
@@ -243,6 +267,12 @@ BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si,
     const DRect &rc = sc.rects[e.rect];
     if (e.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.radiance * rc.area : 0.f;
     float signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
+    if (e.type == BF_TRANSMITTER_PHASED) {
+        // phasedtransmitter.cpp:296-381: geom_gain = antenna / area * sample_wigner(ds with the uninitialised d, Q5)
+        float geom_gain = 1.f * rcp(rc.area);
+        geom_gain *= phased_sample_wigner(e.velems, e.n_velems, e.wid, si.p, mk(-0.f, -0.f, -0.f), lambda0);
+        return (si.wi.z > 0.f) ? signal_power * e.gain * geom_gain : 0.f;
+    }
     float ws = rect_sample_wigner(rc, si.p, mk(0.f, 0.f, 0.f), lambda0);   // Q5: ds.d never initialised -> 0
     return (si.wi.z > 0.f) ? signal_power * e.gain * (1.f * ws) * 6.28318530717958647692f : 0.f;
 }
@@ -269,6 +299,14 @@ BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V
     float t = ref_time;
     if ((double) ds.dist > 5e-7) t += -ds.dist / sc.c;                      // retarded time :422-425
     float signal_power = tx_eval_signal(e, t, freq_of(sc.c, lambda0));
+    if (e.type == BF_TRANSMITTER_PHASED) {
+        // phasedtransmitter.cpp:560-585: geom_gain *= W; ds.pdf *= W; ds.pdf = sqrt(ds.pdf^2); extents = 1
+        float w = phased_sample_wigner(e.velems, e.n_velems, e.wid, p, -ds.d, lambda0);
+        geom_gain *= w;
+        ds.pdf *= w;
+        ds.pdf = __builtin_sqrtf(ds.pdf * ds.pdf);
+        return active ? signal_power * e.gain * geom_gain * 1.f : 0.f;
+    }
     float ws = rect_sample_wigner(rc, p, -ds.d, lambda0);
     geom_gain *= ws;
     ds.pdf *= ws;
@@ -285,6 +323,10 @@ BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p
     float value = rc.inv_area, adp = __builtin_fabsf(dot(d, n_hit));
     value *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
     if (e.type == BF_TRANSMITTER_WIGNER) value *= rect_sample_wigner(rc, p_hit, -d, lambda0);
+    if (e.type == BF_TRANSMITTER_PHASED) {                         // phasedtransmitter.cpp:606-620
+        value *= phased_sample_wigner(e.velems, e.n_velems, e.wid, p_hit, -d, lambda0);
+        value = __builtin_sqrtf(value * value);
+    }
     return (dp < 0.f) ? value : 0.f;
 }
 
@@ -308,6 +350,15 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
     }
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
     lambda0 = (float) ((double) (sc.c * rcp(freq)) * 1e9);
+    if (s.type == BF_RECEIVER_PHASED) {
+        // phasedreceiver.cpp:299-365: geom_gain = W(ds) * pdf * (1 - (ds.d . ds.n)^4), ds.d the LOCAL cosine direction
+        float w = phased_sample_wigner(s.velems, s.n_velems, s.wid, o, local, lambda0);
+        float dn = dot(local, f.n);
+        float geom = w * rc.inv_area * (1 - dn * dn * dn * dn);
+        float ext = rc.area * kPi;
+        if (!s.rx_sig_is_delta) ext = (float) ((double) (ext * (sc.c * rcp(s.freq_ext))) * 1e9);
+        return 1.f * s.gain * geom * ext;
+    }
     float ws = rect_sample_wigner(rc, o, local, lambda0);   // ds.d is the LOCAL cosine direction (:249-252)
     float geom_gain = ws * rc.inv_area;
     float extents = rc.area * kPi;

@@ -1,0 +1,41 @@
+// src/receivers/phasedreceiver.cpp:45-172 — Phasedreceiver (fork), receive_type "raw": the Wigner receiver with the
+// array's n_elems^2 virtual elements (sample_wigner :279-297) and the (1 - cos^4) taper of sample_ray_differential (:338)
+#include "../render.h"
+using namespace bfh;
+class Phasedreceiver final : public Receiver {
+public:
+    explicit Phasedreceiver(const Properties &props) : Receiver(props), m_array(props) {
+        if (props.has_property("to_world"))
+            Throw("Found a 'to_world' transformation -- this is not allowed. The phased receiver inherits this "
+                  "transformation from its parent shape.");
+        if (m_adc->reconstruction_filter()->radius() > 0.5f + 1500 * 5.9604644775390625e-8f)
+            Throw("phasedreceiver: only the box reconstruction filter is supported (adc rfilter radius <= 0.5)");
+        m_f_centre = props.float_("freq_centre", 1.f);
+        m_f_ext = props.float_("freq_ext", 1.f);
+        m_gain = props.float_("gain", 1.f);
+        // :258 reads m_sig_is_delta, which the raw branch never initialises; explicit here
+        m_sig_is_delta = props.bool_("sig_is_delta", false);
+    }
+    void flatten(bf_sensor &s, int32_t shape) const override {
+        if (shape < 0) Throw("receiver must be the child of a shape");
+        s.type = BF_RECEIVER_PHASED;
+        s.array = m_array.flat();
+        s.shape = shape;
+        s.film_width = s.film_height = 1;
+        s.adc_sampling_start = m_adc_sampling_start;
+        s.adc_sampling_time = m_adc_sampling_time;
+        s.t_bins = m_adc->t_bins();
+        s.f_bins = m_adc->f_bins();
+        s.t_bandwidth = m_adc->t_bandwidth();
+        s.f_bandwidth = m_adc->f_bandwidth();
+        s.freq_centre = m_f_centre;
+        s.freq_ext = m_f_ext;
+        s.gain = m_gain;
+        s.rx_sig_is_delta = m_sig_is_delta;
+    }
+private:
+    float m_f_centre, m_f_ext, m_gain;
+    bool m_sig_is_delta;
+    PhasedArray m_array;
+};
+BF_EXPORT_PLUGIN(Phasedreceiver, "Receiver", "phasedreceiver", "Phasedreceiver")

@@ -88,6 +88,70 @@ void Film::put(const float *data, size_t n) {
     for (size_t i = 0; i < n; ++i) m_storage[i] += data[i];
 }
 
+// MTS_WAVELENGTH_MIN / MAX of the fork at HEAD (spectrum.h:15-30): compile-time constants there
+static constexpr float kLambdaMinNm = 7555556.f, kLambdaMaxNm = 9714286.f;
+
+PhasedArray::PhasedArray(const Properties &props) {
+    const int n = (int) props.int_("n_elems", 1);
+    if (n < 1 || n > 256) Throw("phased array: n_elems must be in [1, 256]");
+    Vector3f steer = props.vector3f("steering_vector", Vector3f());
+    steer = Vector3f{std::sin(steer.x), std::sin(steer.y), std::sin(steer.z)};          // steer_vec = sin(steer_vec)
+    const Transform4f array_to_world = props.transform("array_loc", Transform4f());
+    const Vector3f wid = props.vector3f("elem_dims", Vector3f());
+    const Vector3f spacing = props.vector3f("elem_spacing", Vector3f());
+    const Vector3f axis = props.vector3f("elem_axis", Vector3f());
+    elem_dims[0] = wid.x; elem_dims[1] = wid.y; elem_dims[2] = wid.z;
+    const Vector3f step{spacing.x * axis.x, spacing.y * axis.y, spacing.z * axis.z};
+    std::vector<Vector3f> locs((size_t) n);
+    for (int i = 0; i < n; ++i) {
+        // array_centre - elem_spacing*elem_axis*(i - (n/2.f) + 0.5)   (even n)   or   (i - (n-1.f)/2.f)   (odd n)
+        const float k = (n % 2 == 0) ? (float) ((double) ((float) i - (float) n / 2.f) + 0.5) : (float) i - ((float) n - 1.f) / 2.f;
+        locs[(size_t) i] = Vector3f{0.f - step.x * k, 0.f - step.y * k, 0.f - step.z * k};
+    }
+    const float K = (float) (1.0 / ((double) (kLambdaMaxNm - kLambdaMinNm) * 1e-9 / 2));
+    n_velems = (uint32_t) (n * n);
+    table.assign((size_t) n_velems * BF_VELEM_FLOATS, 0.f);
+    auto mulv = [](const Matrix4f &m, float x, float y, float z) {            // 3x3 part times a vector
+        return Vector3f{m.m[0] * x + m.m[1] * y + m.m[2] * z, m.m[4] * x + m.m[5] * y + m.m[6] * z, m.m[8] * x + m.m[9] * y + m.m[10] * z};
+    };
+    auto normalized = [](Vector3f v) {
+        const float inv = 1.f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+        return Vector3f{v.x * inv, v.y * inv, v.z * inv};
+    };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const Vector3f a = locs[(size_t) i], b = locs[(size_t) j];
+            const Vector3f r_v{(a.x + b.x) / 2, (a.y + b.y) / 2, (a.z + b.z) / 2};
+            const Vector3f r_dash{a.x - b.x, a.y - b.y, a.z - b.z};
+            const Transform4f t = array_to_world * Transform4f::translate(r_v) * Transform4f::scale(Vector3f{wid.x / 2, wid.y / 2, wid.z});
+            const Vector3f dp_du = mulv(t.matrix, 2.f, 0.f, 0.f), dp_dv = mulv(t.matrix, 0.f, 2.f, 0.f);
+            // normals transform with the inverse transpose: column 2 of the inverse's rows
+            const Vector3f nrm = normalized(Vector3f{t.inverse.m[8], t.inverse.m[9], t.inverse.m[10]});
+            const Vector3f fs = normalized(dp_du), ft = normalized(dp_dv), fn = normalized(nrm);
+            float *row = table.data() + ((size_t) i * (size_t) n + (size_t) j) * BF_VELEM_FLOATS;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) row[4 * r + c] = t.inverse.m[4 * r + c];     // m_velem_to_object
+            const Vector3f rows[3] = {fs, ft, fn};                                           // Transform::from_frame: rows s, t, n
+            for (int r = 0; r < 3; ++r) {
+                row[12 + 4 * r + 0] = rows[r].x;
+                row[12 + 4 * r + 1] = rows[r].y;
+                row[12 + 4 * r + 2] = rows[r].z;
+            }
+            row[24] = r_dash.x; row[25] = r_dash.y; row[26] = r_dash.z;
+            // m_psi_dash = exp(j * K * dot(array_centre - r', steer_vec))
+            const float theta = K * ((0.f - r_dash.x) * steer.x + (0.f - r_dash.y) * steer.y + (0.f - r_dash.z) * steer.z);
+            row[28] = std::cos(theta);
+            row[29] = std::sin(theta);
+        }
+}
+bf_phased_array PhasedArray::flat() const {
+    bf_phased_array a{};
+    a.velems = table.data();
+    a.n_velems = n_velems;
+    for (int k = 0; k < 3; ++k) a.elem_dims[k] = elem_dims[k];
+    return a;
+}
+
 static std::string exr_path(const std::string &dest) {
     if (dest.empty()) Throw("develop(): no destination file set");
     size_t slash = dest.find_last_of('/'), dot = dest.find_last_of('.');
@@ -393,8 +457,8 @@ void Scene::flatten(const Endpoint *endpoint) {
     if (!endpoint_found) Throw("Scene: the given sensor / receiver does not belong to this scene");
     // physics constants of the fork at HEAD (spectrum.h:15-40, math.h:40-41)
     fl->desc.physics.c = 340.0f;
-    fl->desc.physics.lambda_min_nm = 7555556.f;
-    fl->desc.physics.lambda_max_nm = 9714286.f;
+    fl->desc.physics.lambda_min_nm = kLambdaMinNm;
+    fl->desc.physics.lambda_max_nm = kLambdaMaxNm;
     fl->desc.shapes = fl->shapes.data();
     fl->desc.n_shapes = (uint32_t) fl->shapes.size();
     fl->desc.materials = fl->materials.data();

@@ -124,6 +124,17 @@ public:
     const Class *class_() const override;
 };
 /// fork: include/mitsuba/render/transmitter.h
+/// The n_elems^2 virtual elements the phased-array constructors precompute (phasedtransmitter.cpp:108-165 ==
+/// phasedreceiver.cpp:115-172), in the layout of bf_phased_array (BF_VELEM_FLOATS floats per element).  Reads the
+/// properties n_elems, steering_vector, array_loc, elem_dims, elem_spacing, elem_axis.
+struct PhasedArray {
+    std::vector<float> table;
+    float elem_dims[3] = {0, 0, 0};
+    uint32_t n_velems = 0;
+    explicit PhasedArray(const Properties &props);
+    bf_phased_array flat() const;
+};
+
 class Transmitter : public Endpoint {
 public:
     using Endpoint::Endpoint;

@@ -233,16 +233,68 @@ class SceneDesc:
     # ---- receivers + ADC (gen-3) ----
     def set_receiver(self, shape, kind="omnidirectional", adc_sampling_start=0.0, adc_sampling_end=0.0, t_bins=1024,
                      f_bins=1024, t_bandwidth=3.81e-6, f_bandwidth=250e6, freq_centre=1.0, freq_ext=1.0, gain=1.0,
-                     sig_is_delta=False):
+                     sig_is_delta=False, array=None):
         """receiver.cpp:16-62 + adc.cpp:18-46 (box rfilter, full window)."""
         s = self.sensor
-        s.type = capi.BF_RECEIVER_OMNI if kind == "omnidirectional" else capi.BF_RECEIVER_WIGNER
+        s.type = {"omnidirectional": capi.BF_RECEIVER_OMNI, "wigner": capi.BF_RECEIVER_WIGNER,
+                  "phased": capi.BF_RECEIVER_PHASED}[kind]
+        if array is not None:
+            s.array = array
         s.shape = shape
         self.shapes[shape].is_sensor = 1
         s.adc_sampling_start = adc_sampling_start
         s.adc_sampling_time = f32(adc_sampling_end) - f32(adc_sampling_start)
         s.t_bins, s.f_bins, s.t_bandwidth, s.f_bandwidth = t_bins, f_bins, t_bandwidth, f_bandwidth
         s.freq_centre, s.freq_ext, s.gain, s.rx_sig_is_delta = freq_centre, freq_ext, gain, int(sig_is_delta)
+
+    # ---- phased arrays (phasedtransmitter.cpp:108-165 == phasedreceiver.cpp:115-172) ----
+    def phased_array(self, n_elems, elem_dims, elem_spacing, elem_axis, steering_vector=(0.0, 0.0, 0.0), array_loc=None):
+        """The n_elems^2 virtual elements of the constructors: pairs (i, j) of physical elements placed at
+        -spacing * axis * (i - (n - 1) / 2) around the array centre; per pair the transform of the virtual
+        element (array_loc * translate((r_i + r_j) / 2) * scale(w_x / 2, w_y / 2, w_z)), its inverse, the frame
+        built from it, r' = r_i - r_j and the steering phasor exp(j K (0 - r') . sin(steer)),
+        K = 1 / ((lambda_max - lambda_min) * 1e-9 / 2)."""
+        n = int(n_elems)
+        loc = array_loc if array_loc is not None else Transform4f()
+        wid = np.asarray(elem_dims, f32)
+        spacing, axis = np.asarray(elem_spacing, f32), np.asarray(elem_axis, f32)
+        steer = np.sin(np.asarray(steering_vector, f32)).astype(f32)
+        step = (spacing * axis).astype(f32)
+        locs = [(-(step * f32(i - (n / 2.0) + 0.5 if n % 2 == 0 else i - (n - 1.0) / 2.0))).astype(f32) for i in range(n)]
+        k = f32(1.0 / ((np.float64(f32(self.physics.lambda_max_nm) - f32(self.physics.lambda_min_nm))) * 1e-9 / 2))
+        tab = np.zeros((n * n, capi.BF_VELEM_FLOATS), f32)
+        for i in range(n):
+            for j in range(n):
+                r_v = ((locs[i] + locs[j]) / f32(2)).astype(f32)
+                r_dash = (locs[i] - locs[j]).astype(f32)
+                t = loc * Transform4f.translate(r_v) * Transform4f.scale([wid[0] / f32(2), wid[1] / f32(2), wid[2]])
+                m, inv = t.matrix.astype(f32), t.inv.astype(f32)
+                dp_du, dp_dv = m[:3, :3] @ np.array([2, 0, 0], f32), m[:3, :3] @ np.array([0, 2, 0], f32)
+                nrm = inv[:3, :3].T @ np.array([0, 0, 1], f32)          # normals transform with the inverse transpose
+                cols = [v / np.linalg.norm(v) for v in (dp_du.astype(np.float64), dp_dv.astype(np.float64), nrm.astype(np.float64))]
+                d2l = np.stack(cols, 0).astype(f32)                       # Transform::from_frame: ROWS s, t, n (transform.h:284-295)
+                theta = f32(k * f32(np.dot((-r_dash).astype(f32), steer)))
+                row = tab[i * n + j]
+                row[0:12] = inv[:3, :4].reshape(-1)
+                row[12:24] = np.concatenate([d2l, np.zeros((3, 1), f32)], 1).reshape(-1)
+                row[24:27] = r_dash
+                row[28], row[29] = np.cos(np.float64(theta)), np.sin(np.float64(theta))
+        tab = np.ascontiguousarray(tab)
+        self._keep.append(tab)
+        a = capi.bf_phased_array()
+        a.velems = tab.ctypes.data_as(C.POINTER(C.c_float))
+        a.n_velems = n * n
+        a.elem_dims = (C.c_float * 3)(*[float(x) for x in wid])
+        return a
+
+    def add_phased_transmitter(self, shape, array, signaltype="cw", amplitude=1.0, freq_centre=1.0, freq_ext=0.0, pulse_len=1.0,
+                               prf=1.0, gain=1.0):
+        """phasedtransmitter.cpp: the signal model of the Wigner transmitter + the array's Wigner function."""
+        i = self.add_wigner_transmitter(shape, signaltype=signaltype, amplitude=amplitude, freq_centre=freq_centre,
+                                        freq_ext=freq_ext, pulse_len=pulse_len, prf=prf, gain=gain)
+        self.emitters[i].type = capi.BF_TRANSMITTER_PHASED
+        self.emitters[i].array = array
+        return i
 
     # ---- sensors ----
     def set_fluxmeter(self, shape):

@@ -188,3 +188,38 @@ def single_mesh(v, f, normals=None):
     sd.set_perspective(T.translate([0, 0, 0]), fov=45.0, near_clip=0.1, far_clip=100.0)
     sd.finalize()
     return sd
+
+
+def phased_receive(n_tris=20000, n_paths=20000, n_elems=4, steer_deg=(0.0, 0.0, 0.0), phased_rx=True, phased_tx=True,
+                   t_bins=64, dr=0.1, seed=6):
+    """Gen-3 scene with the fork's phased-array endpoints (src/transmitters/phasedtransmitter.cpp,
+    src/receivers/phasedreceiver.cpp): n_elems elements of 20 x 50 mm spaced 25 mm along the aperture's local x axis,
+    steered by `steer_deg`; pulse signal as in bus_receive; the bus + ground as targets."""
+    sd = SceneDesc()
+    c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
+    pose = T.translate([0, 0, 0.3]) * d0
+    aperture = pose * T.scale([0.5 * n_elems * 25e-3, 25e-3, 1])
+    txa = sd.add_rectangle(aperture, sd.add_diffuse(0.0))
+    rxa = sd.add_rectangle(aperture, sd.add_diffuse(0.5))
+    tau = 2.0 * dr / c
+    t_total = t_bins * tau
+    f_c = c / (0.5 * (lmin + lmax) * 1e-9)
+    arr = lambda: sd.phased_array(n_elems, elem_dims=[20e-3, 50e-3, 1.0], elem_spacing=[25e-3, 0.0, 0.0], elem_axis=[1.0, 0.0, 0.0],
+                                  steering_vector=np.radians(steer_deg), array_loc=pose)
+    if phased_tx:
+        sd.add_phased_transmitter(txa, arr(), signaltype="pulse", amplitude=1.0, freq_centre=f_c, freq_ext=1.0 / tau,
+                                  pulse_len=tau, prf=1.0 / t_total, gain=1.0)
+    else:
+        sd.add_wigner_transmitter(txa, signaltype="pulse", amplitude=1.0, freq_centre=f_c, freq_ext=1.0 / tau, pulse_len=tau,
+                                  prf=1.0 / t_total, gain=1.0)
+    sd.set_receiver(rxa, kind="phased" if phased_rx else "omnidirectional", adc_sampling_start=0.0, adc_sampling_end=t_total,
+                    t_bins=t_bins, f_bins=1, t_bandwidth=t_total, f_bandwidth=2.0 * c / (lmin * 1e-9), freq_centre=f_c,
+                    freq_ext=c / (lmin * 1e-9) - c / (lmax * 1e-9), array=arr() if phased_rx else None)
+    _ground(sd)
+    car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
+    v, f = meshgen.bus(n_tris, seed=1)
+    sd.add_mesh(meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7)), f, car)
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, n_paths, seed=seed, bins=t_bins, bins_y=1)
+    return sd, launch

@@ -92,9 +92,23 @@ enum {
     BF_EMITTER_SPOT = 0,         /* src/emitters/spot.cpp:64-170             */
     BF_EMITTER_AREA = 1,         /* src/emitters/area.cpp:64-150             */
     BF_TRANSMITTER_AREA = 2,     /* src/transmitters/areatransmitter.cpp     */
-    BF_TRANSMITTER_WIGNER = 3    /* src/transmitters/wignertransmitter.cpp   */
+    BF_TRANSMITTER_WIGNER = 3,   /* src/transmitters/wignertransmitter.cpp   */
+    BF_TRANSMITTER_PHASED = 4    /* src/transmitters/phasedtransmitter.cpp   */
 };
 enum { BF_SIGNAL_CW = 0, BF_SIGNAL_PULSE = 1, BF_SIGNAL_LINFMCW = 2 };
+
+/* Phased array (phasedtransmitter.cpp:108-165, phasedreceiver.cpp:115-172): the
+ * n_elems^2 VIRTUAL elements the constructors precompute, BF_VELEM_FLOATS floats
+ * each:  [0..11] m_velem_to_object (3x4 row-major),  [12..23] m_dir_to_local_velem
+ * (3x4 row-major, no translation),  [24..26] m_r_dash,  [28..29] m_psi_dash (re, im),
+ * the rest 0.  The host layer (plugins/phased*.cpp) and beifong_amd/scenedesc.py
+ * build them. */
+#define BF_VELEM_FLOATS 32
+typedef struct bf_phased_array {
+    const float *velems;     /* n_velems * BF_VELEM_FLOATS floats, or NULL   */
+    uint32_t n_velems;       /* n_elems * n_elems                            */
+    float elem_dims[3];      /* m_wid                                        */
+} bf_phased_array;
 
 typedef struct bf_emitter {
     uint32_t type;
@@ -108,6 +122,7 @@ typedef struct bf_emitter {
     uint32_t signal_type;
     float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
     uint32_t resample_freq;
+    bf_phased_array array;   /* BF_TRANSMITTER_PHASED                        */
 } bf_emitter;
 
 /* ---------------- sensor / receiver + film / adc ------------------------- */
@@ -115,7 +130,8 @@ enum {
     BF_SENSOR_FLUXMETER = 0,     /* src/sensors/fluxmeter.cpp:63-105         */
     BF_SENSOR_PERSPECTIVE = 1,   /* src/sensors/perspective.cpp:95-199       */
     BF_RECEIVER_OMNI = 2,        /* src/receivers/omnidirectional.cpp:51-139 */
-    BF_RECEIVER_WIGNER = 3       /* src/receivers/wignerreceiver.cpp:43-299  */
+    BF_RECEIVER_WIGNER = 3,      /* src/receivers/wignerreceiver.cpp:43-299  */
+    BF_RECEIVER_PHASED = 4       /* src/receivers/phasedreceiver.cpp         */
 };
 
 typedef struct bf_sensor {
@@ -135,6 +151,7 @@ typedef struct bf_sensor {
     float freq_centre, freq_ext, gain;     /* wigner receiver                */
     uint32_t rx_sig_is_delta;  /* wignerreceiver.cpp:258 reads an uninitialised
                                   m_sig_is_delta in raw mode; made explicit  */
+    bf_phased_array array;   /* BF_RECEIVER_PHASED                           */
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

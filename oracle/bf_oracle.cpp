@@ -519,6 +519,7 @@ struct OScene {
     std::vector<Emitter> emitters;
     bf_sensor sensor;
     bf_physics physics;
+    std::vector<std::vector<float>> array_tables;   // deep copies of the phased-array element tables
     M4 cam_to_world, sample_to_camera;    // perspective
     // accel
     std::vector<BVHNode> nodes;
@@ -1322,6 +1323,39 @@ static float rect_sample_wigner(const Rect &rc, V3 p, V3 d, float lambda_nm) {
     return gain;
 }
 
+// PhasedTransmitter / Phasedreceiver::sample_wigner — phasedtransmitter.cpp:273-291 == phasedreceiver.cpp:279-297.
+// W = sum over the n^2 virtual elements whose footprint holds p of
+//     W_rect_2D(r_hat, nu_hat, wid) * exp(2 pi j nu_hat . r') * psi',        returned: real(W)
+// r_hat = (velem_to_object * p) / 2, nu_hat = dir_to_local.transform_affine(d) * rcp(lambda * 1e-9) (float * double,
+// stored to a float Normal3f), exp(j x) = (cos x, sin x), complex product (a c - b d, ...).
+static float phased_sample_wigner(const bf_phased_array &arr, V3 p, V3 d, float lambda_nm) {
+    const double inv = 1.0 / ((double) lambda_nm * 1e-9);
+    const float *wid = arr.elem_dims;
+    float w_re = 0.f;
+    for (uint32_t i = 0; i < arr.n_velems; ++i) {
+        const float *e = arr.velems + (size_t) BF_VELEM_FLOATS * i;
+        M4 to_obj, d2l;
+        for (int k = 0; k < 12; ++k) {
+            to_obj.m[k] = e[k];
+            d2l.m[k] = e[12 + k];
+        }
+        to_obj.m[12] = to_obj.m[13] = to_obj.m[14] = d2l.m[12] = d2l.m[13] = d2l.m[14] = 0.f;
+        to_obj.m[15] = d2l.m[15] = 1.f;
+        V3 r_hat = xf_point(to_obj, p) / 2.f;
+        if (jabs(r_hat.x) <= 0.5f && jabs(r_hat.y) <= 0.5f) {
+            V3 md = xf_vector(d2l, d);
+            V3 nu = {(float) ((double) md.x * inv), (float) ((double) md.y * inv), (float) ((double) md.z * inv)};
+            float tx = tri_j(r_hat.x), ty = tri_j(r_hat.y);
+            float wr = 4 * wid[0] * wid[1] * tx * ty * sinc_j(kTwoPi * nu.x * wid[0] * tx) * sinc_j(kTwoPi * nu.y * wid[1] * ty);
+            float sn, cs;
+            bf_sincos(kTwoPi * dot(nu, V3{e[24], e[25], e[26]}), sn, cs);
+            float a = wr * cs, b = wr * sn;
+            w_re += a * e[28] - b * e[29];
+        }
+    }
+    return w_re;
+}
+
 // WignerTransmitter::eval_signal — src/transmitters/wignertransmitter.cpp:111-146
 static float tx_eval_signal(const bf_emitter &e, float time, float frequency) {
     if (e.signal_type == BF_SIGNAL_LINFMCW) {
@@ -1351,6 +1385,13 @@ static float transmitter_eval(const OScene &sc, const Emitter &e, const SI &si, 
     const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
     if (e.d.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.d.radiance * (rc.area) : 0.f;
     float signal_power = tx_eval_signal(e.d, si.time, freq_of(sc, cx.lambda0));
+    if (e.d.type == BF_TRANSMITTER_PHASED) {
+        // phasedtransmitter.cpp:296-381: geom_gain = antenna_texture (1) * rcp(surface_area) * sample_wigner(ds), ds.d the
+        // same uninitialised direction (Q5): 0.  No 2 pi here.
+        float geom_gain = 1.f * rcp(rc.area);
+        geom_gain *= phased_sample_wigner(e.d.array, si.p, V3{-0.f, -0.f, -0.f}, cx.lambda0);
+        return (si.wi.z > 0.f) ? signal_power * e.d.gain * geom_gain : 0.f;
+    }
     // DirectionSample3f ds(si); ds.d *= -1  — d is never initialised there (Q5): defined as 0
     float ws = rect_sample_wigner(rc, si.p, V3{0.f, 0.f, 0.f}, cx.lambda0);
     float geom_gain = 1.f * ws;
@@ -1370,6 +1411,15 @@ static float transmitter_sample_direction(const OScene &sc, const Emitter &e, co
     float geom_gain = 1.f / ds.pdf;
     if ((double) ds.dist > 5e-7) ds.time += -ds.dist / sc.physics.c;       // retarded time :422-425
     float signal_power = tx_eval_signal(e.d, ds.time, freq_of(sc, cx.lambda0));
+    if (e.d.type == BF_TRANSMITTER_PHASED) {
+        // phasedtransmitter.cpp:560-585: Wgain = sample_wigner(-d); geom_gain *= Wgain; ds.pdf *= Wgain[0];
+        // ds.pdf = sqrt(ds.pdf * ds.pdf); extents = 1
+        float w = phased_sample_wigner(e.d.array, ds.p, -ds.d, cx.lambda0);
+        geom_gain *= w;
+        ds.pdf *= w;
+        ds.pdf = std::sqrt(ds.pdf * ds.pdf);
+        return active ? signal_power * e.d.gain * geom_gain * 1.f : 0.f;
+    }
     float ws = rect_sample_wigner(rc, ds.p, -ds.d, cx.lambda0);
     geom_gain *= ws;
     ds.pdf *= ws;
@@ -1385,6 +1435,10 @@ static float transmitter_pdf_direction(const OScene &sc, const Emitter &e, const
     float value = rc.inv_area, adp = std::fabs(dot(ds.d, ds.n));
     value *= (adp != 0.f) ? (ds.dist * ds.dist) / adp : 0.f;
     if (e.d.type == BF_TRANSMITTER_WIGNER) value *= rect_sample_wigner(rc, ds.p, -ds.d, cx.lambda0);
+    if (e.d.type == BF_TRANSMITTER_PHASED) {                       // phasedtransmitter.cpp:606-620
+        value *= phased_sample_wigner(e.d.array, ds.p, -ds.d, cx.lambda0);
+        value = std::sqrt(value * value);
+    }
     return active ? value : 0.f;
 }
 
@@ -1570,6 +1624,16 @@ static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, 
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
     // Wavelength wavelength = MTS_C*rcp(frequencies)*1e9  (float * float, then * double literal)
     cx.lambda0 = (float) ((double) (sc.physics.c * rcp(freq)) * 1e9);
+    if (s.type == BF_RECEIVER_PHASED) {
+        // phasedreceiver.cpp:299-365: geom_gain = sample_wigner(ds) * pdf * (1 - (ds.d . ds.n)^4) with ds.d the LOCAL
+        // cosine direction and ds.n the rectangle's world normal
+        float w = phased_sample_wigner(s.array, p, local, cx.lambda0);
+        float dn = dot(local, rc.frame.n);
+        float geom = w * rc.inv_area * (1 - dn * dn * dn * dn);
+        float ext = area * kPi;
+        if (!s.rx_sig_is_delta) ext = (float) ((double) (ext * (sc.physics.c * rcp(s.freq_ext))) * 1e9);
+        return 1.f * s.gain * geom * ext;
+    }
     float ws = rect_sample_wigner(rc, p, local, cx.lambda0);     // ds.d is the LOCAL cosine direction (:249-252)
     float geom_gain = ws * rc.inv_area;
     float extents = area * kPi;
@@ -1752,6 +1816,11 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
     OScene &sc = h->sc;
     sc.brute_force = brute_force != 0;
     sc.sensor = d->sensor;
+    sc.array_tables.reserve(d->n_emitters + 1);      // no reallocation: the records point into these vectors
+    if (d->sensor.type == BF_RECEIVER_PHASED && d->sensor.array.velems) {
+        sc.array_tables.emplace_back(d->sensor.array.velems, d->sensor.array.velems + (size_t) d->sensor.array.n_velems * BF_VELEM_FLOATS);
+        sc.sensor.array.velems = sc.array_tables.back().data();
+    }
     sc.physics = d->physics;
     sc.materials.assign(d->materials, d->materials + d->n_materials);
     uint32_t prim = 0;
@@ -1814,6 +1883,10 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         Emitter e;
         e.d = d->emitters[i];
+        if (e.d.type == BF_TRANSMITTER_PHASED && e.d.array.velems) {
+            sc.array_tables.emplace_back(e.d.array.velems, e.d.array.velems + (size_t) e.d.array.n_velems * BF_VELEM_FLOATS);
+            e.d.array.velems = sc.array_tables.back().data();
+        }
         std::memcpy(e.to_world.m, e.d.to_world, sizeof(float) * 16);
         if (e.d.type == BF_EMITTER_SPOT) {
             std::memcpy(e.to_object.m, e.d.to_object, sizeof(float) * 16);
@@ -1860,7 +1933,7 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
                      bf_path_record *records_out, bf_stats *stats_out) {
     if (!s || !lp || !hist_out) return BF_ERR_INVALID;
     const bool is_receive = lp->mode == BF_MODE_RECEIVE_RAW || lp->mode == BF_MODE_RECEIVE_IQ;
-    if (is_receive && (s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.type != BF_RECEIVER_WIGNER)) {
+    if (is_receive && (s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.type != BF_RECEIVER_WIGNER && s->sc.sensor.type != BF_RECEIVER_PHASED)) {
         g_err = "receive mode needs a receiver";
         return BF_ERR_INVALID;
     }

@@ -543,3 +543,31 @@ def test_zoo_multi_emitter_one_sided(hiplib, receive, two):
         hg, ho, st = _render_compare(sd, lp)
         if max_depth == -1:
             assert np.count_nonzero(hg) > 3
+
+
+@pytest.mark.parametrize("phased_tx,phased_rx,steer", [(True, True, (0.0, 0.0, 0.0)), (True, False, (12.0, 0.0, 0.0)),
+                                                        (False, True, (0.0, 0.0, 0.0)), (True, True, (20.0, 5.0, 0.0))])
+def test_receive_phased_array_endpoints(hiplib, phased_tx, phased_rx, steer):
+    """src/transmitters/phasedtransmitter.cpp + src/receivers/phasedreceiver.cpp: the array's Wigner function (sum over
+    n_elems^2 virtual elements with complex steering phasors) in eval / sample_direction / pdf_direction / sample_ray."""
+    sd, lp = scenes.phased_receive(n_tris=20000, n_paths=30000, n_elems=4, steer_deg=steer, phased_tx=phased_tx,
+                                   phased_rx=phased_rx)
+    hg, ho, st = _render_compare(sd, lp)
+    assert np.count_nonzero(hg.reshape(64, 3)[:, 0]) > 5
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    _render_compare(sd, lp)
+
+
+def test_phased_array_steering_update(hiplib):
+    """Beam steering between frames: bf_scene_update_endpoints replaces the element tables in place."""
+    sd0, lp = scenes.phased_receive(n_tris=20000, n_paths=20000, steer_deg=(0.0, 0.0, 0.0))
+    sd1, _ = scenes.phased_receive(n_tris=20000, n_paths=20000, steer_deg=(15.0, 0.0, 0.0))
+    g = capi.Scene(sd0)
+    h0, _, _ = g.render(lp)
+    g.update_endpoints(sd1)
+    _render_compare_one(g, lp, OracleScene(sd1).render(lp, records=True, threads=8), 2e-5)
+    h1, _, _ = g.render(lp)
+    assert not np.allclose(h0, h1)
+    sd2, _ = scenes.phased_receive(n_tris=20000, n_paths=20000, n_elems=3)
+    with pytest.raises(capi.BeifongError):
+        g.update_endpoints(sd2)                      # another array size: not an in-place update

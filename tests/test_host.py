@@ -75,7 +75,8 @@ def test_every_plugin_exports_the_reference_plugin_abi(mitsuba):
         names.add(n)
     for need in ("path", "pathlength", "range", "pathtime", "time", "pathtimefrequency", "rectangle", "obj", "ply", "diffuse",
                  "twosided", "roughconductor", "spot", "area", "areatransmitter", "wignertransmitter", "fluxmeter",
-                 "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent"):
+                 "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent", "phase",
+                 "phasedtransmitter", "phasedreceiver"):
         assert need in names, need
 
 
@@ -332,6 +333,76 @@ def test_phase_integrator_plugin_and_nested_depths(mitsuba):
                                                 '<integrator type="pathlength"><integer name="max_depth" value="2"/></integrator>'))
     lp = scene.integrator().launch_for(scene.sensors()[0])
     assert (lp.mode, lp.max_depth) == (capi.BF_MODE_RANGE, 2)
+
+
+PHASED_SCENE = """
+<scene version="2.1.0">
+    <integrator type="pathtimefrequency"/>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.05" y="0.025"/><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+        <transmitter type="phasedtransmitter">
+            <string name="signaltype" value="pulse"/><float name="amplitude" value="1"/>
+            <float name="pulse_len" value="0.000588235"/><float name="prf" value="26.5625"/>
+            <float name="freq_centre" value="39375"/><float name="freq_ext" value="1700"/>
+            <integer name="n_elems" value="4"/>
+            <vector name="steering_vector" x="0.2" y="0" z="0"/>
+            <transform name="array_loc"><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+            <vector name="elem_dims" x="0.02" y="0.05" z="1"/>
+            <vector name="elem_spacing" x="0.025" y="0" z="0"/>
+            <vector name="elem_axis" x="1" y="0" z="0"/>
+        </transmitter>
+    </shape>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="0.05" y="0.025"/><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+        <receiver type="phasedreceiver">
+            <float name="adc_sampling_start" value="0"/><float name="adc_sampling_end" value="0.037647"/>
+            <float name="freq_centre" value="39375"/><float name="freq_ext" value="10000"/>
+            <integer name="n_elems" value="3"/>
+            <transform name="array_loc"><lookat origin="0, 0, 0.3" target="1, 0, 0.3" up="0, 0, 1"/></transform>
+            <vector name="elem_dims" x="0.02" y="0.05" z="1"/>
+            <vector name="elem_spacing" x="0.03" y="0" z="0"/>
+            <vector name="elem_axis" x="1" y="0" z="0"/>
+            <adc type="hdradc"><integer name="t_bins" value="64"/><integer name="f_bins" value="1"/>
+                <float name="t_bandwidth" value="0.037647"/><float name="f_bandwidth" value="90000"/><rfilter type="box"/></adc>
+            <sampler type="independent"><integer name="sample_count" value="4000"/></sampler>
+        </receiver>
+    </shape>
+    <shape type="rectangle">
+        <transform name="to_world"><scale x="20" y="20"/></transform>
+        <bsdf type="twosided"><bsdf type="diffuse"><spectrum name="reflectance" value="0.5"/></bsdf></bsdf>
+    </shape>
+</scene>
+"""
+
+
+def test_phased_array_plugins_build_the_reference_element_tables(mitsuba):
+    """phasedtransmitter / phasedreceiver (src/transmitters, src/receivers of the fork): the constructors'
+    n_elems^2 virtual-element tables (phasedtransmitter.cpp:108-165) from the C++ plugins agree with the numpy builder
+    of beifong_amd/scenedesc.py, and the flattened scene renders through the oracle."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.scenedesc import SceneDesc, Transform4f as T
+    scene = load_string(PHASED_SCENE)
+    rx = scene.receivers()[0]
+    d = scene.flat_desc(rx).desc
+    assert d.emitters[0].type == capi.BF_TRANSMITTER_PHASED and d.sensor.type == capi.BF_RECEIVER_PHASED
+    assert d.emitters[0].array.n_velems == 16 and d.sensor.array.n_velems == 9
+    tab_tx = np.ctypeslib.as_array(d.emitters[0].array.velems, shape=(16, capi.BF_VELEM_FLOATS)).copy()
+    tab_rx = np.ctypeslib.as_array(d.sensor.array.velems, shape=(9, capi.BF_VELEM_FLOATS)).copy()
+    sd = SceneDesc()
+    pose = T.look_at([0, 0, 0.3], [1, 0, 0.3], [0, 0, 1])
+    a_tx = sd.phased_array(4, [0.02, 0.05, 1], [0.025, 0, 0], [1, 0, 0], steering_vector=[0.2, 0, 0], array_loc=pose)
+    a_rx = sd.phased_array(3, [0.02, 0.05, 1], [0.03, 0, 0], [1, 0, 0], array_loc=pose)
+    ref_tx = np.ctypeslib.as_array(a_tx.velems, shape=(16, capi.BF_VELEM_FLOATS))
+    ref_rx = np.ctypeslib.as_array(a_rx.velems, shape=(9, capi.BF_VELEM_FLOATS))
+    # the steering phasor's argument is K * (r' . sin(steer)) with K ~ 9e2: float32 in one, float64 in the other
+    assert np.allclose(tab_tx[:, :28], ref_tx[:, :28], rtol=1e-5, atol=1e-6)
+    assert np.allclose(tab_tx[:, 28:30], ref_tx[:, 28:30], atol=2e-4)
+    assert np.allclose(tab_rx, ref_rx, rtol=1e-5, atol=1e-6)
+    assert np.allclose(tab_rx[:, 28], 1.0) and np.allclose(tab_rx[:, 29], 0.0)          # no steering: psi' = 1
+    assert list(d.emitters[0].array.elem_dims) == [np.float32(0.02), np.float32(0.05), 1.0]
+    lp, h, rec = _oracle_on_host_scene(scene, rx)
+    h = h.reshape(64, 3)
+    assert h[:, 2].sum() == 4000 and np.all(np.isfinite(h)) and np.count_nonzero(h[:, 0]) > 3
 
 
 def test_exr_writer_round_trip(mitsuba, tmp_path):
