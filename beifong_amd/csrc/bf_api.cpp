@@ -709,7 +709,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     }();
     static const int trace_waves = [] {
         const char *e = getenv("BF_TRACE_WAVES");
-        int w = e ? atoi(e) : 6;
+        int w = e ? atoi(e) : 5;
         return w < 4 ? 4 : (w > 8 ? 8 : (w == 7 ? 6 : w));
     }();
     // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
