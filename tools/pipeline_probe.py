@@ -10,6 +10,8 @@ K = int(os.environ.get("K", 8))
 sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=n_paths)
 flags = capi.BF_FLAG_MEGAKERNEL if os.environ.get("MODE", "megakernel") == "megakernel" else 0
 lp.flags = flags
+if os.environ.get('MAXDEPTH'):
+    lp.max_depth = int(os.environ['MAXDEPTH'])
 lib = capi.load_library()
 nch = lib.bf_launch_channels(lp)
 for n_streams in [int(x) for x in os.environ.get("STREAMS", "1,2,3").split(",")]:
