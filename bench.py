@@ -253,6 +253,12 @@ def cpu_baseline(sd, lp, args):
     _, _, st = o.render(l, rng_mode=0, threads=cores)
     dt = time.perf_counter() - t0
     rays = st.n_rays_closest + st.n_rays_shadow
+    # single core (BASELINE.md §3 asks for both): 1/16 of the sample, the reference's own 1x1-film renders are one thread
+    n1 = max(1 << 16, args.cpu_paths // 16)
+    l1 = capi.make_launch(lp.mode, n1, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
+    t1 = time.perf_counter()
+    _, _, st1 = o.render(l1, rng_mode=0, threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": round(rays / dt / 1e6, 3),
         "unit": "Mrays/s",
@@ -260,6 +266,8 @@ def cpu_baseline(sd, lp, args):
         "kind": "port",
         "sample": "%d paths of the same C2 scene (same seed, per-path PCG32 streams), oracle/bf_oracle.cpp with its "
                   "own median-split BVH, %d std::threads, %.1f s wall" % (args.cpu_paths, cores, dt),
+        "value_1core": round((st1.n_rays_closest + st1.n_rays_shadow) / dt1 / 1e6, 3),
+        "sample_1core": "%d paths, 1 thread, %.1f s wall" % (n1, dt1),
     }
 
 
