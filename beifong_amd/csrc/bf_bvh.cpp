@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <future>
 #include <limits>
 
@@ -43,11 +44,31 @@ struct Builder {
     std::vector<Box> tb;          // per-triangle bounds
     std::vector<float> cent;      // per-triangle centroid [3n]
     std::vector<uint32_t> &order;
-    std::vector<Node> &nodes;
-    uint32_t max_depth = 0;
+    std::atomic<uint32_t> max_depth{0};
     float abs_pad = 0.f;          // origin-rounding allowance (see bf_bvh.h)
 
-    Builder(const std::vector<BuildTri> &t, BVH &out) : tris(t), order(out.order), nodes(out.nodes) {}
+    Builder(const std::vector<BuildTri> &t, BVH &out) : tris(t), order(out.order) {}
+
+    // Subtrees of at least kParallelMin triangles are built by their own
+    // task into their own node vector and spliced in afterwards (child indices shifted), so the node order —
+    // hence the device layout — is the same depth-first order whatever the thread schedule.
+    static constexpr uint32_t kParallelMin = 8192;
+    std::atomic<int> task_budget{48};       // concurrent subtree tasks (SAH trees can be lopsided: no depth limit)
+    static int32_t splice(std::vector<Node> &out, std::vector<Node> &sub, int32_t ref) {
+        if (ref < 0) return ref;
+        const int32_t off = (int32_t) out.size();
+        for (Node &n : sub) {
+            if (n.child[0] >= 0) n.child[0] += off;
+            if (n.child[1] >= 0) n.child[1] += off;
+        }
+        out.insert(out.end(), sub.begin(), sub.end());
+        return ref + off;
+    }
+    void note_depth(uint32_t d) {
+        uint32_t cur = max_depth.load(std::memory_order_relaxed);
+        while (d > cur && !max_depth.compare_exchange_weak(cur, d, std::memory_order_relaxed)) {
+        }
+    }
 
     void pad(Box &b) const {
         // fp32 hit distances can land a hair outside the exact box: widen by a
@@ -69,8 +90,8 @@ struct Builder {
     }
 
     // returns the child reference for [first, first+count)
-    int32_t build(uint32_t first, uint32_t count, const Box &bounds, uint32_t depth) {
-        max_depth = std::max(max_depth, depth);
+    int32_t build(std::vector<Node> &nodes, uint32_t first, uint32_t count, const Box &bounds, uint32_t depth) {
+        note_depth(depth);
         if (count <= (uint32_t) kMaxLeaf) return ~(int32_t) ((first << 3) | (count - 1));
 
         Box cb;
@@ -153,8 +174,24 @@ struct Builder {
         Box lb = range_bounds(first, mid), rb = range_bounds(first + mid, count - mid);
         int32_t me = (int32_t) nodes.size();
         nodes.push_back(Node());
-        int32_t l = build(first, mid, lb, depth + 1);
-        int32_t r = build(first + mid, count - mid, rb, depth + 1);
+        int32_t l, r;
+        bool parallel = std::min(mid, count - mid) >= kParallelMin;
+        if (parallel && task_budget.fetch_sub(1, std::memory_order_relaxed) <= 0) {
+            task_budget.fetch_add(1, std::memory_order_relaxed);
+            parallel = false;
+        }
+        if (parallel) {
+            std::vector<Node> ln, rn;
+            auto fut = std::async(std::launch::async, [&]() { return build(ln, first, mid, lb, depth + 1); });
+            const int32_t rr = build(rn, first + mid, count - mid, rb, depth + 1);
+            const int32_t ll = fut.get();
+            l = splice(nodes, ln, ll);
+            r = splice(nodes, rn, rr);
+            task_budget.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            l = build(nodes, first, mid, lb, depth + 1);
+            r = build(nodes, first + mid, count - mid, rb, depth + 1);
+        }
         pad(lb);
         pad(rb);
         Node &n = nodes[me];
@@ -204,13 +241,13 @@ void build_bvh(const std::vector<BuildTri> &tris, BVH &out, float origin_scale) 
     float scale = origin_scale;
     for (int k = 0; k < 3; ++k) scale = std::max({scale, std::fabs(all.lo[k]), std::fabs(all.hi[k])});
     b.abs_pad = 2e-7f * scale;
-    out.root_child = b.build(0, (uint32_t) n, all, 0);
+    out.root_child = b.build(out.nodes, 0, (uint32_t) n, all, 0);
     b.pad(all);
     for (int i = 0; i < 3; ++i) {
         out.lo[i] = all.lo[i];
         out.hi[i] = all.hi[i];
     }
-    out.max_depth = b.max_depth;
+    out.max_depth = b.max_depth.load();
 }
 
 namespace {

@@ -26,8 +26,11 @@ namespace bfd {
 // slot of the wavefront queue (state + the closest hit already traced for it)
 // and runs that path to completion here, instead of paying two launches per
 // bounce for a nearly empty chip.
+#ifndef BF_TAIL_WAVES
+#define BF_TAIL_WAVES 2
+#endif
 template <bool STATS, bool RESUME, bool SPILL>
-__global__ __launch_bounds__(kBlock, RESUME ? 2 : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
+__global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -317,6 +320,13 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     // launch within the scene's traversal-spill columns)
     unsigned grid = (std::min(n_slots, wf->n_slots) + bfd::kBlock - 1) / bfd::kBlock;
     grid = std::min(grid, sc->spill_stride / bfd::kBlock);
+    {
+        static const unsigned cap = [] {
+            const char *e = getenv("BF_TAIL_BLOCKS");
+            return e ? (unsigned) atoi(e) : 0u;
+        }();
+        if (cap) grid = std::min(grid, cap);
+    }
     if (grid == 0) return hipSuccess;
     const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
     unsigned long long *counters = wf->counters;

@@ -1,6 +1,9 @@
 // Test harness (tests/ only): builds the product's host-side BVH (beifong_amd/csrc/bf_bvh.cpp) for a triangle soup
 // and checks its structural invariants on the CPU.  Compiled by tests/test_bvh_host.py with g++.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -79,9 +82,15 @@ extern "C" int bvh_check(uint32_t n, const float *verts /* n*9 */, uint32_t out[
         std::memcpy(tris[i].p2, verts + 9 * i + 6, 12);
     }
     bf::BVH bvh2;
+    auto t0 = std::chrono::steady_clock::now();
     bf::build_bvh(tris, bvh2, 0.f);
+    auto t1 = std::chrono::steady_clock::now();
     bf::BVH4 bvh4;
     bf::collapse_bvh4(bvh2, bvh4);
+    auto t2 = std::chrono::steady_clock::now();
+    if (getenv("BVH_CHECK_TIMING"))
+        fprintf(stderr, "build %.1f ms, collapse %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
     Ctx c;
     c.tris = &tris;
     c.bvh2 = &bvh2;
