@@ -27,7 +27,7 @@ namespace bfd {
 // and runs that path to completion here, instead of paying two launches per
 // bounce for a nearly empty chip.
 #ifndef BF_TAIL_WAVES
-#define BF_TAIL_WAVES 2
+#define BF_TAIL_WAVES 3
 #endif
 template <bool STATS, bool RESUME, bool SPILL>
 __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
