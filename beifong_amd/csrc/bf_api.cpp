@@ -645,7 +645,6 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.ray1, n * 16));
     HIP_TRY(alloc((void **) &wf.sa, n * 16));
     HIP_TRY(alloc((void **) &wf.sb, n * 16));
-    HIP_TRY(alloc((void **) &wf.sc, n * 16));
     HIP_TRY(alloc((void **) &wf.sd, n * 16));
     HIP_TRY(alloc((void **) &wf.se, n * 16));
     HIP_TRY(alloc((void **) &wf.hit, n * 16));

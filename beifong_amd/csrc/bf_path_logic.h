@@ -43,7 +43,7 @@ struct PathState {
 
 BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     float4 r0 = wf.ray0[i], r1 = wf.ray1[i], a = wf.sa[i], bb = wf.sb[i];
-    uint4 c = wf.sc[i], d = wf.sd[i];
+    uint4 d = wf.sd[i];
     s.ro = mk(r0.x, r0.y, r0.z);
     s.rmint = r0.w;
     s.rd = mk(r1.x, r1.y, r1.z);
@@ -54,9 +54,9 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     s.result = a.w;
     s.aux = bb.x;
     s.bs_pdf = bb.y;
-    s.prev_p = mk(bb.z, bb.w, __uint_as_float(c.x));
-    s.flags = c.y;
-    s.n_rays = c.z;
+    s.prev_p = s.ro;             // the previous vertex IS the origin of the ray in flight (spawn_ray, interaction.h:61-64)
+    s.flags = __float_as_uint(bb.z);
+    s.n_rays = __float_as_uint(bb.w);
     s.rng.state = ((uint64_t) d.y << 32) | d.x;
     s.path_i = ((uint64_t) d.w << 32) | d.z;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
@@ -72,8 +72,7 @@ BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState 
     wf.ray0[j] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
     wf.ray1[j] = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
     wf.sa[j] = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
-    wf.sb[j] = make_float4(s.aux, s.bs_pdf, s.prev_p.x, s.prev_p.y);
-    wf.sc[j] = make_uint4(__float_as_uint(s.prev_p.z), s.flags, s.n_rays, 0u);
+    wf.sb[j] = make_float4(s.aux, s.bs_pdf, __uint_as_float(s.flags), __uint_as_float(s.n_rays));
     wf.sd[j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
                           (uint32_t) (s.path_i >> 32));
     if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, s.phase);

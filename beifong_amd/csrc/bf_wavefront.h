@@ -31,8 +31,7 @@ struct WF {
     float4 *ray0;       // o.xyz, mint
     float4 *ray1;       // d.xyz, maxt
     float4 *sa;         // throughput, eta, emission_weight, result
-    float4 *sb;         // aux, bs_pdf, prev_p.x, prev_p.y
-    uint4 *sc;          // prev_p.z, depth|flags, n_rays, -
+    float4 *sb;         // aux, bs_pdf, depth|flags (bits), n_rays (bits)
     uint4 *sd;          // rng state lo/hi, path index lo/hi
     float4 *se;         // receive mode only: ray.time, t_rx, lambda0, -
     float4 *hit;        // t, u, v, triangle slot
