@@ -226,6 +226,129 @@ BF_DEV bool traverse_dyn(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     }
     return best.t != BF_INF;
 }
+// ---------------------------------------------------------------------------
+// Quad-cooperative traversal for sparse waves (the latency-bound tail): FOUR lanes per ray.  Lane q of an aligned
+// quad tests child q of a node / triangle q of a leaf / rectangle q, q + 4, ...; keys, children and candidate hits
+// are exchanged inside the quad, so every lane of it follows the same walk.  A lone wave issues one instruction
+// per ~5-10 cycles however few lanes are live, so dividing the instructions per node step by ~3 is what shortens
+// the serial depth of the longest paths.  Results are those of traverse_dyn bit for bit (same tests, same tie rule).
+// All four lanes pass the same ray; `active` = the quad has a ray at all.  The stack lives in the LEADER's LDS column
+// (and spill column): only q == 0 writes, all four read.
+// ---------------------------------------------------------------------------
+// lane exchanges inside an aligned quad: DPP quad_perm (a register move, no LDS round trip)
+template <int CTRL> BF_DEV int quad_perm(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int I> BF_DEV int quad_bcast(int v) { return quad_perm<I | (I << 2) | (I << 4) | (I << 6)>(v); }
+template <int I> BF_DEV uint32_t quad_bcast(uint32_t v) { return (uint32_t) quad_bcast<I>((int) v); }
+template <int CTRL> BF_DEV float quad_perm(float v) { return __int_as_float(quad_perm<CTRL>(__float_as_int(v))); }
+
+BF_DEV void quad_merge_hit(Hit &best) {
+    {   // partner lane ^ 1: quad_perm [1,0,3,2]
+        const float t = quad_perm<0xB1>(best.t), u = quad_perm<0xB1>(best.u), v = quad_perm<0xB1>(best.v);
+        const uint32_t prim = (uint32_t) quad_perm<0xB1>((int) best.prim);
+        const int32_t slot = quad_perm<0xB1>(best.slot);
+        if (t != BF_INF) consider(best, t, u, v, prim, slot);
+    }
+    {   // partner lane ^ 2: quad_perm [2,3,0,1]
+        const float t = quad_perm<0x4E>(best.t), u = quad_perm<0x4E>(best.u), v = quad_perm<0x4E>(best.v);
+        const uint32_t prim = (uint32_t) quad_perm<0x4E>((int) best.prim);
+        const int32_t slot = quad_perm<0x4E>(best.slot);
+        if (t != BF_INF) consider(best, t, u, v, prim, slot);
+    }
+}
+
+template <bool STATS, bool SPILL>
+BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, float mint, float maxt, int *lds_leader_column,
+                          Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris) {
+    const int lane = threadIdx.x & 63, q = lane & 3, base = lane & ~3;
+    best.t = BF_INF;
+    best.u = best.v = 0.f;
+    best.prim = 0;
+    best.slot = 0;
+    found = false;
+    // rectangles: one per lane of the quad
+    bool rect_hit = false;
+    if (active) {
+        for (uint32_t i = (uint32_t) q; i < sc.n_rects; i += 4u) {
+            const DRect &rc = sc.rects[i];
+            float t, lx, ly;
+            if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
+                rect_hit = true;
+                consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
+            }
+        }
+    }
+    {
+        const unsigned long long m = __ballot(rect_hit);
+        const bool quad_any = ((m >> base) & 0xFull) != 0ull;
+        if (any && quad_any) found = true;
+        quad_merge_hit(best);
+    }
+    int node = (active && !found && sc.n_tris != 0) ? sc.root : kNoNode;
+    V3 id, oid;
+    ray_inverse(o, d, id, oid);
+    LaneStack<kStackDepth, SPILL> st;
+    st.lds = lds_leader_column;
+    st.spill = sc.spill + ((size_t) blockIdx.x * kBlock + (threadIdx.x & ~3u));
+    st.spill_stride = sc.spill_stride;
+    st.sp = 0;
+    while (__ballot(node != kNoNode)) {
+        if (node >= 0) {
+            if (STATS && q == 0) ++n_nodes;
+            const float *nf = reinterpret_cast<const float *>(sc.nodes + 8u * (uint32_t) node);
+            const float lox = nf[q], loy = nf[4 + q], loz = nf[8 + q], hix = nf[12 + q], hiy = nf[16 + q], hiz = nf[20 + q];
+            const int child = __float_as_int(nf[24 + q]);
+            float tn;
+            const float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
+            const bool h = slab_fma(lox, loy, loz, hix, hiy, hiz, id, oid, mint, tmax, tn) && child != kNoNode;
+            const uint32_t key = child_key(h, tn, (uint32_t) q);
+            const uint32_t k0 = quad_bcast<0>(key), k1 = quad_bcast<1>(key), k2 = quad_bcast<2>(key), k3 = quad_bcast<3>(key);
+            const int c0 = quad_bcast<0>(child), c1 = quad_bcast<1>(child), c2 = quad_bcast<2>(child), c3 = quad_bcast<3>(child);
+            const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), dd = max(k2, k3);
+            const uint32_t lo = min(a, c), x = max(a, c), y = min(b, dd), hi = max(b, dd);
+            const uint32_t m1 = min(x, y), m2 = max(x, y);
+            auto pick = [&](uint32_t k) -> int {
+                const uint32_t i = k & 3u;
+                return i == 0u ? c0 : (i == 1u ? c1 : (i == 2u ? c2 : c3));
+            };
+            // all four lanes keep sp in step; only the leader touches the memory
+            auto push = [&](int v) {
+                if (q == 0) {
+                    st.push(v);
+                } else {
+                    ++st.sp;
+                }
+            };
+            if (hi < kMissKey) push(pick(hi));
+            if (m2 < kMissKey) push(pick(m2));
+            if (m1 < kMissKey) push(pick(m1));
+            node = (lo < kMissKey) ? pick(lo) : st.pop_or_none();
+        } else if (node != kNoNode) {
+            const uint32_t enc = ~(uint32_t) node;
+            const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+            bool tri_hit = false;
+            for (uint32_t i = (uint32_t) q; i < cnt; i += 4u) {
+                const float4 *tp = sc.tris + 3u * (first + i);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) ++n_tris;
+                float t, u, v;
+                if (tri_intersect(mk(ta.x, ta.y, ta.z), mk(tb.x, tb.y, tb.z), mk(tc.x, tc.y, tc.z), o, d, mint, maxt, t, u, v)) {
+                    tri_hit = true;
+                    consider(best, t, u, v, __float_as_uint(ta.w), (int32_t) (first + i));
+                }
+            }
+            const unsigned long long m = __ballot(tri_hit);
+            const bool quad_any = ((m >> base) & 0xFull) != 0ull;
+            quad_merge_hit(best);
+            if (any && quad_any) {
+                found = true;
+                node = kNoNode;
+            } else {
+                node = st.pop_or_none();
+            }
+        }
+    }
+}
+
 template <bool ANY, bool STATS, bool SPILL>
 BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
                      uint32_t &n_tris) {

@@ -147,7 +147,53 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
         const bool trace_closest = alive && need_closest && !term_pending;
         const unsigned long long want_mask = __ballot(sh.want);
         bool occluded = false;
-        if (want_mask) {
+        const unsigned long long closest_mask = __ballot(trace_closest);
+        const uint32_t n_cl = (uint32_t) __popcll(closest_mask), n_sh = (uint32_t) __popcll(want_mask);
+        if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= 16u) {
+            // ---- sparse wave (the deep tail): four lanes per ray (traverse_quad) -----------------------
+            // job k < n_cl: closest-hit ray of the k-th lane of closest_mask; job n_cl + k: shadow ray of the k-th
+            // lane of want_mask; quad k = lanes 4k .. 4k + 3 serves job k
+            const uint32_t job = (uint32_t) lane >> 2;
+            const bool job_active = job < n_cl + n_sh;
+            const bool job_any = job >= n_cl;
+            int src = lane;
+            if (job_active) src = (int) (job_any ? nth_set_bit(want_mask, job - n_cl) : nth_set_bit(closest_mask, job));
+            const V3 co = mk(__shfl(s.ro.x, src), __shfl(s.ro.y, src), __shfl(s.ro.z, src));
+            const V3 cd = mk(__shfl(s.rd.x, src), __shfl(s.rd.y, src), __shfl(s.rd.z, src));
+            const float cmint = __shfl(s.rmint, src), cmaxt = __shfl(s.rmaxt, src);
+            const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
+            const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
+            const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
+            Hit qbest;
+            bool qfound;
+            traverse_quad<STATS, SPILL>(sc, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
+                                        job_any ? smaxt : cmaxt, s_stack + (tid & ~3), qbest, qfound, c_nodes, c_tris);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            // deliver: closest hits to their lanes, occlusion verdicts to the requesters
+            const int my_cl_quad = (int) __popcll(closest_mask & below) * 4;
+            const float ht = __shfl(qbest.t, my_cl_quad), hu = __shfl(qbest.u, my_cl_quad), hv = __shfl(qbest.v, my_cl_quad);
+            const int hs = __shfl(qbest.slot, my_cl_quad);
+            const uint32_t hp = (uint32_t) __shfl((int) qbest.prim, my_cl_quad);
+            if (trace_closest) {
+                hit.t = ht;
+                hit.u = hu;
+                hit.v = hv;
+                hit.slot = hs;
+                hit.prim = hp;
+                ++c_closest;
+            }
+            const unsigned long long occl_mask = __ballot(job_active && job_any && qfound);
+            if (sh.want) {
+                const uint32_t leader = (n_cl + (uint32_t) __popcll(want_mask & below)) * 4u;
+                occluded = (occl_mask >> leader) & 1ull;
+                ++c_shadow;
+                if (!occluded) {                                  // Scene::ray_test == false (scene.cpp:220-224)
+                    s.result += sh.c;
+                    if (lp.iq) s.phase += sh.c_im;
+                }
+                sh.want = false;
+            }
+        } else if (want_mask) {
             const unsigned long long free_mask = __ballot(!trace_closest && !sh.want);
             const uint32_t n_del = min((uint32_t) __popcll(want_mask), (uint32_t) __popcll(free_mask));
             const unsigned long long below = (1ull << lane) - 1ull;
