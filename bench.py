@@ -64,13 +64,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_SHARE_DEVICE=1 / BENCH_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a one-GPU box (all ranks on
+    # cuda:0, host-staged collectives); the driver's multi-GPU runs use neither
+    dev_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     lib = capi.load_library()
-    capi.check(lib, lib.bf_set_device(local_rank), "bf_set_device")
+    capi.check(lib, lib.bf_set_device(dev_index), "bf_set_device")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sd, lp = scenes.bus_radar(n_tris=args.tris, n_paths=args.paths, bins=256, dr=0.1, seed=1)
     n_streams = max(1, args.streams)
