@@ -108,6 +108,7 @@ struct bf_scene {
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     float4 *tris0 = nullptr, *nodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
+    std::vector<bfd::DShape> shapes_host;         // as created: mesh triangles carry their shape's material / emitter index
     std::vector<float *> array_dev;
     std::vector<uint32_t> array_n;
     float *sensor_array_dev = nullptr;
@@ -269,6 +270,8 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
             rc.area = area;
             rc.shape = i;
             rc.prim = prim;
+            rc.material = s.material;
+            rc.emitter = s.emitter;
             ds.rect = (int32_t) rects.size();
             rects.push_back(rc);
             prim += 1;
@@ -451,7 +454,13 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         uint32_t src = bvh.order[slot];
         const bf::BuildTri &t = btris[src];
         const TriMeta &m = meta[src];
-        uint32_t has_n = m.n0 ? 1u : 0u;
+        if (desc->n_materials > 0xfffu || desc->n_emitters > 0xffeu) {
+            bf_scene_destroy(sc);
+            return fail(BF_ERR_UNSUPPORTED, "more than 4095 materials or 4094 emitters");
+        }
+        // tag word: bit 0 = has vertex normals, bits 8..19 = material, bits 20..31 = emitter + 1 (bf_device_core.h)
+        const bf_shape &msh = desc->shapes[m.shape];
+        uint32_t has_n = (m.n0 ? 1u : 0u) | ((uint32_t) msh.material << 8) | ((uint32_t) (msh.emitter + 1) << 20);
         float w0, w1, w2;
         std::memcpy(&w0, &m.prim, 4);
         std::memcpy(&w1, &m.shape, 4);
@@ -512,6 +521,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(sensor_vec, sensor);
 #undef UP
     sc->n_materials = desc->n_materials;
+    sc->shapes_host = shapes;
     sc->d.n_tris = (uint32_t) btris.size();
     sc->d.n_rects = (uint32_t) rects.size();
     sc->d.n_emitters = (uint32_t) emitters.size();
@@ -558,6 +568,10 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
                                     "(shapes %zu/%u, rectangles %zu/%u, emitters %zu/%u, triangles %u/%u)",
                     f.shapes.size(), scene->info.n_shapes, f.rects.size(), scene->d.n_rects, f.emitters.size(),
                     scene->d.n_emitters, f.n_tris, scene->d.n_tris);
+    for (size_t i = 0; i < f.shapes.size(); ++i)
+        if (f.shapes[i].rect < 0 && (f.shapes[i].material != scene->shapes_host[i].material || f.shapes[i].emitter != scene->shapes_host[i].emitter))
+            return fail(BF_ERR_UNSUPPORTED, "bf_scene_update_endpoints: mesh shape %zu changed its material / emitter index (the "
+                                            "triangle records carry them); create a new scene", i);
     if (scene->d.n_tris && f.origin_scale > scene->origin_scale_built)
         return fail(BF_ERR_UNSUPPORTED, "bf_scene_update_endpoints: an endpoint moved to |coordinate| %g, outside the bound %g the "
                                         "BVH boxes were padded for; create a new scene", (double) f.origin_scale,

@@ -29,6 +29,8 @@ struct DRect {
     float area;           // Rectangle::surface_area()
     uint32_t shape;
     uint32_t prim;        // global primitive index
+    uint32_t material;    // of the carrying shape
+    int32_t emitter;      // of the carrying shape, or -1
 };
 
 struct DShape {

@@ -366,7 +366,12 @@ struct SI {
     V3 p, wi;
     Frame sh;
     uint32_t shape;
+    uint32_t material;      // index into DScene::materials (carried by the primitive record: no shapes[] hop)
+    int32_t emitter;        // index into DScene::emitters or -1
 };
+// third tag word of a triangle record: bit 0 = has vertex normals, bits 8..19 = material, bits 20..31 = emitter + 1
+BF_DEV uint32_t tri_tag_material(uint32_t tag) { return (tag >> 8) & 0xfffu; }
+BF_DEV int32_t tri_tag_emitter(uint32_t tag) { return (int32_t) (tag >> 20) - 1; }
 
 BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
     si.t = h.t;
@@ -374,23 +379,35 @@ BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
     if (h.slot < 0) {
         const DRect &rc = sc.rects[-h.slot - 1];
         si.shape = rc.shape;
+        si.material = rc.material;
+        si.emitter = rc.emitter;
         si.p = fmadd3(d, h.t, o);
         si.sh.n = mk(rc.n[0], rc.n[1], rc.n[2]);
         dp_du = mk(rc.s[0], rc.s[1], rc.s[2]);
     } else {
         const float4 *tp = sc.tris + 3 * (size_t) h.slot;
         float4 a = tp[0], b = tp[1], c = tp[2];
+        // the vertex normals are fetched together with the positions, not after the tag has arrived (one dependent
+        // memory round trip less per shaded vertex); scenes without any normals skip the load
+        float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
+        if (sc.normals) {
+            const float4 *nq = sc.normals + 3 * (size_t) h.slot;
+            na = nq[0];
+            nb = nq[1];
+            nc = nq[2];
+        }
         V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
         si.shape = __float_as_uint(b.w);
+        const uint32_t tag = __float_as_uint(c.w);
+        si.material = tri_tag_material(tag);
+        si.emitter = tri_tag_emitter(tag);
         float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
         V3 dp0 = p1 - p0, dp1 = p2 - p0;
         si.p = p0 * b0 + p1 * b1 + p2 * b2;
         V3 n = normalize(cross(dp0, dp1));
         V3 dp_dv;
         coordinate_system(n, dp_du, dp_dv);
-        if (__float_as_uint(c.w) != 0u) {
-            const float4 *nq = sc.normals + 3 * (size_t) h.slot;
-            float4 na = nq[0], nb = nq[1], nc = nq[2];
+        if (tag & 1u) {
             si.sh.n = normalize(mk(na.x, na.y, na.z) * b0 + mk(nb.x, nb.y, nb.z) * b1 + mk(nc.x, nc.y, nc.z) * b2);
         } else {
             si.sh.n = n;

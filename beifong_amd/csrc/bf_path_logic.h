@@ -452,7 +452,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     int emitter = -1;
     if (si_valid) {
         make_si(sc, s.ro, s.rd, hit, si);
-        emitter = sc.shapes[si.shape].emitter;
+        emitter = si.emitter;
     }
     uint32_t depth = s.flags & kDepthMask;
     if (depth == 0) {
@@ -512,7 +512,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     }
     if (depth >= (uint32_t) lp.max_depth || !active) return false;
 
-    const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+    const bf_material &mat = sc.materials[si.material];
     ++c_bounces;
     if (bsdf_smooth(mat)) {
         // Scene::sample_emitter_direction / sample_transmitter_direction — scene.cpp:180-230, 249-299
