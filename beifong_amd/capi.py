@@ -19,6 +19,7 @@ BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED = range(5)
 BF_VELEM_FLOATS = 32
+BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
 BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL = 1, 2, 4
@@ -37,7 +38,7 @@ class bf_shape(C.Structure):
     _fields_ = [("type", C.c_uint32), ("material", C.c_uint32), ("emitter", C.c_int32),
                 ("is_sensor", C.c_uint32), ("to_world", M16), ("to_object", M16),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
-                ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
+                ("texcoords", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
 
 
 class bf_phased_array(C.Structure):
@@ -111,7 +112,7 @@ class bf_scene_info(C.Structure):
 EXPORTED_SYMBOLS = [
     "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
     "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
-    "bf_trace_closest", "bf_trace_any", "bf_eval_elementary",
+    "bf_trace_closest", "bf_trace_any", "bf_ray_intersect", "bf_eval_elementary",
 ]
 
 _lib = None
@@ -148,6 +149,7 @@ def load_library(path=None):
     lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
     lib.bf_trace_any.argtypes = [vp, C.c_uint64, vp, vp]
+    lib.bf_ray_intersect.argtypes = [vp, C.c_uint64, vp, vp, vp, vp]
     lib.bf_eval_elementary.argtypes = [C.c_int, C.c_uint64, vp, vp]
     if path is None:
         _lib = lib
@@ -244,6 +246,19 @@ class Scene:
         check(self.lib, self.lib.bf_trace_closest(self.handle, n, _ptr(rays), _ptr(t), _ptr(prim), _ptr(shape), _ptr(uv)),
               "bf_trace_closest")
         return t, prim, shape, uv
+
+    def ray_intersect(self, rays):
+        """Scene::ray_intersect -> dict of SurfaceInteraction fields (arrays over rays), prim, shape."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        si = np.empty((n, BF_SI_FLOATS), np.float32)
+        prim = np.empty(n, np.uint32)
+        shape = np.empty(n, np.uint32)
+        check(self.lib, self.lib.bf_ray_intersect(self.handle, n, _ptr(rays), _ptr(si), _ptr(prim), _ptr(shape)),
+              "bf_ray_intersect")
+        return dict(t=si[:, 0], p=si[:, 1:4], n=si[:, 4:7], sh_n=si[:, 7:10], sh_s=si[:, 10:13], sh_t=si[:, 13:16],
+                    wi=si[:, 16:19], prim_uv=si[:, 19:21], dp_du=si[:, 21:24], dp_dv=si[:, 24:27], prim=prim, shape=shape,
+                    raw=si)
 
     def trace_any(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

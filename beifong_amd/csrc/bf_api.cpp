@@ -25,7 +25,7 @@ extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, ui
 extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y);
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
-                                       hipStream_t stream);
+                                       float *out_si, hipStream_t stream);
 
 extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
@@ -182,6 +182,7 @@ namespace {
 struct TriMeta {
     uint32_t prim, shape;
     const float *n0, *n1, *n2;
+    const float *uv0, *uv1, *uv2;
 };
 // Everything of a scene description except the BVH: shape / rectangle / emitter tables and the sensor record.
 struct Flat {
@@ -189,7 +190,7 @@ struct Flat {
     std::vector<bfd::DRect> rects;
     std::vector<bf::BuildTri> btris;      // filled only when with_meshes
     std::vector<TriMeta> meta;
-    bool any_normals = false;
+    bool any_normals = false, any_uvs = false;
     std::vector<bfd::DEmitter> emitters;
     bfd::DSensor sensor;
     uint32_t n_tris = 0;
@@ -240,7 +241,9 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
     std::vector<bf::BuildTri> &btris = f.btris;
     std::vector<TriMeta> &meta = f.meta;
     bool &any_normals = f.any_normals;
+    bool &f_any_uvs = f.any_uvs;
     any_normals = false;
+    f.any_uvs = false;
     uint32_t prim = 0;
     uint64_t n_tris_total = 0;
     for (uint32_t i = 0; i < desc->n_shapes; ++i) {
@@ -287,7 +290,13 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
                 std::memcpy(t.p1, s.positions + 3 * i1, 12);
                 std::memcpy(t.p2, s.positions + 3 * i2, 12);
                 btris.push_back(t);
-                TriMeta m{prim + f, i, nullptr, nullptr, nullptr};
+                TriMeta m{prim + f, i, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                if (s.texcoords) {
+                    m.uv0 = s.texcoords + 2 * i0;
+                    m.uv1 = s.texcoords + 2 * i1;
+                    m.uv2 = s.texcoords + 2 * i2;
+                    f_any_uvs = true;
+                }
                 if (s.normals) {
                     m.n0 = s.normals + 3 * i0;
                     m.n1 = s.normals + 3 * i1;
@@ -450,6 +459,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
     if (any_normals) nrm_data.resize(3 * btris.size());
+    std::vector<float4> uv_data;
+    if (flat.any_uvs) uv_data.assign(btris.size(), make_float4(0, 0, 0, 0));
     for (size_t slot = 0; slot < btris.size(); ++slot) {
         uint32_t src = bvh.order[slot];
         const bf::BuildTri &t = btris[src];
@@ -458,9 +469,12 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
             bf_scene_destroy(sc);
             return fail(BF_ERR_UNSUPPORTED, "more than 4095 materials or 4094 emitters");
         }
-        // tag word: bit 0 = has vertex normals, bits 8..19 = material, bits 20..31 = emitter + 1 (bf_device_core.h)
+        // tag word: bit 0 = has vertex normals, bit 1 = has texture coordinates, bits 8..19 = material,
+        // bits 20..31 = emitter + 1 (bf_device_core.h)
         const bf_shape &msh = desc->shapes[m.shape];
-        uint32_t has_n = (m.n0 ? 1u : 0u) | ((uint32_t) msh.material << 8) | ((uint32_t) (msh.emitter + 1) << 20);
+        uint32_t has_n = (m.n0 ? 1u : 0u) | (m.uv0 ? 2u : 0u) | ((uint32_t) msh.material << 8) | ((uint32_t) (msh.emitter + 1) << 20);
+        if (m.uv0)   // mesh.cpp:494-499: duv0 = uv1 - uv0, duv1 = uv2 - uv0
+            uv_data[slot] = make_float4(m.uv1[0] - m.uv0[0], m.uv1[1] - m.uv0[1], m.uv2[0] - m.uv0[0], m.uv2[1] - m.uv0[1]);
         float w0, w1, w2;
         std::memcpy(&w0, &m.prim, 4);
         std::memcpy(&w1, &m.shape, 4);
@@ -513,6 +527,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(node_data, nodes);
     UP(tri_data, tris);
     UP(nrm_data, normals);
+    UP(uv_data, uvs);
     UP(rects, rects);
     UP(shapes, shapes);
     UP(mats, materials);
@@ -988,10 +1003,11 @@ bf_status bf_render(const bf_scene *scene, const bf_launch *launch, float *hist_
 }
 
 static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *rays, int any_hit, float *out_t,
-                              uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit) {
+                              uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
+                              float *out_si = nullptr) {
     if (!scene || (n && !rays)) return fail(BF_ERR_INVALID, "null argument");
     if (n == 0) return BF_OK;
-    float *d_rays = nullptr, *d_t = nullptr, *d_uv = nullptr;
+    float *d_rays = nullptr, *d_t = nullptr, *d_uv = nullptr, *d_si = nullptr;
     uint32_t *d_prim = nullptr, *d_shape = nullptr;
     uint8_t *d_hit = nullptr;
     std::vector<void *> tmp;
@@ -1011,8 +1027,9 @@ static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *ra
         if (e == hipSuccess) e = alloc((void **) &d_prim, n * 4);
         if (e == hipSuccess) e = alloc((void **) &d_shape, n * 4);
         if (e == hipSuccess) e = alloc((void **) &d_uv, n * 8);
+        if (e == hipSuccess && out_si) e = alloc((void **) &d_si, n * BF_SI_FLOATS * sizeof(float));
     }
-    if (e == hipSuccess) e = bfk_launch_trace(&scene->d, n, d_rays, any_hit, d_t, d_prim, d_shape, d_uv, d_hit, nullptr);
+    if (e == hipSuccess) e = bfk_launch_trace(&scene->d, n, d_rays, any_hit, d_t, d_prim, d_shape, d_uv, d_hit, d_si, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && any_hit && out_hit) e = hipMemcpy(out_hit, d_hit, n, hipMemcpyDeviceToHost);
     if (e == hipSuccess && !any_hit) {
@@ -1020,6 +1037,7 @@ static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *ra
         if (e == hipSuccess && out_prim) e = hipMemcpy(out_prim, d_prim, n * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_shape) e = hipMemcpy(out_shape, d_shape, n * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_uv) e = hipMemcpy(out_uv, d_uv, n * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_si) e = hipMemcpy(out_si, d_si, n * BF_SI_FLOATS * sizeof(float), hipMemcpyDeviceToHost);
     }
     cleanup();
     if (e != hipSuccess) return fail(BF_ERR_DEVICE, "bf_trace: %s", hipGetErrorString(e));
@@ -1029,6 +1047,12 @@ static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *ra
 bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays, float *out_t, uint32_t *out_prim,
                            uint32_t *out_shape, float *out_uv) {
     return trace_common(scene, n, rays, 0, out_t, out_prim, out_shape, out_uv, nullptr);
+}
+
+bf_status bf_ray_intersect(const bf_scene *scene, uint64_t n, const float *rays, float *out_si, uint32_t *out_prim,
+                           uint32_t *out_shape) {
+    if (n && !out_si) return fail(BF_ERR_INVALID, "bf_ray_intersect: null output");
+    return trace_common(scene, n, rays, 0, nullptr, out_prim, out_shape, nullptr, nullptr, out_si);
 }
 
 bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays, uint8_t *out_hit) {

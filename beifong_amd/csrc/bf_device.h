@@ -6,8 +6,9 @@
 //   tris    : float4[3 * n_tris]     48 B per triangle, BVH leaf order:
 //               q0 = (p0.xyz, bits(global prim index))
 //               q1 = (p1.xyz, bits(shape index))
-//               q2 = (p2.xyz, bits(has_normals))
+//               q2 = (p2.xyz, tag: normals / texcoords bits, material, emitter)
 //   normals : float4[3 * n_tris]     only if some mesh carries vertex normals
+//   uvs     : float4[n_tris]         (uv1 - uv0, uv2 - uv0), only if some mesh carries texture coordinates
 //   rects, shapes, materials, emitters : small tables (scenes hold a handful)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -74,6 +75,7 @@ struct DScene {
     const float4 *nodes;      // 4 float4 per node
     const float4 *tris;       // 3 float4 per triangle
     const float4 *normals;    // 3 float4 per triangle or nullptr
+    const float4 *uvs;        // 1 float4 per triangle or nullptr
     const DRect *rects;
     const DShape *shapes;
     const bf_material *materials;

@@ -369,11 +369,17 @@ struct SI {
     uint32_t material;      // index into DScene::materials (carried by the primitive record: no shapes[] hop)
     int32_t emitter;        // index into DScene::emitters or -1
 };
-// third tag word of a triangle record: bit 0 = has vertex normals, bits 8..19 = material, bits 20..31 = emitter + 1
+// third tag word of a triangle record: bit 0 = has vertex normals, bit 1 = has texture coordinates,
+// bits 8..19 = material, bits 20..31 = emitter + 1
 BF_DEV uint32_t tri_tag_material(uint32_t tag) { return (tag >> 8) & 0xfffu; }
 BF_DEV int32_t tri_tag_emitter(uint32_t tag) { return (int32_t) (tag >> 20) - 1; }
 
-BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
+// the parts of a SurfaceInteraction the estimator never reads (bf_ray_intersect reports them)
+struct SIGeom {
+    V3 n, dp_du, dp_dv;
+};
+
+template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si, SIGeom *geom = nullptr) {
     si.t = h.t;
     V3 dp_du;
     if (h.slot < 0) {
@@ -384,6 +390,11 @@ BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
         si.p = fmadd3(d, h.t, o);
         si.sh.n = mk(rc.n[0], rc.n[1], rc.n[2]);
         dp_du = mk(rc.s[0], rc.s[1], rc.s[2]);
+        if (FULL) {
+            geom->n = si.sh.n;
+            geom->dp_du = dp_du;
+            geom->dp_dv = mk(rc.t[0], rc.t[1], rc.t[2]);
+        }
     } else {
         const float4 *tp = sc.tris + 3 * (size_t) h.slot;
         float4 a = tp[0], b = tp[1], c = tp[2];
@@ -396,6 +407,8 @@ BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
             nb = nq[1];
             nc = nq[2];
         }
+        float4 duv = make_float4(0, 0, 0, 0);   // (uv1 - uv0, uv2 - uv0), same speculation
+        if (sc.uvs) duv = sc.uvs[h.slot];
         V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
         si.shape = __float_as_uint(b.w);
         const uint32_t tag = __float_as_uint(c.w);
@@ -407,6 +420,20 @@ BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si) {
         V3 n = normalize(cross(dp0, dp1));
         V3 dp_dv;
         coordinate_system(n, dp_du, dp_dv);
+        if (tag & 2u) {
+            // mesh.cpp:493-512: tangents of the UV parameterisation; a degenerate one keeps coordinate_system(n)
+            float det = fmsub(duv.x, duv.w, duv.y * duv.z), inv_det = rcp(det);
+            if (det != 0.f) {
+                dp_du = mk(fmsub(duv.w, dp0.x, duv.y * dp1.x), fmsub(duv.w, dp0.y, duv.y * dp1.y), fmsub(duv.w, dp0.z, duv.y * dp1.z)) * inv_det;
+                if (FULL)
+                    dp_dv = mk(fnmadd(duv.z, dp0.x, duv.x * dp1.x), fnmadd(duv.z, dp0.y, duv.x * dp1.y), fnmadd(duv.z, dp0.z, duv.x * dp1.z)) * inv_det;
+            }
+        }
+        if (FULL) {
+            geom->n = n;
+            geom->dp_du = dp_du;
+            geom->dp_dv = dp_dv;
+        }
         if (tag & 1u) {
             si.sh.n = normalize(mk(na.x, na.y, na.z) * b0 + mk(nb.x, nb.y, nb.z) * b1 + mk(nc.x, nc.y, nc.z) * b2);
         } else {

@@ -307,7 +307,8 @@ template <bool SPILL>
 __global__ __launch_bounds__(kBlock) void bf_trace_kernel(DScene sc, uint64_t n, const float *__restrict__ rays,
                                                           int any_hit, float *__restrict__ out_t,
                                                           uint32_t *__restrict__ out_prim, uint32_t *__restrict__ out_shape,
-                                                          float *__restrict__ out_uv, uint8_t *__restrict__ out_hit) {
+                                                          float *__restrict__ out_uv, uint8_t *__restrict__ out_hit,
+                                                          float *__restrict__ out_si) {
     __shared__ int s_stack[kStackDepth * kBlock];
     int *stack = s_stack + threadIdx.x;
     for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t) gridDim.x * kBlock) {
@@ -330,6 +331,30 @@ __global__ __launch_bounds__(kBlock) void bf_trace_kernel(DScene sc, uint64_t n,
         if (out_uv) {
             out_uv[2 * i] = h.u;
             out_uv[2 * i + 1] = h.v;
+        }
+        if (out_si) {
+            // SurfaceInteraction record of bf_ray_intersect (BF_SI_FLOATS); misses report t = +inf and zeros
+            float *q = out_si + (size_t) BF_SI_FLOATS * i;
+            for (int k = 0; k < BF_SI_FLOATS; ++k) q[k] = 0.f;
+            q[0] = h.t;
+            if (valid) {
+                SI si;
+                SIGeom g;
+                make_si<true>(sc, o, d, h, si, &g);
+                const V3 v[8] = {si.p, g.n, si.sh.n, si.sh.s, si.sh.t, si.wi, g.dp_du, g.dp_dv};
+                for (int k = 0; k < 6; ++k) {
+                    q[1 + 3 * k] = v[k].x;
+                    q[2 + 3 * k] = v[k].y;
+                    q[3 + 3 * k] = v[k].z;
+                }
+                q[19] = h.u;
+                q[20] = h.v;
+                for (int k = 6; k < 8; ++k) {
+                    q[3 + 3 * k] = v[k].x;
+                    q[4 + 3 * k] = v[k].y;
+                    q[5 + 3 * k] = v[k].z;
+                }
+            }
         }
     }
     }
@@ -459,14 +484,14 @@ extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, 
 
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
-                                       hipStream_t stream) {
+                                       float *out_si, hipStream_t stream) {
     unsigned grid = (unsigned) std::min<uint64_t>((n + bfd::kBlock - 1) / bfd::kBlock, sc->spill_stride / bfd::kBlock);
     if (grid == 0) return hipSuccess;
     if (sc->stack_need > (uint32_t) bfd::kStackDepth)
         hipLaunchKernelGGL(bfd::bf_trace_kernel<true>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, n, rays, any_hit, out_t,
-                           out_prim, out_shape, out_uv, out_hit);
+                           out_prim, out_shape, out_uv, out_hit, out_si);
     else
         hipLaunchKernelGGL(bfd::bf_trace_kernel<false>, dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, n, rays, any_hit, out_t,
-                       out_prim, out_shape, out_uv, out_hit);
+                           out_prim, out_shape, out_uv, out_hit, out_si);
     return hipGetLastError();
 }

@@ -417,6 +417,7 @@ void Scene::flatten(const Endpoint *endpoint) {
             copy16(bs.to_object, Matrix4f::identity());
             bs.positions = s->positions()->data();
             bs.normals = s->normals() ? s->normals()->data() : nullptr;
+            bs.texcoords = s->texcoords() ? s->texcoords()->data() : nullptr;
             bs.indices = s->faces()->data();
             bs.n_vertices = (uint32_t) (s->positions()->size() / 3);
             bs.n_faces = (uint32_t) (s->faces()->size() / 3);

@@ -187,6 +187,7 @@ public:
     /// mesh arrays (world space) or nullptr for analytic shapes
     virtual const std::vector<float> *positions() const { return nullptr; }
     virtual const std::vector<float> *normals() const { return nullptr; }
+    virtual const std::vector<float> *texcoords() const { return nullptr; }
     virtual const std::vector<uint32_t> *faces() const { return nullptr; }
     const Class *class_() const override;
 
@@ -208,6 +209,7 @@ public:
     float surface_area() const override;
     const std::vector<float> *positions() const override { return &m_positions; }
     const std::vector<float> *normals() const override { return m_normals.empty() ? nullptr : &m_normals; }
+    const std::vector<float> *texcoords() const override { return m_texcoords.empty() ? nullptr : &m_texcoords; }
     const std::vector<uint32_t> *faces() const override { return &m_faces; }
     bool has_vertex_normals() const { return !m_normals.empty(); }
     bool has_vertex_texcoords() const { return !m_texcoords.empty(); }

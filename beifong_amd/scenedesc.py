@@ -174,16 +174,18 @@ class SceneDesc:
         self.shapes.append(s)
         return len(self.shapes) - 1
 
-    def add_mesh(self, positions, indices, material, normals=None, emitter=-1):
+    def add_mesh(self, positions, indices, material, normals=None, emitter=-1, texcoords=None):
         pos = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nrm = None if normals is None else np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
-        self._keep += [pos, idx, nrm]
+        tex = None if texcoords is None else np.ascontiguousarray(texcoords, dtype=f32).reshape(-1, 2)
+        self._keep += [pos, idx, nrm, tex]
         s = capi.bf_shape()
         s.type, s.material, s.emitter, s.is_sensor = capi.BF_SHAPE_MESH, material, emitter, 0
         s.to_world, s.to_object = _m16(np.eye(4)), _m16(np.eye(4))
         s.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
         s.normals = nrm.ctypes.data_as(C.POINTER(C.c_float)) if nrm is not None else None
+        s.texcoords = tex.ctypes.data_as(C.POINTER(C.c_float)) if tex is not None else None
         s.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
         s.n_vertices, s.n_faces = pos.shape[0], idx.shape[0]
         self.shapes.append(s)

@@ -180,11 +180,11 @@ def plate_doppler(wavelength_m=0.1, n_paths=1 << 16, t_bins=1, plate_x=5.0, plat
     return sd, launch
 
 
-def single_mesh(v, f, normals=None):
+def single_mesh(v, f, normals=None, texcoords=None):
     """Bare mesh scene for Scene::ray_intersect tests (test_kdtrees.py style)."""
     sd = SceneDesc()
     m = sd.add_diffuse(0.5)
-    sd.add_mesh(v, f, m, normals=normals)
+    sd.add_mesh(v, f, m, normals=normals, texcoords=texcoords)
     sd.set_perspective(T.translate([0, 0, 0]), fov=45.0, near_clip=0.1, far_clip=100.0)
     sd.finalize()
     return sd

@@ -82,6 +82,9 @@ typedef struct bf_shape {
        (to_world already applied, as obj.cpp / ply.cpp do at load time)      */
     const float *positions;  /* [3 * n_vertices]                             */
     const float *normals;    /* [3 * n_vertices] or NULL                     */
+    const float *texcoords;  /* [2 * n_vertices] or NULL: with them dp_du follows the
+                                UV parameterisation (mesh.cpp:493-512) instead of
+                                coordinate_system(n), which turns the shading frame */
     const uint32_t *indices; /* [3 * n_faces]                                */
     uint32_t n_vertices;
     uint32_t n_faces;
@@ -304,6 +307,17 @@ bf_status bf_trace_closest(const bf_scene *scene, uint64_t n, const float *rays,
                            float *out_uv);
 bf_status bf_trace_any(const bf_scene *scene, uint64_t n, const float *rays,
                        uint8_t *out_hit);
+
+/* Scene::ray_intersect returning the whole SurfaceInteraction3f
+ * (scene.cpp:129-146 -> PreliminaryIntersection::compute_surface_interaction,
+ * interaction.h:613-644; Mesh::compute_surface_interaction mesh.cpp:452-548;
+ * Rectangle::compute_surface_interaction rectangle.cpp:265-298).
+ * out_si: [n][BF_SI_FLOATS] = t, p.xyz, n.xyz, sh_frame.n.xyz, sh_frame.s.xyz,
+ * sh_frame.t.xyz, wi.xyz (local), prim_uv.xy, dp_du.xyz, dp_dv.xyz.
+ * A miss has t = +inf and zeros elsewhere.  out_prim / out_shape may be NULL. */
+#define BF_SI_FLOATS 27
+bf_status bf_ray_intersect(const bf_scene *scene, uint64_t n, const float *rays,
+                           float *out_si, uint32_t *out_prim, uint32_t *out_shape);
 
 /* Evaluate the engine's fp32 elementary functions ON THE DEVICE over a HOST
  * array (conformance checks: the kernels use these in place of the libm calls

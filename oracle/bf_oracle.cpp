@@ -471,6 +471,8 @@ struct Tri {
     V3 p0, p1, p2;
     V3 n0, n1, n2;
     bool has_normals;
+    float uv[3][2];       // vertex texture coordinates (mesh.h:344-348), if the mesh carries them
+    bool has_uv;
 };
 struct Shape {
     uint32_t type, material;
@@ -504,6 +506,7 @@ struct Ray {
 struct SI {
     float t = kInf, time = 0;
     V3 p, n, wi;
+    V3 dp_du = {0, 0, 0}, dp_dv = {0, 0, 0};
     Frame sh;
     uint32_t shape = 0, prim = 0;
     bool valid() const { return t != kInf; }
@@ -738,6 +741,8 @@ static SI make_si(const OScene &sc, const Ray &ray, const Hit &h) {
         si.n = rc.frame.n;
         si.sh.n = rc.frame.n;
         dp_du = rc.frame.s;
+        si.dp_du = rc.frame.s;
+        si.dp_dv = rc.frame.t;
     } else {
         const Tri &tr = sc.tris[sh.tri_offset + (h.prim - sh.prim_offset)];
         float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
@@ -746,6 +751,18 @@ static SI make_si(const OScene &sc, const Ray &ray, const Hit &h) {
         si.n = normalize(cross(dp0, dp1));
         V3 dp_dv;
         coordinate_system(si.n, dp_du, dp_dv);
+        if (tr.has_uv) {
+            // mesh.cpp:493-512: dp_du, dp_dv from the UV parameterisation (kept when it is degenerate)
+            float duv0x = tr.uv[1][0] - tr.uv[0][0], duv0y = tr.uv[1][1] - tr.uv[0][1];
+            float duv1x = tr.uv[2][0] - tr.uv[0][0], duv1y = tr.uv[2][1] - tr.uv[0][1];
+            float det = fmsub(duv0x, duv1y, duv0y * duv1x), inv_det = rcp(det);
+            if (det != 0.f) {
+                dp_du = V3{fmsub(duv1y, dp0.x, duv0y * dp1.x), fmsub(duv1y, dp0.y, duv0y * dp1.y), fmsub(duv1y, dp0.z, duv0y * dp1.z)} * inv_det;
+                dp_dv = V3{fnmadd(duv1x, dp0.x, duv0x * dp1.x), fnmadd(duv1x, dp0.y, duv0x * dp1.y), fnmadd(duv1x, dp0.z, duv0x * dp1.z)} * inv_det;
+            }
+        }
+        si.dp_du = dp_du;
+        si.dp_dv = dp_dv;
         if (tr.has_normals)
             si.sh.n = normalize(tr.n0 * b0 + tr.n1 * b1 + tr.n2 * b2);
         else
@@ -1873,6 +1890,12 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
                 } else {
                     t.n0 = t.n1 = t.n2 = V3{0, 0, 0};
                 }
+                t.has_uv = s.texcoords != nullptr;
+                const uint32_t vi[3] = {i0, i1, i2};
+                for (int k = 0; k < 3; ++k) {
+                    t.uv[k][0] = t.has_uv ? s.texcoords[2 * vi[k]] : 0.f;
+                    t.uv[k][1] = t.has_uv ? s.texcoords[2 * vi[k] + 1] : 0.f;
+                }
                 sc.tris.push_back(t);
                 sc.tri_shape.push_back(i);
             }
@@ -2050,8 +2073,9 @@ bf_status bfo_ray_intersect_full(const bfo_scene *s, const float *r, float *out)
     Hit h;
     traverse<false>(s->sc, ray, h);
     SI si = make_si(s->sc, ray, h);
-    float o[21] = {si.t, si.p.x, si.p.y, si.p.z, si.n.x, si.n.y, si.n.z, si.sh.n.x, si.sh.n.y, si.sh.n.z,
-                   si.sh.s.x, si.sh.s.y, si.sh.s.z, si.sh.t.x, si.sh.t.y, si.sh.t.z, si.wi.x, si.wi.y, si.wi.z, h.u, h.v};
+    float o[27] = {si.t, si.p.x, si.p.y, si.p.z, si.n.x, si.n.y, si.n.z, si.sh.n.x, si.sh.n.y, si.sh.n.z,
+                   si.sh.s.x, si.sh.s.y, si.sh.s.z, si.sh.t.x, si.sh.t.y, si.sh.t.z, si.wi.x, si.wi.y, si.wi.z, h.u, h.v,
+                   si.dp_du.x, si.dp_du.y, si.dp_du.z, si.dp_dv.x, si.dp_dv.y, si.dp_dv.z};
     std::memcpy(out, o, sizeof(o));
     return BF_OK;
 }

@@ -110,7 +110,7 @@ class OracleScene:
 
     def intersect_full(self, ray):
         ray = np.ascontiguousarray(ray, np.float32).reshape(8)
-        out = np.zeros(21, np.float32)
+        out = np.zeros(27, np.float32)
         self.lib.bfo_ray_intersect_full(self.handle, _ptr(ray), _ptr(out))
         return dict(t=out[0], p=out[1:4], n=out[4:7], sh_n=out[7:10], sh_s=out[10:13], sh_t=out[13:16],
-                    wi=out[16:19], prim_uv=out[19:21])
+                    wi=out[16:19], prim_uv=out[19:21], dp_du=out[21:24], dp_dv=out[24:27])

@@ -493,7 +493,16 @@ def test_pulse_sweep_range_doppler_peak(hiplib):
     assert np.allclose(h_k.reshape(1, 3), cube[k], rtol=1e-4, atol=1e-6 * np.abs(cube[k]).max())
 
 
-def _zoo_scene(two_emitters=True, receive=False):
+def _planar_uv(v):
+    """Texture coordinates for the zoo meshes: an oblique planar projection, with a patch collapsed to one point so
+    that some triangles carry a degenerate parameterisation (mesh.cpp:500-502 keeps coordinate_system(n) there)."""
+    v = np.asarray(v, np.float32)
+    uv = np.stack([0.37 * v[:, 0] + 0.11 * v[:, 2], 0.29 * v[:, 1] - 0.2 * v[:, 2]], 1).astype(np.float32)
+    uv[v[:, 2] > np.quantile(v[:, 2], 0.9)] = [0.25, 0.75]
+    return uv
+
+
+def _zoo_scene(two_emitters=True, receive=False, uv=False):
     """Small scene exercising the branches the radar configs do not: several emitters (uniform emitter
     selection, scene.cpp:180-230 / 249-299), one-sided materials, a mesh with and a mesh without normals."""
     sd = SceneDesc()
@@ -526,10 +535,13 @@ def _zoo_scene(two_emitters=True, receive=False):
         lp = capi.make_launch(capi.BF_MODE_RANGE, 30000, seed=9, bins=128, bin_width=0.1, color_mode=capi.BF_COLOR_RGB)
     sd.add_rectangle(T.scale([20, 20, 1]), sd.add_diffuse(0.4, twosided=False))
     v, f, n = meshgen.car_body(6000, seed=3)
-    sd.add_mesh(meshgen.place(v, 25.0, (4.0, 0.5, 0.8)), f, sd.add_roughconductor(alpha=0.3, twosided=False, specular_reflectance=0.7),
-                normals=meshgen.vertex_normals(meshgen.place(v, 25.0, (4.0, 0.5, 0.8)), f))
+    vc = meshgen.place(v, 25.0, (4.0, 0.5, 0.8))
+    # uv=True: anisotropic roughness, so that the shading frame's s (from dp_du, interaction.h:159-162) shapes the lobe
+    sd.add_mesh(vc, f, sd.add_roughconductor(alpha=0.3, alpha_v=0.05 if uv else None, twosided=False, specular_reflectance=0.7),
+                normals=meshgen.vertex_normals(vc, f), texcoords=_planar_uv(vc) if uv else None)
     v, f = meshgen.bus(4000, seed=6)
-    sd.add_mesh(meshgen.place(v, -40.0, (7.0, -3.0, 1.7), scale=0.5), f, sd.add_diffuse(0.9, twosided=True))
+    vb = meshgen.place(v, -40.0, (7.0, -3.0, 1.7), scale=0.5)
+    sd.add_mesh(vb, f, sd.add_diffuse(0.9, twosided=True), texcoords=_planar_uv(vb) if uv else None)
     sd.finalize()
     return sd, lp
 
@@ -543,6 +555,44 @@ def test_zoo_multi_emitter_one_sided(hiplib, receive, two):
         hg, ho, st = _render_compare(sd, lp)
         if max_depth == -1:
             assert np.count_nonzero(hg) > 3
+
+
+def test_ray_intersect_full_surface_interaction(hiplib):
+    """bf_ray_intersect: every field of the SurfaceInteraction (mesh.cpp:452-548, rectangle.cpp:265-298,
+    interaction.h:159-162) bit-equal to the oracle, with and without vertex normals / texture coordinates."""
+    for uv in (False, True):
+        sd, _ = _zoo_scene(uv=uv)
+        g, o = capi.Scene(sd), OracleScene(sd)
+        rays = _rays(3000, 21 + uv, extent=1.0)
+        rays[:, 0:3] += [4.0, 0.0, 1.5]
+        r = g.ray_intersect(rays)
+        t, prim, shape, _ = o.trace_closest(rays)
+        assert np.array_equal(r["t"].view(np.uint32), t.view(np.uint32))
+        hit = np.isfinite(t)
+        assert np.array_equal(r["prim"][hit], prim[hit]) and np.array_equal(r["shape"][hit], shape[hit])
+        assert len(set(shape[hit])) >= 3 and hit.sum() > 1500
+        assert not r["raw"][~hit, 1:].any()
+        n_uv_tangent = 0
+        for i in np.flatnonzero(hit):
+            ref = o.intersect_full(rays[i])
+            for k in ("t", "p", "n", "sh_n", "sh_s", "sh_t", "wi", "prim_uv", "dp_du", "dp_dv"):
+                a, b = np.atleast_1d(r[k][i]), np.atleast_1d(ref[k])
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (uv, i, k, a, b)
+            # dp_du x dp_dv is parallel to n unless coordinate_system(n) was kept: count the UV-parameterised ones
+            n_uv_tangent += shape[i] >= len(sd.shapes) - 2 and abs(np.linalg.norm(ref["dp_du"]) - 1.0) > 1e-3
+        assert (n_uv_tangent > 500) if uv else n_uv_tangent == 0
+
+
+def test_render_uv_tangents_shape_anisotropic_lobe(hiplib):
+    sd, lp = _zoo_scene(uv=True)
+    hist, _, _ = _render_compare(sd, lp)
+    # the same scene without texture coordinates renders differently: the tangent frame is observable
+    sd0, _ = _zoo_scene(uv=True)
+    for s in sd0.shapes:
+        s.texcoords = None
+    sd0.finalize()
+    h0, _, _ = capi.Scene(sd0).render(lp)
+    assert not np.array_equal(h0, hist)
 
 
 @pytest.mark.parametrize("phased_tx,phased_rx,steer", [(True, True, (0.0, 0.0, 0.0)), (True, False, (12.0, 0.0, 0.0)),

@@ -128,10 +128,16 @@ def test_xml_errors_are_reported_like_the_reference(mitsuba):
         load_string(TRANS_RAD_LIKE.replace('name="width" value="1"', 'name="width" value="4"'))
 
 
-def _write_obj(path, v, f, with_normals=False):
+def _write_obj(path, v, f, with_normals=False, texcoords=None):
     with open(path, "w") as fh:
         for p in v:
             fh.write("v %r %r %r\n" % tuple(float(x) for x in p))
+        if texcoords is not None:
+            for uv in texcoords:
+                fh.write("vt %r %r\n" % (float(uv[0]), float(uv[1])))
+            for t in f:
+                fh.write("f %d/%d %d/%d %d/%d\n" % tuple(int(i) + 1 for i in t for _ in (0, 1)))
+            return
         if with_normals:
             fh.write("vn 0 0 1\n")
         for t in f:
@@ -183,6 +189,18 @@ def test_obj_loader_known_answers_and_normals(mitsuba, tmp_path):
     t, prim, _, uv = o.trace_closest([[-0.3, -0.3, -10, eps, 0, 0, 1, np.inf]])
     assert np.isclose(r["t"], 10) and np.allclose(r["prim_uv"], [0.35, 0.3], atol=1e-6)
     assert prim[0] == 1                  # global primitive index: the emitter rectangle is primitive 0
+    # texture coordinates (flip_tex_coords defaults to true: obj.cpp:99,199) reach the boundary and give the tangents
+    # test_mesh.py:284-285,296-297 expect
+    uv = (v[:, :2] + 1) / 2
+    _write_obj(tmp_path / "rectangle_uv.obj", v, f, texcoords=np.stack([uv[:, 0], 1 - uv[:, 1]], 1))
+    scene = load_string(MESH_SCENE % ("obj", "rectangle_uv.obj", ""), base_dir=str(tmp_path))
+    desc = scene.flat_desc(scene.sensors()[0])
+    sh = desc.desc.shapes[1]
+    assert bool(sh.texcoords) and sh.n_vertices == 4
+    pos = np.ctypeslib.as_array(sh.positions, shape=(4, 3))
+    assert np.allclose(np.ctypeslib.as_array(sh.texcoords, shape=(4, 2)), (pos[:, :2] + 1) / 2, atol=1e-6)
+    r = OracleScene(desc).intersect_full([-0.3, -0.3, -10, eps, 0, 0, 1, np.inf])
+    assert np.allclose(r["dp_du"], [2, 0, 0], atol=1e-6) and np.allclose(r["dp_dv"], [0, 2, 0], atol=1e-6)
     # quad face + face_normals=true: one polygon fan-triangulated, no normals kept
     with open(tmp_path / "quad.obj", "w") as fh:
         fh.write("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n")

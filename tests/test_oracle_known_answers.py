@@ -136,6 +136,17 @@ def test_mesh_rectangle_obj_known_answers():
     assert np.allclose(r["p"], [0.3, 0.3, 0.0], atol=1e-6)
     assert np.allclose(r["n"], [0, 0, 1], atol=1e-6)
     assert np.allclose(r["wi"], [0, 0, -1], atol=1e-6)
+    # the file carries texture coordinates (u, v) = ((x + 1) / 2, (y + 1) / 2): dp_du, dp_dv follow them
+    # (test_mesh.py:284-285,296-297; mesh.cpp:493-512) and so does the shading frame's s (interaction.h:159-162)
+    uv = (v[:, :2] + 1) / 2
+    o = OracleScene(scenes.single_mesh(v, f, texcoords=uv))
+    for ray in ([-0.3, -0.3, -10, capi_eps(), 0, 0, 1, np.inf], [0.3, 0.3, -10, capi_eps(), 0, 0, 1, np.inf]):
+        r = o.intersect_full(ray)
+        assert np.allclose(r["dp_du"], [2, 0, 0], atol=1e-6) and np.allclose(r["dp_dv"], [0, 2, 0], atol=1e-6)
+        assert np.allclose(r["sh_s"], [1, 0, 0], atol=1e-6) and np.allclose(r["sh_t"], [0, 1, 0], atol=1e-6)
+    # without texture coordinates: coordinate_system(n) (vector.h:116-136)
+    r0 = OracleScene(scenes.single_mesh(v, f)).intersect_full([-0.3, -0.3, -10, capi_eps(), 0, 0, 1, np.inf])
+    assert not np.allclose(r0["dp_du"], [2, 0, 0], atol=1e-3)
 
 
 @pytest.mark.parametrize("brute", [False, True])
