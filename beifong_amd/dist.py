@@ -30,3 +30,17 @@ def render_sharded(render_fn, n_paths, n_floats, device="cpu", group=None):
     if world > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
     return hist, (off, cnt)
+
+
+def render_cube_sharded(render_fn, n_paths, shape, device="cpu", group=None):
+    """Sweep variant (BASELINE configs[4]): render_fn(path_offset, count, cube) accumulates this rank's share of the
+    paths of EVERY frame / pulse into cube (float32[shape], e.g. [n_pulses, cells, 3]); the whole cube is reduced
+    with ONE all-reduce after the last local kernel ("shard paths within each pulse")."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    off, cnt = shard_range(n_paths, rank, world)
+    cube = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+    render_fn(off, cnt, cube)
+    if world > 1:
+        dist.all_reduce(cube, op=dist.ReduceOp.SUM, group=group)
+    return cube, (off, cnt)

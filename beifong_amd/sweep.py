@@ -69,7 +69,15 @@ def render_sweep(frames, n_streams=4, lib=None, device=None):
     return out
 
 
-def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None):
+def _shard_launch(launch, off, cnt):
+    lp = capi.bf_launch()
+    C.memmove(C.byref(lp), C.byref(launch), C.sizeof(capi.bf_launch))
+    lp.path_offset = launch.path_offset + off
+    lp.n_paths = cnt
+    return lp
+
+
+def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None, group=None):
     """Coherent pulse sweep over a rigidly moving target (BASELINE configs[4]).
 
     `sd`      scene description whose meshes are the target (rectangles — ground, antennas — stay put);
@@ -79,8 +87,14 @@ def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None):
 
     The BVH is built once per stream handle and re-fitted per pulse on the device
     (bf_scene_translate_meshes); pulses rotate over the streams.  Returns the slow-time x fast-time
-    cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W)."""
+    cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W).
+
+    Under an initialised torch.distributed job (one process per GPU) every rank renders its contiguous share of
+    each pulse's paths (bf_launch.path_offset) and the cube is summed with one all-reduce at the end
+    (beifong_amd.dist.render_cube_sharded); every rank returns the full cube."""
     import torch
+    import torch.distributed as tdist
+    from .dist import render_cube_sharded
     lib = lib or capi.load_library()
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
     offsets = np.asarray(offsets, dtype=np.float32).reshape(-1, 3)
@@ -88,14 +102,19 @@ def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None):
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     handles = [capi.Scene(sd, lib) for _ in range(n_streams)]
     n_chan = handles[0].channels(launch)
-    cube = torch.zeros((len(offsets), n_chan), dtype=torch.float32, device=dev)
-    for k, off in enumerate(offsets):
-        j = k % n_streams
-        with torch.cuda.stream(streams[j]):
-            handles[j].translate_meshes(off, stream=streams[j].cuda_stream)
-            handles[j].render_device(launch, cube[k].data_ptr(), stream=streams[j].cuda_stream)
-    for s in streams:
-        s.synchronize()
+
+    def render(path_off, count, cube):
+        lp = _shard_launch(launch, path_off, count)
+        for k, off in enumerate(offsets):
+            j = k % n_streams
+            with torch.cuda.stream(streams[j]):
+                handles[j].translate_meshes(off, stream=streams[j].cuda_stream)
+                handles[j].render_device(lp, cube[k].data_ptr(), stream=streams[j].cuda_stream)
+        for s in streams:
+            s.synchronize()
+
+    cube, _ = render_cube_sharded(render, int(launch.n_paths), (len(offsets), n_chan), device=dev,
+                                  group=group if tdist.is_initialized() else None)
     out = cube.cpu().numpy().reshape(len(offsets), -1, 3)
     for h in handles:
         h.close()

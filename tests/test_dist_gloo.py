@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from beifong_amd import capi, scenes
-from beifong_amd.dist import render_sharded, shard_range
+from beifong_amd.dist import render_cube_sharded, render_sharded, shard_range
 
 
 def test_shard_range_partitions():
@@ -69,3 +69,43 @@ def test_two_rank_all_reduce_equals_single_run(tmp_path):
     assert h0[4] == n_paths
     s0, s1 = np.load(tmp_path / "span_0.npy"), np.load(tmp_path / "span_1.npy")
     assert s0[0] == 0 and s0[0] + s0[1] == s1[0] and s1[0] + s1[1] == n_paths
+
+
+def _pulse_scene(k):
+    """Pulse k of a tiny coherent sweep: the plate 4 mm closer per pulse (scene rebuilt — the oracle has no refit)."""
+    sd, lp = scenes.plate_doppler(wavelength_m=0.1, n_paths=3001, plate_x=5.0 - 0.004 * k)
+    return sd, lp
+
+
+def _cube_worker(rank, world, port, n_pulses, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.oracle_lib import OracleScene
+    _, lp0 = _pulse_scene(0)
+
+    def render(off, cnt, cube):
+        from beifong_amd.sweep import _shard_launch
+        for k in range(n_pulses):
+            sd, lp = _pulse_scene(k)
+            h, _, _ = OracleScene(sd).render(_shard_launch(lp, off, cnt))
+            cube[k] += torch.from_numpy(h)
+
+    cube, _ = render_cube_sharded(render, int(lp0.n_paths), (n_pulses, 3))
+    np.save(os.path.join(out_dir, f"cube_{rank}.npy"), cube.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_pulse_cube_equals_single_run(tmp_path):
+    """C5 sharding: paths of every pulse split over the ranks, ONE all-reduce of the (I, Q, W) cube."""
+    n_pulses, world = 4, 2
+    mp.spawn(_cube_worker, args=(world, _free_port(), n_pulses, str(tmp_path)), nprocs=world, join=True)
+    from tests.oracle_lib import OracleScene
+    ref = np.stack([OracleScene(sd).render(lp)[0] for sd, lp in map(_pulse_scene, range(n_pulses))])
+    c0, c1 = np.load(tmp_path / "cube_0.npy"), np.load(tmp_path / "cube_1.npy")
+    assert np.array_equal(c0, c1)
+    assert np.allclose(c0, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+    assert np.array_equal(c0[:, 2], ref[:, 2])             # W: the count of samples put, exact
+    assert np.abs(ref[:, :2]).max() > 0 and not np.allclose(ref[0, :2], ref[1, :2])   # the phase moves with the plate

@@ -1,0 +1,13 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd $R
+export ONLY=wavefront
+pass() { n=$1; shift; timeout -k 5 90 rocprofv3 --pmc "$@" -d $O/pmc_$n -o c -- python3 tools/quick_bench.py > $O/pmc_$n.log 2>&1 && echo "$n done"; }
+pass ta1 TA_TA_BUSY_sum GRBM_GUI_ACTIVE &&
+pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum &&
+pass tcp1 TCP_GATE_EN1_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum &&
+pass tcp2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum &&
+pass tcp3 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TD_TD_BUSY_sum
+python3 tools/rocpd_summary.py counters $(find $O/pmc_ta1 $O/pmc_ta2 $O/pmc_tcp1 $O/pmc_tcp2 $O/pmc_tcp3 -name "*.db") > $O/pmc_ta_summary.txt 2>&1
+cat $O/pmc_ta_summary.txt
