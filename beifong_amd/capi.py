@@ -80,7 +80,8 @@ class bf_launch(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("color_mode", C.c_uint32), ("n_paths", C.c_uint64),
                 ("path_offset", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_int32),
                 ("rr_depth", C.c_int32), ("bins", C.c_uint32), ("bins_y", C.c_uint32), ("bin_width", C.c_float),
-                ("time_c", C.c_float), ("flags", C.c_uint32), ("phase_bins", C.c_uint32)]
+                ("time_c", C.c_float), ("flags", C.c_uint32), ("phase_bins", C.c_uint32),
+                ("film_width", C.c_uint32), ("film_height", C.c_uint32), ("spp", C.c_uint32)]
 
 
 class bf_path_record(C.Structure):
@@ -167,8 +168,12 @@ def _ptr(a):
 
 
 def make_launch(mode, n_paths, seed=0, path_offset=0, bins=0, bin_width=0.0, color_mode=BF_COLOR_RGB,
-                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0, bins_y=0, phase_bins=0):
+                max_depth=-1, rr_depth=5, time_c=3.0e8, flags=0, bins_y=0, phase_bins=0, film=None, spp=0):
+    """film=(width, height), spp: multi-pixel film of the render modes; n_paths is then this call's share of the
+    width * height * spp paths of the whole film (path g samples pixel g // spp)."""
     lp = bf_launch()
+    if film is not None:
+        lp.film_width, lp.film_height, lp.spp = int(film[0]), int(film[1]), int(spp)
     lp.mode, lp.color_mode, lp.n_paths, lp.path_offset, lp.seed = mode, color_mode, n_paths, path_offset, seed
     lp.max_depth, lp.rr_depth, lp.bins, lp.bin_width, lp.time_c, lp.flags = max_depth, rr_depth, bins, bin_width, time_c, flags
     lp.bins_y = bins_y

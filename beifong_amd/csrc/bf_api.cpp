@@ -106,6 +106,7 @@ struct bf_scene {
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
     bfd::DSensor sensor_host;              // host copy of the device sensor record
+    uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
     float4 *tris0 = nullptr, *nodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
     std::vector<bfd::DShape> shapes_host;         // as created: mesh triangles carry their shape's material / emitter index
@@ -152,12 +153,16 @@ bf_status bf_set_device(int device) {
     return BF_OK;
 }
 
+static uint32_t film_pixels(const bf_launch *lp) {
+    return (lp->spp && lp->film_width && lp->film_height) ? lp->film_width * lp->film_height : 1u;
+}
+
 uint32_t bf_launch_channels(const bf_launch *lp) {
     if (!lp) return 0;
     switch (lp->mode) {
-        case BF_MODE_PATH: return 5;
-        case BF_MODE_RANGE: return 5 + lp->bins;
-        case BF_MODE_TIME: return 5 + 3 * lp->bins;
+        case BF_MODE_PATH: return 5 * film_pixels(lp);
+        case BF_MODE_RANGE: return (5 + lp->bins) * film_pixels(lp);
+        case BF_MODE_TIME: return (5 + 3 * lp->bins) * film_pixels(lp);
         case BF_MODE_RECEIVE_RAW: return (3 + lp->phase_bins) * lp->bins * lp->bins_y;
         case BF_MODE_RECEIVE_IQ: return 3 * lp->bins * lp->bins_y;
     }
@@ -418,8 +423,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     *out = nullptr;
     if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
     if (desc->n_materials == 0 || !desc->materials) return fail(BF_ERR_INVALID, "at least one material is required");
-    if (desc->sensor.film_width != 1 || desc->sensor.film_height != 1)
-        return fail(BF_ERR_UNSUPPORTED, "only 1x1 films are supported (all radar scenes; fluxmeter.cpp:51-52)");
+    if (desc->sensor.film_width == 0 || desc->sensor.film_height == 0)
+        return fail(BF_ERR_INVALID, "sensor film is %u x %u", desc->sensor.film_width, desc->sensor.film_height);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(BF_ERR_DEVICE, "no HIP device available: the HIP path has no CPU fallback");
@@ -450,6 +455,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         }
     }
     sc->sensor_host = flat.sensor;
+    sc->film_w = desc->sensor.film_width;
+    sc->film_h = desc->sensor.film_height;
     sc->origin_scale_built = origin_scale;
     bf::BVH bvh;
     bf::build_bvh(btris, bvh, origin_scale);
@@ -607,6 +614,8 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, desc->materials, desc->n_materials * sizeof(bf_material), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync((void *) scene->d.sensor, &f.sensor, sizeof(bfd::DSensor), hipMemcpyHostToDevice, stream));
     scene->sensor_host = f.sensor;
+    scene->film_w = desc->sensor.film_width;
+    scene->film_h = desc->sensor.film_height;
     scene->emitter_types.clear();
     for (const auto &e : f.emitters) scene->emitter_types.push_back(e.type);
     scene->d.c = desc->physics.c;
@@ -899,9 +908,27 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     if (launch->phase_bins > 4096) return fail(BF_ERR_INVALID, "phase_bins %u out of range", launch->phase_bins);
     if ((launch->mode == BF_MODE_RANGE || launch->mode == BF_MODE_TIME) && (launch->bins == 0 || !(launch->bin_width > 0.f)))
         return fail(BF_ERR_INVALID, "range/time mode needs bins > 0 and bin_width > 0");
+    const bool multi_pixel = launch->spp && launch->film_width && launch->film_height;
+    if (multi_pixel ? (launch->film_width != scene->film_w || launch->film_height != scene->film_h)
+                    : (scene->film_w != 1 || scene->film_h != 1) && !is_rx)
+        return fail(BF_ERR_INVALID, "the sensor's film is %u x %u: the launch must name the same film and spp > 0 (it has %u x %u, spp %u)",
+                    scene->film_w, scene->film_h, launch->film_width, launch->film_height, launch->spp);
+    if (multi_pixel) {
+        if (launch->mode == BF_MODE_RECEIVE_RAW || launch->mode == BF_MODE_RECEIVE_IQ)
+            return fail(BF_ERR_INVALID, "receive modes bin into the ADC: film_width / film_height / spp must be 0");
+        const uint64_t px = (uint64_t) launch->film_width * launch->film_height;
+        if (px > (1u << 24) || px * (5ull + 3ull * launch->bins) > (1ull << 31))
+            return fail(BF_ERR_UNSUPPORTED, "film %u x %u with %u bins is too large", launch->film_width, launch->film_height, launch->bins);
+        if (launch->path_offset + launch->n_paths > px * launch->spp)
+            return fail(BF_ERR_INVALID, "path_offset + n_paths = %llu exceeds film_width * film_height * spp = %llu",
+                        (unsigned long long) (launch->path_offset + launch->n_paths), (unsigned long long) (px * launch->spp));
+    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     bfd::DLaunch lp;
     std::memset(&lp, 0, sizeof(lp));
+    lp.film_w = multi_pixel ? launch->film_width : 1u;
+    lp.film_h = multi_pixel ? launch->film_height : 1u;
+    lp.spp = multi_pixel ? launch->spp : 0u;
     lp.mode = launch->mode;
     lp.color_mode = launch->color_mode;
     lp.n_paths = launch->n_paths;
@@ -917,6 +944,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     lp.bin_width = launch->bin_width;
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);
+    lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
     lp.lds_hist = (lp.n_chan <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan : 0);
     lds = (lds + 15) & ~size_t(15);

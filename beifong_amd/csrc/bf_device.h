@@ -100,6 +100,9 @@ struct DLaunch {
     uint32_t n_chan;
     uint32_t lds_hist;        // 1: histogram privatised in LDS
     uint32_t iq;              // 1: BF_MODE_RECEIVE_IQ (mode is RECEIVE_RAW inside the kernels): contributions are phasors
+    uint32_t film_w, film_h;  // render modes: film size in pixels (>= 1)
+    uint32_t spp;             // paths per pixel; 0 = single-pixel film (every path samples pixel 0)
+    uint32_t chan_px;         // channels per pixel (n_chan = film_w * film_h * chan_px)
 };
 
 // device counters (uint64 each)

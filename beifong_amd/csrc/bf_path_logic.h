@@ -23,6 +23,8 @@
 namespace bfd {
 
 constexpr uint32_t kFlagValid = 1u << 24, kFlagFilmOk = 1u << 25, kFlagTermPending = 1u << 26, kDepthMask = 0xffffffu;
+// multi-pixel films: the sample landed in the left / upper neighbour of the pixel it was drawn in (ImageBlock::put)
+constexpr uint32_t kFlagFilmLeft = 1u << 27, kFlagFilmUp = 1u << 28;
 
 struct PathState {
     V3 ro, rd;
@@ -376,7 +378,7 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
     float ax = .5f, ay = .5f;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
-    bool film_ok = true;
+    bool film_ok = true, film_left = false, film_up = false;
     if (receive) {
         // receive_sample — integrator.cpp:1544-1572
         ax = next_1d(s.rng);
@@ -399,9 +401,21 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
         }
         if (sc.sensor->shutter_open_time > 0.f) (void) next_1d(s.rng);
         (void) next_1d(s.rng);     // wavelength sample (consumed in RGB mode too)
-        (void) sensor_sample_ray(sc, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
-        // ImageBlock::put box branch: lo = ceil(pos - .5 - .5) must be 0 for the 1x1 film
-        film_ok = __builtin_ceilf((fx - .5f) - .5f) == 0.f && __builtin_ceilf((fy - .5f) - .5f) == 0.f;
+        // position_sample = pos + next_2d; adjusted_position = position_sample / crop_size (integrator.cpp:263,276-278)
+        uint32_t px = 0, py = 0;
+        if (lp.spp) {
+            const uint64_t q = (lp.path_offset + path_i) / lp.spp;
+            px = (uint32_t) (q % lp.film_w);
+            py = (uint32_t) (q / lp.film_w);
+        }
+        const float posx = (float) px + fx, posy = (float) py + fy;
+        (void) sensor_sample_ray(sc, posx / (float) lp.film_w, posy / (float) lp.film_h, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
+        // ImageBlock::put, box branch (imageblock.cpp:166-172): the sample lands in pixel lo = ceil(pos - .5 - .5),
+        // i.e. the pixel it was drawn in or, when next_2d returned exactly 0, its left / upper neighbour
+        const float lx = __builtin_ceilf((posx - .5f) - .5f), ly = __builtin_ceilf((posy - .5f) - .5f);
+        film_ok = lx >= 0.f && lx < (float) lp.film_w && ly >= 0.f && ly < (float) lp.film_h;
+        film_left = lx < (float) px;
+        film_up = ly < (float) py;
         s.aux = 0.f;
     }
     s.throughput = 1.f;
@@ -410,7 +424,7 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
     s.result = 0.f;
     s.bs_pdf = 0.f;
     s.prev_p = mk(0, 0, 0);
-    s.flags = film_ok ? kFlagFilmOk : 0u;
+    s.flags = (film_ok ? kFlagFilmOk : 0u) | (film_left ? kFlagFilmLeft : 0u) | (film_up ? kFlagFilmUp : 0u);
     s.n_rays = 1;
 }
 
@@ -667,11 +681,28 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         if (is_time && lp.color_mode == BF_COLOR_RGB) srgb_to_xyz_grey(s.result, a0, a1, a2);
         bool ok = (s.flags & kFlagFilmOk) && __builtin_isfinite(X) && __builtin_isfinite(Y) && __builtin_isfinite(Z);
         if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
+        // multi-pixel film: every channel of the sample goes to its pixel's block of the histogram; the 1 x 1 film
+        // keeps the five base channels in registers until film_flush
+        uint32_t pix = 0u;
+        if (lp.spp) {
+            const uint64_t q = (lp.path_offset + s.path_i) / lp.spp;
+            const uint32_t px = (uint32_t) (q % lp.film_w) - ((s.flags & kFlagFilmLeft) ? 1u : 0u);
+            const uint32_t py = (uint32_t) (q / lp.film_w) - ((s.flags & kFlagFilmUp) ? 1u : 0u);
+            pix = (py * lp.film_w + px) * lp.chan_px;          // only used when kFlagFilmOk
+        }
         if (ok) {
-            acc.X += X;
-            acc.Y += Y;
-            acc.Z += Z;
-            acc.A += valid ? 1.f : 0.f;
+            if (lp.spp) {
+                if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 0u, X);
+                if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 1u, Y);
+                if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 2u, Z);
+                if (valid) hist_add(s_hist, g_hist, lds_hist, pix + 3u, 1.f);
+                hist_add(s_hist, g_hist, lds_hist, pix + 4u, 1.f);
+            } else {
+                acc.X += X;
+                acc.Y += Y;
+                acc.Z += Z;
+                acc.A += valid ? 1.f : 0.f;
+            }
             acc.W += 1.f;
             if (is_range || is_time) {
                 // range.cpp:141-161 / time.cpp:134-153: bin i takes the sample iff
@@ -684,11 +715,11 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                     float lo = (float) i * w, hi = (float) i * w + w;
                     if (s.aux >= lo && s.aux < hi) {
                         if (is_range) {
-                            if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, 5u + (uint32_t) i, a0);
+                            if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 5u + (uint32_t) i, a0);
                         } else if (a0 != 0.f || a1 != 0.f || a2 != 0.f) {
-                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 0u, a0);
-                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 1u, a1);
-                            hist_add(s_hist, g_hist, lds_hist, 5u + 3u * (uint32_t) i + 2u, a2);
+                            hist_add(s_hist, g_hist, lds_hist, pix + 5u + 3u * (uint32_t) i + 0u, a0);
+                            hist_add(s_hist, g_hist, lds_hist, pix + 5u + 3u * (uint32_t) i + 1u, a1);
+                            hist_add(s_hist, g_hist, lds_hist, pix + 5u + 3u * (uint32_t) i + 2u, a2);
                         }
                     }
                 }
@@ -722,7 +753,7 @@ BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_
             acc.A += __shfl_down(acc.A, off);
             acc.W += __shfl_down(acc.W, off);
         }
-        if (lane == 0 && acc.W != 0.f) {
+        if (lane == 0 && acc.W != 0.f && !lp.spp) {
             hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
             hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
             hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);

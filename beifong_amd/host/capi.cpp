@@ -98,6 +98,12 @@ int bfh_integrator_launch(void *integrator, void *endpoint, bf_launch *out) {
         if (auto *se = dynamic_cast<Sensor *>((Object *) endpoint)) {
             out->n_paths = se->sampler()->sample_count();
             out->seed = se->sampler()->base_seed();
+            if (se->film()->width() != 1 || se->film()->height() != 1) {       // as SamplingIntegrator::render
+                out->film_width = se->film()->width();
+                out->film_height = se->film()->height();
+                out->spp = (uint32_t) out->n_paths;
+                out->n_paths *= (uint64_t) se->film()->width() * se->film()->height();
+            }
         } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
             out->n_paths = re->sampler()->sample_count();
             out->seed = re->sampler()->base_seed();

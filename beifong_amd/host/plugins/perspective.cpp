@@ -1,4 +1,4 @@
-// src/sensors/perspective.cpp:95-132 — PerspectiveCamera (1x1 film)
+// src/sensors/perspective.cpp:95-132 — PerspectiveCamera
 #include <cmath>
 #include "../render.h"
 using namespace bfh;
@@ -37,13 +37,12 @@ public:
         if (m_to_world.has_scale()) Throw("Scale factors in the camera-to-world transformation are not allowed!");
     }
     void flatten(bf_sensor &s, int32_t) const override {
-        if (m_film->width() != 1 || m_film->height() != 1)
-            Throw("perspective: only 1x1 films are supported on the radar path (all radar scenes use one)");
         s.type = BF_SENSOR_PERSPECTIVE;
         s.shape = -1;
-        // perspective_projection — sensor.h:196-231 (aspect 1, no crop) and its inverse
+        // perspective_projection — sensor.h:196-231 (no crop) and its inverse
+        const float aspect = m_film->width() / (float) m_film->height();
         Transform4f c2s = Transform4f::scale({1.f, 1.f, 1.f}) * Transform4f::translate({0.f, 0.f, 0.f}) *
-                          Transform4f::scale({-0.5f, -0.5f, 1.f}) * Transform4f::translate({-1.f, -1.f, 0.f}) *
+                          Transform4f::scale({-0.5f, -0.5f * aspect, 1.f}) * Transform4f::translate({-1.f, -1.f / aspect, 0.f}) *
                           Transform4f::perspective(m_x_fov, m_near_clip, m_far_clip);
         for (int i = 0; i < 16; ++i) {
             s.to_world[i] = m_to_world.matrix.m[i];

@@ -500,7 +500,7 @@ static uint32_t color_mode_of_variant() {
 }
 
 bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
-    // integrator.cpp:58-204 for a 1x1 film: channels X,Y,Z,A,W + aov_names()
+    // integrator.cpp:58-204: channels X,Y,Z,A,W + aov_names() per pixel
     Film *film = sensor->film();
     std::vector<std::string> channels = {"X", "Y", "Z", "A", "W"};
     for (auto &n : aov_names()) channels.push_back(n);
@@ -509,6 +509,14 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
     std::memset(&lp, 0, sizeof(lp));
     lp.color_mode = color_mode_of_variant();
     lp.n_paths = sensor->sampler()->sample_count();
+    if (film->width() != 1 || film->height() != 1) {
+        // sample_count samples per pixel, pixels row-major (bf_launch.spp)
+        if (lp.n_paths > 0xffffffffull) Throw("sample_count %llu is too large", (unsigned long long) lp.n_paths);
+        lp.film_width = film->width();
+        lp.film_height = film->height();
+        lp.spp = (uint32_t) lp.n_paths;
+        lp.n_paths *= (uint64_t) film->width() * film->height();
+    }
     lp.seed = sensor->sampler()->base_seed();
     lp.max_depth = max_depth();
     lp.rr_depth = rr_depth();
@@ -516,7 +524,8 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
     configure(lp);
     if (lp.mode == BF_MODE_RECEIVE_RAW) Throw("this integrator only supports receive(), not render()");
     uint32_t n = bf_launch_channels(&lp);
-    if (n != channels.size()) Throw("internal error: channel count mismatch (%u vs %zu)", n, channels.size());
+    if (n != channels.size() * film->width() * film->height())
+        Throw("internal error: channel count mismatch (%u vs %zu)", n, channels.size() * film->width() * film->height());
     std::vector<float> hist(n);
     auto t0 = std::chrono::steady_clock::now();
     bf_status st = bf_render(scene->device_scene(sensor), &lp, hist.data(), nullptr, &m_stats.stats);

@@ -121,16 +121,17 @@ def _coordinate_system(n):
     return s, t
 
 
-def perspective_sample_to_camera(fov_x_deg, near, far):
-    """m_sample_to_camera for a 1x1 film without crop.
+def perspective_sample_to_camera(fov_x_deg, near, far, aspect=1.0):
+    """m_sample_to_camera for a film of aspect = width / height without crop.
 
     include/mitsuba/render/sensor.h:196-231: camera_to_sample =
     scale(1/rel) * translate(-off) * scale(-.5, -.5*aspect, 1) *
     translate(-1, -1/aspect, 0) * perspective(fov, near, far); inverse taken
     through Transform's analytic inverse composition.
     """
-    t = (Transform4f.scale([1, 1, 1]) * Transform4f.translate([0, 0, 0]) * Transform4f.scale([-0.5, -0.5, 1.0]) *
-         Transform4f.translate([-1.0, -1.0, 0.0]) * Transform4f.perspective(fov_x_deg, near, far))
+    aspect = float(f32(aspect))
+    t = (Transform4f.scale([1, 1, 1]) * Transform4f.translate([0, 0, 0]) * Transform4f.scale([-0.5, -0.5 * aspect, 1.0]) *
+         Transform4f.translate([-1.0, -1.0 / aspect, 0.0]) * Transform4f.perspective(fov_x_deg, near, far))
     return t.inv.copy()
 
 
@@ -303,11 +304,13 @@ class SceneDesc:
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_FLUXMETER, shape
         self.shapes[shape].is_sensor = 1
 
-    def set_perspective(self, to_world, fov=45.0, near_clip=0.01, far_clip=10000.0):
+    def set_perspective(self, to_world, fov=45.0, near_clip=0.01, far_clip=10000.0, film=(1, 1)):
+        """film = (width, height) in pixels; fov is the horizontal field of view (fov_axis "x")."""
         s = self.sensor
         s.type, s.shape = capi.BF_SENSOR_PERSPECTIVE, -1
+        s.film_width, s.film_height = int(film[0]), int(film[1])
         s.to_world = _m16(to_world.matrix)
-        s.sample_to_camera = _m16(perspective_sample_to_camera(fov, near_clip, far_clip))
+        s.sample_to_camera = _m16(perspective_sample_to_camera(fov, near_clip, far_clip, film[0] / film[1]))
         s.fov_x_deg, s.near_clip, s.far_clip = fov, near_clip, far_clip
 
     def finalize(self):

@@ -223,3 +223,19 @@ def phased_receive(n_tris=20000, n_paths=20000, n_elems=4, steer_deg=(0.0, 0.0, 
     sd.finalize()
     launch = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, n_paths, seed=seed, bins=t_bins, bins_y=1)
     return sd, launch
+
+
+def film_half_lit(film=(4, 2), spp=256, radiance=3.0, mode=None, bins=0, dr=0.0):
+    """Multi-pixel film known answer: a perspective camera at the origin looking along +z (up +y, horizontal
+    fov 90 deg) and an area light at z = 2 that fills exactly the half of the view on the camera's +x side —
+    the LEFT half of the image (sensor.h:196-231: sample.x = (1 - x_clip) / 2)."""
+    sd = SceneDesc()
+    w, h = film
+    half_h = 2.0 * h / w                                    # view half-extents at z = 2: 2 horizontally, 2 h / w vertically
+    light = sd.add_rectangle(T.translate([1.0, 0.0, 2.0]) * T.rotate([0, 1, 0], 180) * T.scale([1.0, half_h, 1.0]), sd.add_diffuse(0.0))
+    sd.add_area_emitter(light, radiance)
+    sd.set_perspective(T.look_at([0, 0, 0], [0, 0, 1], [0, 1, 0]), fov=90.0, near_clip=0.1, far_clip=100.0, film=film)
+    sd.finalize()
+    lp = capi.make_launch(capi.BF_MODE_PATH if mode is None else mode, w * h * spp, seed=11, bins=bins, bin_width=dr,
+                          color_mode=capi.BF_COLOR_MONO, film=film, spp=spp)
+    return sd, lp

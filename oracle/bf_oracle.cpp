@@ -1676,11 +1676,22 @@ struct SampleOut {
     PathResult pr;
 };
 
-static uint32_t launch_channels(const bf_launch &lp) {
+// multi-pixel film of the render modes (bf_launch.film_width / film_height / spp)
+static bool film_multi(const bf_launch &lp) { return lp.spp && lp.film_width && lp.film_height; }
+static uint32_t film_pixels(const bf_launch &lp) { return film_multi(lp) ? lp.film_width * lp.film_height : 1u; }
+static uint32_t pixel_channels(const bf_launch &lp) {
     switch (lp.mode) {
         case BF_MODE_PATH: return 5;
         case BF_MODE_RANGE: return 5 + lp.bins;
         case BF_MODE_TIME: return 5 + 3 * lp.bins;
+    }
+    return 0;
+}
+static uint32_t launch_channels(const bf_launch &lp) {
+    switch (lp.mode) {
+        case BF_MODE_PATH:
+        case BF_MODE_RANGE:
+        case BF_MODE_TIME: return pixel_channels(lp) * film_pixels(lp);
         case BF_MODE_RECEIVE_RAW: return (3 + lp.phase_bins) * lp.bins * lp.bins_y;
         case BF_MODE_RECEIVE_IQ: return 3 * lp.bins * lp.bins_y;
     }
@@ -1689,23 +1700,34 @@ static uint32_t launch_channels(const bf_launch &lp) {
 
 // one render_sample(); accumulates into hist (double accumulators so the CPU
 // sum itself is not the error source when compared with the GPU's fp32 atomics)
-static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, double *hist) {
+static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, double *hist, uint64_t global_path) {
     SampleOut out;
+    // pixel of this sample: row-major over the film, spp consecutive paths per pixel (the reference's wavefront
+    // branch, integrator.cpp:171-187; its scalar branch walks Morton-ordered blocks, same sample set per pixel)
+    const bool multi = film_multi(lp);
+    const uint32_t film_w = multi ? lp.film_width : 1u, film_h = multi ? lp.film_height : 1u;
+    uint32_t px = 0, py = 0;
+    if (multi) {
+        const uint64_t q = global_path / lp.spp;
+        px = (uint32_t) (q % film_w);
+        py = (uint32_t) (q / film_w);
+    }
     float fx, fy;
-    smp.next_2d(fx, fy);                                    // :263 (pos = 0 for the 1x1 film)
+    smp.next_2d(fx, fy);                                    // :263 position_sample = pos + next_2d
+    const float posx = (float) px + fx, posy = (float) py + fy;
     float ax = .5f, ay = .5f;
     if (sensor_needs_aperture_sample(sc.sensor)) smp.next_2d(ax, ay);   // :265-267
     float time = sc.sensor.shutter_open;
     if (sc.sensor.shutter_open_time > 0.f) time += smp.next_1d() * sc.sensor.shutter_open_time;   // :269-271
     float wl = smp.next_1d();                               // :273
-    // adjusted_position = (position_sample - crop_offset) / crop_size, 1x1 film
+    // adjusted_position = (position_sample - crop_offset) / crop_size (:276-278), crop_offset = 0
     Ray ray;
-    float w = sensor_sample_ray(sc, time, wl, fx / 1.f, fy / 1.f, ax, ay, ray);
+    float w = sensor_sample_ray(sc, time, wl, posx / (float) film_w, posy / (float) film_h, ax, ay, ray);
     out.pr = path_sample(sc, lp, smp, ray);
     float L = w * out.pr.L;
     out.L = L;
 
-    const uint32_t nchan = launch_channels(lp);
+    const uint32_t nchan = pixel_channels(lp);
     static thread_local std::vector<float> aovs;
     aovs.assign(nchan, 0.f);
     float xyz[3];
@@ -1740,11 +1762,15 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     // lo = ceil(pos - .5 - .5) must be 0 in both axes for the 1x1 film
     bool ok = true;
     for (uint32_t k = 0; k < nchan; ++k) ok = ok && std::isfinite(aovs[k]);
-    int lox = (int) std::ceil((fx - .5f) - .5f), loy = (int) std::ceil((fy - .5f) - .5f);
-    ok = ok && lox == 0 && loy == 0;
+    // (film level: pos = position_sample - (0 - 0 + .5), imageblock.cpp:113,166-172; the reference applies
+    // the same rule per spiral block, whose size follows the thread count)
+    int lox = (int) std::ceil((posx - .5f) - .5f), loy = (int) std::ceil((posy - .5f) - .5f);
+    ok = ok && lox >= 0 && lox < (int) film_w && loy >= 0 && loy < (int) film_h;
     out.put = ok;
-    if (ok)
-        for (uint32_t k = 0; k < nchan; ++k) hist[k] += (double) aovs[k];
+    if (ok) {
+        double *dst = hist + (size_t) nchan * ((size_t) loy * film_w + (size_t) lox);
+        for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) aovs[k];
+    }
     return out;
 }
 
@@ -1930,10 +1956,10 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
         // m_sample_to_camera (perspective.cpp:104-109) is supplied by the host
         std::memcpy(sc.sample_to_camera.m, d->sensor.sample_to_camera, sizeof(float) * 16);
     }
-    if (d->sensor.film_width != 1 || d->sensor.film_height != 1) {
-        g_err = "only 1x1 films are supported";
+    if (d->sensor.film_width == 0 || d->sensor.film_height == 0) {
+        g_err = "sensor film has no pixels";
         delete h;
-        return BF_ERR_UNSUPPORTED;
+        return BF_ERR_INVALID;
     }
     build_bvh(sc);
     *out = h;
@@ -1962,6 +1988,15 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
     }
     const OScene &sc = s->sc;
     const uint32_t nchan = launch_channels(*lp);
+    if (!is_receive && (film_multi(*lp) ? (lp->film_width != s->sc.sensor.film_width || lp->film_height != s->sc.sensor.film_height)
+                                        : (s->sc.sensor.film_width != 1 || s->sc.sensor.film_height != 1))) {
+        g_err = "the launch must name the sensor's film (film_width, film_height, spp > 0) unless it is 1 x 1";
+        return BF_ERR_INVALID;
+    }
+    if (film_multi(*lp) && (is_receive || lp->path_offset + lp->n_paths > (uint64_t) film_pixels(*lp) * lp->spp)) {
+        g_err = "multi-pixel film: render modes only, path_offset + n_paths <= film_width * film_height * spp";
+        return BF_ERR_INVALID;
+    }
     if (rng_mode == 1) n_threads = 1;
     if (n_threads < 1) n_threads = 1;
     std::vector<std::vector<double>> th_hist(n_threads, std::vector<double>(nchan, 0.0));
@@ -1976,8 +2011,11 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
         if (rng_mode == 1) smp.rng.seed(lp->seed + 0);
         for (uint64_t i = lo; i < hi; ++i) {
             if (rng_mode == 0) smp.rng.seed(lp->seed + lp->path_offset + i);
+            // literal scalar mode on a multi-pixel film: one stream per pixel (render_block, integrator.cpp:221)
+            if (rng_mode == 1 && film_multi(*lp) && (lp->path_offset + i) % lp->spp == 0)
+                smp.rng.seed(lp->seed + (lp->path_offset + i) / lp->spp);
             SampleOut o = is_receive ? receive_sample(sc, *lp, smp, th_hist[tid].data())
-                                     : render_sample(sc, *lp, smp, th_hist[tid].data());
+                                     : render_sample(sc, *lp, smp, th_hist[tid].data(), lp->path_offset + i);
             bf_stats &st = th_stats[tid];
             st.n_paths++;
             st.n_rays_closest += o.pr.n_closest;

@@ -97,3 +97,46 @@ def test_film_develop_through_the_python_layer(mitsuba, hiplib, tmp_path):
     ref = np.array(bmp)
     for k, n in enumerate(names):
         assert np.array_equal(img[:, :, k], ref[:, :, bmp.channel_names().index(n)])
+
+
+FILM_SCENE = """
+<scene version="2.1.0">
+    <integrator type="range"><integrator type="pathlength"/><float name="dr" value="0.5"/><integer name="bins" value="20"/></integrator>
+    <sensor type="perspective">
+        <float name="fov" value="90"/><float name="near_clip" value="0.1"/><float name="far_clip" value="100"/>
+        <transform name="to_world"><lookat origin="0, 0, 0" target="0, 0, 1" up="0, 1, 0"/></transform>
+        <film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="2"/><rfilter type="box"/></film>
+        <sampler type="independent"><integer name="sample_count" value="128"/></sampler>
+    </sensor>
+    <shape type="rectangle">
+        <transform name="to_world"><rotate y="1" angle="180"/><translate x="1" z="2"/></transform>
+        <emitter type="area"><spectrum name="radiance" value="3"/></emitter>
+    </shape>
+</scene>
+"""
+
+
+def test_multi_pixel_film_through_the_plugin_surface(mitsuba, hiplib, tmp_path):
+    """hdrfilm width x height > 1 x 1: sample_count paths per pixel, bitmap [H, W, 5 + bins] (integrator.cpp:58-204)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    scene = load_string(FILM_SCENE)
+    sensor = scene.sensors()[0]
+    scene.integrator().render(scene, sensor)
+    bmp = np.array(sensor.film().bitmap(raw=True))
+    assert bmp.shape == (2, 4, 25)
+    assert np.array_equal(bmp[:, :, 4], np.full((2, 4), 128)) and np.array_equal(bmp[:, :, 3], [[128, 128, 0, 0]] * 2)
+    lp = scene.integrator().launch_for(sensor)
+    assert (lp.film_width, lp.film_height, lp.spp, lp.n_paths) == (4, 2, 128, 1024)
+    ref, _, _ = OracleScene(scene.flat_desc(sensor)).render(lp, threads=4)
+    assert np.allclose(bmp.reshape(-1), ref, rtol=2e-5, atol=1e-3)
+    assert bmp[:, :2, 5:].sum() > 0 and not bmp[:, 2:, 5:].any()
+    # and as an EXR of that size
+    from beifong_amd.mitsuba._host import read_exr
+    film = sensor.film()
+    film.set_destination_file(str(tmp_path / "img"))
+    film.develop()
+    img, names = read_exr(str(tmp_path / "img.exr"))
+    chan = film.bitmap(raw=True).channel_names()
+    assert img.shape == (2, 4, 25)
+    for k, n in enumerate(names):
+        assert np.array_equal(img[:, :, k], bmp[:, :, chan.index(n)])

@@ -647,3 +647,74 @@ def test_cross_seed_statistical_agreement(hiplib):
     assert np.mean(z < 3.0) > 0.9 and np.median(z) < 1.5
     assert abs(sa.n_rays_closest / n - sb.n_rays_closest / n) < 0.02
     assert abs(float(ha[3]) - float(hb[3])) < 5 * np.sqrt(n)            # alpha: hit fraction
+
+
+def _film_compare(sd, lp, film, chan):
+    """Multi-pixel film: per-path records exact, per-pixel histograms to summation order, both pipelines."""
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
+    g = capi.Scene(sd)
+    out = None
+    for flags in (capi.BF_FLAG_MEGAKERNEL, 0, capi.BF_FLAG_GLOBAL_ATOMICS):
+        lp.flags = flags
+        hg, rg, sg = g.render(lp, records=True)
+        for k in ("n_rays", "valid"):
+            assert np.array_equal(rg[k], ro[k])
+        assert np.array_equal(rg["aux"].view(np.uint32), ro["aux"].view(np.uint32))
+        assert np.array_equal(rg["L"].view(np.uint32), ro["L"].view(np.uint32))
+        assert sg.n_rays_closest == so.n_rays_closest and sg.n_rays_shadow == so.n_rays_shadow and sg.n_invalid == so.n_invalid
+        a, b = hg.reshape(film[1], film[0], chan), ho.reshape(film[1], film[0], chan)
+        assert np.array_equal(a[:, :, 3:5], b[:, :, 3:5])                    # alpha and weight: integer counts
+        amax = float(np.abs(ro["L"]).max())
+        assert np.allclose(a, b, rtol=2e-5, atol=lp.spp * 2.0 ** -24 * max(amax, 1.0) * 4)
+        out = a
+    lp.flags = 0
+    return out
+
+
+def test_multi_pixel_film_known_answer_on_device(hiplib):
+    film, spp = (4, 2), 256
+    sd, lp = scenes.film_half_lit(film, spp, 3.0)
+    img = _film_compare(sd, lp, film, 5)
+    assert np.array_equal(img[:, :, 4], np.full((2, 4), spp)) and np.array_equal(img[:, :, 3], [[spp, spp, 0, 0]] * 2)
+    assert np.allclose(img[:, :2, :3], 3.0 * spp, rtol=1e-6)
+    # spp = 0 on a 1 x 1 film is the same launch
+    sd1, lp1 = scenes.film_half_lit((1, 1), 4096, 3.0)
+    g = capi.Scene(sd1)
+    a = g.render(lp1)[0]
+    lp1.film_width = lp1.film_height = lp1.spp = 0
+    assert np.allclose(a, g.render(lp1)[0], rtol=1e-6)
+    # the launch has to name the sensor's film
+    lp.film_width = 3
+    with pytest.raises(capi.BeifongError, match="film"):
+        capi.Scene(sd).render(lp)
+
+
+@pytest.mark.parametrize("mode,film", [(capi.BF_MODE_RANGE, (8, 6)), (capi.BF_MODE_TIME, (5, 3)), (capi.BF_MODE_RANGE, (96, 64))])
+def test_multi_pixel_range_image_of_the_zoo(hiplib, mode, film):
+    """A transient (range / time resolved) IMAGE: the zoo scene through a perspective camera with a W x H film.
+    96 x 64 x (5 + 128) floats exceed the LDS-privatised histogram: global atomics."""
+    sd, lp0 = _zoo_scene(two_emitters=True)
+    T = Transform4f
+    sd.set_perspective(T.translate([0, 0, 0.3]) * T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90), fov=60.0, near_clip=0.1,
+                       far_clip=100.0, film=film)
+    sd.finalize()
+    spp = 64 if film[0] < 32 else 4
+    bins = 128 if mode == capi.BF_MODE_RANGE else 40
+    lp = capi.make_launch(mode, film[0] * film[1] * spp, seed=5, bins=bins, bin_width=0.1 if mode == capi.BF_MODE_RANGE else 1e-9,
+                          color_mode=capi.BF_COLOR_RGB, film=film, spp=spp)
+    chan = 5 + bins * (1 if mode == capi.BF_MODE_RANGE else 3)
+    img = _film_compare(sd, lp, film, chan)
+    assert np.array_equal(img[:, :, 4], np.full((film[1], film[0]), spp))
+    assert (img[:, :, 5:].sum(axis=2) > 0).mean() > 0.3                     # the scene is in view
+    # sharding by path_offset tiles the film's sample set exactly
+    if film == (8, 6):
+        g = capi.Scene(sd)
+        full = g.render(lp, records=True)[1]
+        half = lp.n_paths // 2 + 7
+        parts = []
+        for off, cnt in ((0, half), (half, lp.n_paths - half)):
+            l2 = capi.make_launch(mode, cnt, seed=5, path_offset=off, bins=bins, bin_width=lp.bin_width, color_mode=capi.BF_COLOR_RGB,
+                                  film=film, spp=spp)
+            parts.append(g.render(l2, records=True))
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), full)
+        assert np.allclose(parts[0][0] + parts[1][0], img.ravel(), rtol=2e-5, atol=1e-4)

@@ -318,3 +318,45 @@ def test_elementary_functions(oracle):
     # tan (Beckmann phi warp argument range)
     x, y = run(6, rng.uniform(-1.5, 1.5, n))
     assert _ulp_err(y, np.tan(x.astype(np.float64))).max() < 4.0
+
+
+def test_multi_pixel_film_known_answer():
+    """SamplingIntegrator::render over a W x H film (integrator.cpp:58-310; perspective_projection,
+    sensor.h:196-231; ImageBlock::put box branch, imageblock.cpp:166-172): an area light that fills the
+    camera's +x half of the view lights exactly the LEFT half of the image, every pixel takes its spp samples."""
+    film, spp, radiance = (4, 2), 256, 3.0
+    sd, lp = scenes.film_half_lit(film, spp, radiance)
+    h, rec, st = OracleScene(sd).render(lp, records=True, threads=4)
+    img = h.reshape(film[1], film[0], 5)
+    assert np.array_equal(img[:, :, 4], np.full((2, 4), spp))               # W: samples put per pixel
+    assert np.array_equal(img[:, :2, 3], np.full((2, 2), spp))              # alpha: the light is hit
+    assert np.array_equal(img[:, 2:, 3], np.zeros((2, 2)))
+    assert np.allclose(img[:, :2, :3], radiance * spp, rtol=1e-6)           # emitter seen directly: L = radiance
+    assert not img[:, 2:, :3].any()
+    assert st.n_rays_closest == 8 * spp and st.n_invalid == 0
+    # path g samples pixel g // spp, row-major
+    assert np.array_equal(rec["valid"].reshape(2, 4, spp).all(axis=2), [[1, 1, 0, 0], [1, 1, 0, 0]])
+    # the 1 x 1 film of the radar scenes is the same launch with spp = 0
+    sd1, lp1 = scenes.film_half_lit((1, 1), 512, radiance)
+    a = OracleScene(sd1).render(lp1)[0]
+    lp1.film_width = lp1.film_height = lp1.spp = 0
+    b = OracleScene(sd1).render(lp1)[0]
+    assert np.array_equal(a, b) and a[4] == 512 and 0.45 < a[3] / 512 < 0.55
+    # a range histogram per pixel: the light is binned at pathlength 3 t (first hit + emitter vertex + NEE block each
+    # add si.t: pathlength.cpp:146,161,209), t in [2, 3] over the lit half
+    sd, lp = scenes.film_half_lit(film, spp, radiance, mode=capi.BF_MODE_RANGE, bins=20, dr=0.5)
+    img = OracleScene(sd).render(lp)[0].reshape(2, 4, 5 + 20)
+    assert np.allclose(img[:, :2, 5:].sum(axis=2), radiance * spp, rtol=1e-6) and not img[:, 2:, 5:].any()
+    ks = np.nonzero(img[0, 0, 5:])[0]
+    assert ks.min() >= int(3 * 2.0 / 0.5) and ks.max() <= int(3 * np.sqrt(4 + 4 + 1) / 0.5)
+    assert np.nonzero(img[0, 1, 5:])[0].max() < ks.max()          # the inner column is nearer than the outer one
+
+
+def test_launch_film_must_match_sensor_film():
+    sd, lp = scenes.film_half_lit((4, 2), 4, 1.0)
+    lp.film_width = 2
+    with pytest.raises(RuntimeError, match="film"):
+        OracleScene(sd).render(lp)
+    lp.film_width, lp.n_paths = 4, 4 * 2 * 4 + 1
+    with pytest.raises(RuntimeError, match="film"):
+        OracleScene(sd).render(lp)
