@@ -77,6 +77,48 @@ def _shard_launch(launch, off, cnt):
     return lp
 
 
+class PulseSweeper:
+    """Device-resident state of a pulse sweep: `n_streams` scene handles (one BVH build and one path pool each) and
+    their HIP streams, kept across sweeps — the second sweep of the same scene pays no build, no allocation and no
+    host synchronisation (the handles' launch plans are learnt by the first one).  See render_pulse_sweep."""
+
+    def __init__(self, sd, launch, n_streams=3, lib=None, device=None):
+        import torch
+        self.lib = lib or capi.load_library()
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.launch = launch
+        self.n_streams = max(1, int(n_streams))
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n_streams)]
+        self.handles = [capi.Scene(sd, self.lib) for _ in range(self.n_streams)]
+        self.n_chan = self.handles[0].channels(launch)
+
+    def render(self, offsets, group=None):
+        """float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W) for target offsets float[n_pulses, 3]."""
+        import torch
+        import torch.distributed as tdist
+        from .dist import render_cube_sharded
+        offsets = np.asarray(offsets, dtype=np.float32).reshape(-1, 3)
+
+        def render(path_off, count, cube):
+            lp = _shard_launch(self.launch, path_off, count)
+            for k, off in enumerate(offsets):
+                j = k % self.n_streams
+                with torch.cuda.stream(self.streams[j]):
+                    self.handles[j].translate_meshes(off, stream=self.streams[j].cuda_stream)
+                    self.handles[j].render_device(lp, cube[k].data_ptr(), stream=self.streams[j].cuda_stream)
+            for s in self.streams:
+                s.synchronize()
+
+        cube, _ = render_cube_sharded(render, int(self.launch.n_paths), (len(offsets), self.n_chan), device=self.dev,
+                                      group=group if tdist.is_initialized() else None)
+        return cube.cpu().numpy().reshape(len(offsets), -1, 3)
+
+    def close(self):
+        for h in self.handles:
+            h.close()
+        self.handles = []
+
+
 def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None, group=None):
     """Coherent pulse sweep over a rigidly moving target (BASELINE configs[4]).
 
@@ -87,38 +129,18 @@ def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None, 
 
     The BVH is built once per stream handle and re-fitted per pulse on the device
     (bf_scene_translate_meshes); pulses rotate over the streams.  Returns the slow-time x fast-time
-    cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W).
+    cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W).  One-shot form of PulseSweeper (which keeps the
+    handles for further sweeps).
 
     Under an initialised torch.distributed job (one process per GPU) every rank renders its contiguous share of
     each pulse's paths (bf_launch.path_offset) and the cube is summed with one all-reduce at the end
     (beifong_amd.dist.render_cube_sharded); every rank returns the full cube."""
-    import torch
-    import torch.distributed as tdist
-    from .dist import render_cube_sharded
-    lib = lib or capi.load_library()
-    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-    offsets = np.asarray(offsets, dtype=np.float32).reshape(-1, 3)
-    n_streams = max(1, min(n_streams, len(offsets)))
-    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
-    handles = [capi.Scene(sd, lib) for _ in range(n_streams)]
-    n_chan = handles[0].channels(launch)
-
-    def render(path_off, count, cube):
-        lp = _shard_launch(launch, path_off, count)
-        for k, off in enumerate(offsets):
-            j = k % n_streams
-            with torch.cuda.stream(streams[j]):
-                handles[j].translate_meshes(off, stream=streams[j].cuda_stream)
-                handles[j].render_device(lp, cube[k].data_ptr(), stream=streams[j].cuda_stream)
-        for s in streams:
-            s.synchronize()
-
-    cube, _ = render_cube_sharded(render, int(launch.n_paths), (len(offsets), n_chan), device=dev,
-                                  group=group if tdist.is_initialized() else None)
-    out = cube.cpu().numpy().reshape(len(offsets), -1, 3)
-    for h in handles:
-        h.close()
-    return out
+    n = len(np.asarray(offsets, dtype=np.float32).reshape(-1, 3))
+    sw = PulseSweeper(sd, launch, max(1, min(n_streams, n)), lib, device)
+    try:
+        return sw.render(offsets, group)
+    finally:
+        sw.close()
 
 
 def range_doppler(cube, window=True):
