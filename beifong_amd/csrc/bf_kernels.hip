@@ -390,6 +390,16 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     // (any grid finishes the job: waves loop over their segment of the alive masks; the cap keeps the
     // launch within the scene's traversal-spill columns)
     unsigned grid = (std::min(n_slots, wf->n_slots) + bfd::kBlock - 1) / bfd::kBlock;
+    {
+        // spread the survivors thinly while the chip has room: a wave that starts with ~16 paths instead of 64 runs
+        // them four lanes per ray (traverse_quad) from its first bounce and waits for the longest of 16, not of 64
+        static const unsigned spread = [] {
+            const char *e = getenv("BF_TAIL_SPREAD");
+            return e ? (unsigned) std::max(1, atoi(e)) : 1u;
+        }();
+        const unsigned resident = (sc->spill_stride / bfd::kBlock) * BF_TAIL_WAVES / bfd::kTraceBlocksPerCU;
+        if (spread > 1 && grid < resident) grid = std::min(grid * spread, resident);
+    }
     grid = std::min(grid, sc->spill_stride / bfd::kBlock);
     {
         static const unsigned cap = [] {
