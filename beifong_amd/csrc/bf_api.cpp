@@ -183,6 +183,8 @@ bf_status bf_scene_destroy(bf_scene *s) {
     return BF_OK;
 }
 
+static_assert(bf::kTopNodes == bfd::kTopNodes, "the builder's breadth-first prefix is what wf_trace caches");
+
 namespace {
 struct TriMeta {
     uint32_t prim, shape;
@@ -981,6 +983,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         stats_out->n_rays_closest = c[bfd::CTR_CLOSEST];
         stats_out->n_rays_shadow = c[bfd::CTR_SHADOW];
         stats_out->n_nodes_visited = c[bfd::CTR_NODES];
+        stats_out->n_nodes_lds = c[bfd::CTR_NODES_LDS];
         stats_out->n_tris_tested = c[bfd::CTR_TRIS];
         stats_out->n_invalid = c[bfd::CTR_INVALID];
         stats_out->n_bounces = c[bfd::CTR_BOUNCES];

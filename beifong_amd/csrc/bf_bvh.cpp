@@ -338,6 +338,35 @@ void collapse_bvh4(const BVH &in, BVH4 &out) {
     Collapser c{in, out, 4};
     out.root_child = 0;
     out.stack_need = c.emit(in.root_child, 0, 1);      // <= 3 * kMaxDepth (the binary depth bound)
+
+    // top levels first, breadth-first (BVH4 comment); child references follow the move
+    const size_t n = out.nodes.size();
+    std::vector<int32_t> new_of(n, -1);
+    std::vector<int32_t> order;
+    order.reserve(n);
+    order.push_back(0);
+    new_of[0] = 0;
+    for (size_t head = 0; head < order.size() && order.size() < kTopNodes; ++head)
+        for (int i = 0; i < 4 && order.size() < kTopNodes; ++i) {
+            const int32_t ch = out.nodes[(size_t) order[head]].child[i];
+            if (ch >= 0) {
+                new_of[(size_t) ch] = (int32_t) order.size();
+                order.push_back(ch);
+            }
+        }
+    for (size_t i = 0; i < n; ++i)
+        if (new_of[i] < 0) {
+            new_of[i] = (int32_t) order.size();
+            order.push_back((int32_t) i);
+        }
+    std::vector<Node4> moved(n);
+    for (size_t k = 0; k < n; ++k) {
+        Node4 w = out.nodes[(size_t) order[k]];
+        for (int i = 0; i < 4; ++i)
+            if (w.child[i] >= 0) w.child[i] = new_of[(size_t) w.child[i]];
+        moved[k] = w;
+    }
+    out.nodes.swap(moved);
 }
 
 }  // namespace bf

@@ -63,6 +63,10 @@ struct alignas(16) Node4 {
 static_assert(sizeof(Node4) == 128, "wide node must be 128 bytes");
 constexpr int32_t kEmptyChild = INT32_MIN;
 
+// The first kTopNodes nodes of a BVH4 are its top levels in breadth-first order (the traversal kernels keep a copy
+// of them in LDS: every ray walks through them); the rest keep the depth-first order of the collapse.
+constexpr uint32_t kTopNodes = 85;    // 1 + 4 + 16 + 64: three full levels under the root
+
 struct BVH4 {
     std::vector<Node4> nodes;         // nodes[0] is the root if root_child >= 0
     int32_t root_child;               // >= 0: node index, < 0: the whole mesh is one leaf

@@ -21,6 +21,7 @@ namespace bfd {
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kStackDepth = 32;      // per-lane traversal stack entries in LDS
 constexpr int kMaxLdsHist = 12288;   // floats of LDS-privatised histogram (48 KiB)
+constexpr uint32_t kTopNodes = 85;   // == bf::kTopNodes (bf_bvh.h): nodes of the tree's top levels kept in LDS by wf_trace
 
 struct DRect {
     float to_world[12];   // 3x4 row-major affine
@@ -106,6 +107,6 @@ struct DLaunch {
 };
 
 // device counters (uint64 each)
-enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_TRACED, CTR_COUNT };
+enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_TRACED, CTR_NODES_LDS, CTR_COUNT };
 
 }  // namespace bfd

@@ -151,9 +151,8 @@ BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
 // [mint, tmax], push the hit children far-to-near and return the nearest one (or the next
 // stack entry, or kNoNode when the traversal is finished).
 template <class Stack>
-BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, float mint, float tmax, Stack &st) {
-    const float4 *np = nodes + 8u * (uint32_t) node;
-    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+BF_DEV int node4_decide(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz,
+                        const float4 ch, V3 id, V3 oid, float mint, float tmax, Stack &st) {
     float t0, t1, t2, t3;
     const bool h0 = slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, mint, tmax, t0);
     const bool h1 = slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, mint, tmax, t1);
@@ -169,6 +168,37 @@ BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid,
     if (m1 < kMissKey) st.push(pick_child(ch, m1));
     if (lo < kMissKey) return pick_child(ch, lo);
     return st.pop_or_none();
+}
+template <class Stack>
+BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, float mint, float tmax, Stack &st) {
+    const float4 *np = nodes + 8u * (uint32_t) node;
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, mint, tmax, st);
+}
+
+// The top of the tree — its first n_top nodes, breadth-first (bf_bvh.h: kTopNodes) — is walked by every ray; a
+// workgroup keeps a copy in LDS (`top`, kTopStride float4 per node: 144-byte stride, so that lanes at different
+// nodes fall into different bank groups while lanes at the same node broadcast) and only deeper nodes go through
+// the vector-memory pipeline, the busiest unit of the traversal kernels.
+constexpr uint32_t kTopStride = 9;
+BF_DEV void load_top_nodes(const float4 *__restrict__ nodes, uint32_t n_top, float4 *top, uint32_t tid, uint32_t n_threads) {
+    for (uint32_t i = tid; i < n_top * 7u; i += n_threads) {
+        const uint32_t node = i / 7u, j = i - node * 7u;
+        top[node * kTopStride + j] = nodes[8u * node + j];
+    }
+}
+template <class Stack>
+BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, int n_top, int node, V3 id, V3 oid, float mint,
+                          float tmax, Stack &st) {
+    float4 lx, ly, lz, hx, hy, hz, ch;
+    if (node < n_top) {
+        const float4 *np = top + kTopStride * (uint32_t) node;
+        lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    } else {
+        const float4 *np = nodes + 8u * (uint32_t) node;
+        lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    }
+    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, mint, tmax, st);
 }
 
 // all triangles of one leaf; returns true when an any-hit query is decided

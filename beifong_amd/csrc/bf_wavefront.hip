@@ -298,10 +298,14 @@ constexpr int kLdsStack = 16;
 template <bool STATS, int W>
 __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t it) {
     __shared__ int s_stack[kLdsStack * kBlock];
+    __shared__ float4 s_top[kTopNodes * kTopStride];
     int *stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int nxt = (it & 1) ^ 1;
-    uint32_t c_nodes = 0, c_tris = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_top = 0;
+    const int n_top = (int) min(sc.n_nodes, kTopNodes);
+    load_top_nodes(sc.nodes, (uint32_t) n_top, s_top, threadIdx.x, kBlock);
+    __syncthreads();
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     LaneStack<kLdsStack, true> st = make_stack<kLdsStack, true>(sc, stack);
     const uint32_t n_batches = wf.n_slots >> 6;
@@ -397,8 +401,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 // progress guarantee: only postpone the stragglers if some lane has a leaf to intersect
                 if ((uint32_t) __popcll(at_node) < wf.trace_stragglers && __ballot(has && node < 0 && node != kNoNode)) break;
                 if (has && node >= 0) {
-                    if (STATS) ++c_nodes;
-                    node = node4_step(sc.nodes, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
+                    if (STATS) {
+                        ++c_nodes;
+                        c_top += node < n_top ? 1u : 0u;
+                    }
+                    node = node4_step_top(sc.nodes, s_top, n_top, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
                 }
             }
             // (b) intersect the postponed leaves together
@@ -431,15 +438,17 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
         }
     }
     if (STATS) {
-        unsigned long long v_nodes = c_nodes, v_tris = c_tris;
+        unsigned long long v_nodes = c_nodes, v_tris = c_tris, v_top = c_top;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             v_nodes += __shfl_down(v_nodes, off);
             v_tris += __shfl_down(v_tris, off);
+            v_top += __shfl_down(v_top, off);
         }
         if (lane == 0) {
             atomicAdd(&wf.counters[CTR_NODES], v_nodes);
             atomicAdd(&wf.counters[CTR_TRIS], v_tris);
+            atomicAdd(&wf.counters[CTR_NODES_LDS], v_top);
         }
     }
 }

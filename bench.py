@@ -120,6 +120,10 @@ def main():
     v_n_tr = st.n_nodes_visited * share / max(st.n_rays_traced, 1)
     v_t_tr = st.n_tris_tested * share / max(st.n_rays_traced, 1)
     b_ray_tr = v_n_tr * info.node_bytes + v_t_tr * info.tri_bytes + 48.0
+    # node visits wf_trace serves from its LDS copy of the tree's top levels (they are algorithmic bytes of the
+    # traversal all the same; the figure without them is reported next to the headline one)
+    v_n_lds = st.n_nodes_lds / max(st.n_rays_traced, 1)
+    b_ray_tr_mem = (v_n_tr - v_n_lds) * info.node_bytes + v_t_tr * info.tri_bytes + 48.0
     # every scene handle allocates its wavefront pool and learns its launch plan on first use:
     # touch each once (untimed, before the W warm-up steps) so neither pass below pays for that
     for j in range(n_streams):
@@ -228,6 +232,8 @@ def main():
                 "bytes_per_ray": round(b_ray_tr, 1),
                 "nodes_per_ray": round(v_n_tr, 2),
                 "tris_per_ray": round(v_t_tr, 2),
+                "nodes_per_ray_from_lds": round(v_n_lds, 2),
+                "achieved_without_lds_served_nodes": round(achieved * b_ray_tr_mem / b_ray_tr, 2),
                 "all_rays": {"bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(v_n, 2), "tris_per_ray": round(v_t, 2),
                              "resolved_in_wf_shade_frac": round(1.0 - bvh_rays0 / rays0, 4)},
                 "rays_per_launch": int(rays_per_launch),

@@ -247,6 +247,8 @@ typedef struct bf_stats {
     uint64_t n_rays_tail;      /* rays traced by the tail kernel (not by wf_trace)   */
     uint64_t n_rays_traced;    /* rays that entered wf_trace (the others were resolved
                                   by wf_shade: rectangles + BVH root-box test)       */
+    uint64_t n_nodes_lds;      /* of n_nodes_visited: served from wf_trace's LDS copy of
+                                  the tree's top levels (only with BF_FLAG_STATS)     */
 } bf_stats;
 
 typedef struct bf_scene_info {
