@@ -181,6 +181,9 @@ BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid,
 // nodes fall into different bank groups while lanes at the same node broadcast) and only deeper nodes go through
 // the vector-memory pipeline, the busiest unit of the traversal kernels.
 constexpr uint32_t kTopStride = 9;
+typedef float bf_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const bf_f4 *lds_f4_ptr;
+BF_DEV float4 to_float4(bf_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 BF_DEV void load_top_nodes(const float4 *__restrict__ nodes, uint32_t n_top, float4 *top, uint32_t tid, uint32_t n_threads) {
     for (uint32_t i = tid; i < n_top * 7u; i += n_threads) {
         const uint32_t node = i / 7u, j = i - node * 7u;
@@ -192,8 +195,11 @@ BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, i
                           float tmax, Stack &st) {
     float4 lx, ly, lz, hx, hy, hz, ch;
     if (node < n_top) {
-        const float4 *np = top + kTopStride * (uint32_t) node;
-        lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+        // read through an LDS-qualified pointer: with a generic one the compiler folds both branches into one
+        // flat_load per row, which still occupies the vector-memory pipeline for every lane
+        const lds_f4_ptr np = (lds_f4_ptr) top + kTopStride * (uint32_t) node;
+        lx = to_float4(np[0]), ly = to_float4(np[1]), lz = to_float4(np[2]), hx = to_float4(np[3]), hy = to_float4(np[4]),
+        hz = to_float4(np[5]), ch = to_float4(np[6]);
     } else {
         const float4 *np = nodes + 8u * (uint32_t) node;
         lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
