@@ -749,10 +749,10 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     static const int trace_waves = [] {
         const char *e = getenv("BF_TRACE_WAVES");
         int w = e ? atoi(e) : 5;
-        return w < 4 ? 4 : (w > 8 ? 8 : (w == 7 ? 6 : w));
+        return w < 5 ? 4 : 5;
     }();
-    // persistent grids: shade is register-heavy (2 workgroups per CU), trace runs
-    // 8 workgroups per CU (16 KiB LDS stack each, <= 64 VGPRs)
+    // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
+    // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)
     const unsigned batches_per_block = bfd::kBlock / 64;
     const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
     const unsigned grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), max_blocks));

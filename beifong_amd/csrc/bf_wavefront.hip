@@ -483,11 +483,8 @@ extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uin
         hipLaunchKernelGGL((bfd::wf_trace<true, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);        \
     else                                                                                                            \
         hipLaunchKernelGGL((bfd::wf_trace<false, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
-    if (waves >= 8) {
-        BF_TRACE_LAUNCH(8);
-    } else if (waves >= 6) {
-        BF_TRACE_LAUNCH(6);
-    } else if (waves == 5) {
+    // 28.6 KiB of LDS per workgroup (stacks + the tree's top levels): five workgroups per CU is the most that fit
+    if (waves >= 5) {
         BF_TRACE_LAUNCH(5);
     } else {
         BF_TRACE_LAUNCH(4);
