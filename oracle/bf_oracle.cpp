@@ -2118,6 +2118,16 @@ bf_status bfo_ray_intersect_full(const bfo_scene *s, const float *r, float *out)
     return BF_OK;
 }
 
+/* Sensor::sample_ray for one film / aperture sample (src/sensors/tests/test_perspective.py:61-175):
+ * out[0..7] = o.xyz, mint, d.xyz, ray weight */
+bf_status bfo_sensor_sample_ray(const bfo_scene *s, float fx, float fy, float ax, float ay, float *out) {
+    Ray ray;
+    float w = sensor_sample_ray(s->sc, 0.f, 0.f, fx, fy, ax, ay, ray);
+    float o[8] = {ray.o.x, ray.o.y, ray.o.z, ray.mint, ray.d.x, ray.d.y, ray.d.z, w};
+    std::memcpy(out, o, sizeof(o));
+    return BF_OK;
+}
+
 /* ---- unit-level entry points for the known-answer tests ------------------ */
 float bfo_tea_float32(uint32_t v0, uint32_t v1, int rounds) {
     uint32_t u = (tea32(v0, v1, rounds, nullptr) >> 9) | 0x3f800000u;
@@ -2177,6 +2187,35 @@ float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x
     return w;
 }
 float bfo_erfinv(float x) { return erfinv_giles(x); }
+/* MicrofacetDistribution unit access (golden vectors of src/librender/tests/test_microfacet.py).
+ * op: 0 eval(m), 1 pdf(wi, m), 2 smith_g1(v = m argument, m = wi argument), 3 sample(wi, (s0, s1)) -> out[0..2] = m,
+ * out[3] = pdf.  type: BF_MF_*. */
+void bfo_microfacet(int op, uint32_t type, float alpha_u, float alpha_v, int sample_visible, const float *wi, const float *m,
+                    float s0, float s1, float *out) {
+    bf_material mat;
+    std::memset(&mat, 0, sizeof(mat));
+    mat.distribution = type;
+    mat.alpha_u = alpha_u;
+    mat.alpha_v = alpha_v;
+    mat.sample_visible = (uint32_t) sample_visible;
+    Microfacet d(mat);
+    V3 w = {wi[0], wi[1], wi[2]}, mm = {m[0], m[1], m[2]};
+    if (op == 0) {
+        out[0] = d.eval(mm);
+    } else if (op == 1) {
+        out[0] = d.pdf(w, mm);
+    } else if (op == 2) {
+        out[0] = d.smith_g1(mm, w);
+    } else {
+        V3 r;
+        float pdf;
+        d.sample(w, s0, s1, r, pdf);
+        out[0] = r.x;
+        out[1] = r.y;
+        out[2] = r.z;
+        out[3] = pdf;
+    }
+}
 /* op: 0 sin, 1 cos, 2 acos, 3 exp, 4 log, 5 erf, 6 tan */
 void bfo_elementary(int op, uint32_t n, const float *x, float *y) {
     for (uint32_t i = 0; i < n; ++i) {

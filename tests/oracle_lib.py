@@ -102,6 +102,12 @@ class OracleScene:
         self.lib.bfo_trace_closest(self.handle, n, _ptr(rays), _ptr(t), _ptr(prim), _ptr(shape), _ptr(uv))
         return t, prim, shape, uv
 
+    def sensor_sample_ray(self, fx, fy, ax=0.5, ay=0.5):
+        out = np.zeros(8, np.float32)
+        self.lib.bfo_sensor_sample_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        self.lib.bfo_sensor_sample_ray(self.handle, fx, fy, ax, ay, _ptr(out))
+        return dict(o=out[0:3], mint=out[3], d=out[4:7], weight=out[7])
+
     def trace_any(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hit = np.empty(rays.shape[0], np.uint8)

@@ -473,3 +473,49 @@ def test_bfrender_cli_without_gpu_fails_cleanly(mitsuba, tmp_path):
     p.write_text(TRANS_RAD_LIKE)
     r = subprocess.run([os.path.join(HOST, "bfrender"), "-m", "scalar_rgb", "-Dspp=16", str(p)], capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.parametrize("direction", [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+@pytest.mark.parametrize("fov", [34, 80])
+def test_perspective_sensor_known_answers(mitsuba, direction, fov):
+    """src/sensors/tests/test_perspective.py:61-175 through the perspective plugin and the boundary: the ray of the film
+    centre leaves the camera origin along the camera direction, and a film sample at the extremity of the fov axis makes
+    an angle of fov / 2 with it — for fov_axis x / larger (512 x 256 film: x), y / smaller (y) and diagonal (corners)."""
+    from beifong_amd.mitsuba.core import Transform4f
+    from beifong_amd.mitsuba.core.xml import load_dict
+    origin = [1.0, 0.0, 1.5]
+    target = [origin[k] + direction[k] for k in range(3)]
+
+    def camera(fov_axis):
+        scene = load_dict({
+            "type": "scene",
+            "integrator": {"type": "path"},
+            "sensor": {"type": "perspective", "near_clip": 1.0, "far_clip": 35.0, "fov": fov, "fov_axis": fov_axis,
+                       "to_world": Transform4f.look_at(origin, target, [0, 1, 0]),
+                       "sampler": {"type": "independent", "sample_count": 4},
+                       "film": {"type": "hdrfilm", "rfilter": {"type": "box"}, "width": 512, "height": 256}},
+            "so": {"type": "rectangle", "bsdf": {"type": "diffuse"}},
+        })
+        desc = scene.flat_desc(scene.sensors()[0])
+        assert (desc.desc.sensor.film_width, desc.desc.sensor.film_height) == (512, 256)
+        return OracleScene(desc)
+
+    def angle(cam, sample):
+        r = cam.sensor_sample_ray(*sample)
+        assert np.allclose(r["o"], origin, atol=1e-6)
+        return np.degrees(np.arccos(np.clip(np.dot(r["d"], direction), -1, 1)))
+
+    cam = camera("x")
+    r = cam.sensor_sample_ray(0.5, 0.5)
+    assert np.allclose(r["d"], direction, atol=1e-6) and np.allclose(r["o"], origin, atol=1e-6) and r["weight"] == 1.0
+    for axis in ("x", "larger"):
+        cam = camera(axis)
+        for sample in ([0.0, 0.5], [1.0, 0.5]):
+            assert np.isclose(angle(cam, sample), fov / 2, atol=1e-3)
+    for axis in ("y", "smaller"):
+        cam = camera(axis)
+        for sample in ([0.5, 0.0], [0.5, 1.0]):
+            assert np.isclose(angle(cam, sample), fov / 2, atol=1e-3)
+    cam = camera("diagonal")
+    for sample in ([0.0, 0.0], [0.0, 1.0], [1.0, 0.0], [1.0, 1.0]):
+        assert np.isclose(angle(cam, sample), fov / 2, atol=1e-3)

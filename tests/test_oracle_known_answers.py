@@ -2,6 +2,7 @@
 hold for the building blocks of the hot path.  Each test names
 the reference test file:line the expected values come from."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -360,3 +361,62 @@ def test_launch_film_must_match_sensor_film():
     lp.film_width, lp.n_paths = 4, 4 * 2 * 4 + 1
     with pytest.raises(RuntimeError, match="film"):
         OracleScene(sd).render(lp)
+
+
+def _microfacet(op, typ, au, av, visible, wi, m, s=(0.0, 0.0)):
+    from tests.oracle_lib import load
+    lib = load()
+    lib.bfo_microfacet.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                   C.c_void_p]
+    lib.bfo_microfacet.restype = None
+    wi = np.ascontiguousarray(wi, np.float32)
+    m = np.ascontiguousarray(m, np.float32)
+    out = np.zeros(4, np.float32)
+    lib.bfo_microfacet(op, typ, au, av, int(visible), wi.ctypes.data, m.ctypes.data, float(s[0]), float(s[1]), out.ctypes.data)
+    return out
+
+
+def test_microfacet_distribution_golden_vectors():
+    """MicrofacetDistribution eval / pdf / smith_g1 / sample against the Mitsuba 0.6 reference data the reference's own
+    test holds (src/librender/tests/test_microfacet.py:18-313; vectors extracted by tools/make_microfacet_golden.py).
+    The inputs are rebuilt here as that file describes them; tolerances are its own (allclose defaults, sample: 5e-4 / 1e-4)."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "microfacet_vectors.json")))["vectors"]
+    f32 = np.float32
+    wi = [0, 0, 1]
+
+    def sweep(theta, phi):
+        theta, phi = np.broadcast_arrays(np.asarray(theta, f32), np.asarray(phi, f32))
+        return np.stack([np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)], 1).astype(f32)
+
+    steps = 20
+    B, G = capi.BF_MF_BECKMANN, capi.BF_MF_GGX
+    # test02: theta in [0, pi] at phi = pi/2, then theta = 0.1 over phi in [0, 2 pi]
+    v1 = sweep(np.linspace(0, np.pi, steps), np.full(steps, np.pi / 2))
+    v2 = sweep(np.full(steps, 0.1), np.linspace(0, 2 * np.pi, steps))
+    g = vec["test02_eval_pdf_beckmann"]
+    ev = lambda au, av, vs: np.array([_microfacet(0, B, au, av, False, wi, v)[0] for v in vs])
+    pd = lambda au, av, vs: np.array([_microfacet(1, B, au, av, False, wi, v)[0] for v in vs])
+    assert np.allclose(ev(0.1, 0.3, v1), g[0], rtol=1e-5, atol=1e-8) and np.allclose(pd(0.1, 0.3, v1), g[1], rtol=1e-5, atol=1e-8)
+    assert np.allclose(ev(0.1, 0.1, v1), g[2], rtol=1e-5, atol=1e-8) and np.allclose(pd(0.1, 0.1, v1), g[3], rtol=1e-5, atol=1e-8)
+    assert np.allclose(ev(0.1, 0.3, v2), g[4], rtol=1e-5) and np.allclose(pd(0.1, 0.3, v2), np.array(g[5]) * np.cos(0.1), rtol=1e-5)
+    assert np.allclose(ev(0.1, 0.1, v2), 11.86709118, rtol=1e-5) and np.allclose(pd(0.1, 0.1, v2), 11.86709118 * np.cos(0.1), rtol=1e-5)
+    # test03 (Beckmann, GGX): smith_g1(v, wi) over theta in [pi/3, pi/2] at phi = pi/2, then theta = 0.98 pi/2 over phi
+    v3 = sweep(np.linspace(np.pi / 3, np.pi / 2, steps), np.full(steps, np.pi / 2))
+    v4 = sweep(np.full(steps, np.pi / 2 * 0.98), np.linspace(0, 2 * np.pi, steps))
+    for typ, key, iso in ((B, "test03_smith_g1_beckmann", 0.67333597), (G, "test03_smith_g1_ggx", 0.46130955)):
+        g = vec[key]
+        g1 = lambda au, av, vs: np.array([_microfacet(2, typ, au, av, False, wi, v)[0] for v in vs])
+        # the last entry (theta = pi/2: grazing, 1e-6-sized) is sensitive to how cos(pi/2) rounds; compare it absolutely
+        assert np.allclose(g1(0.1, 0.3, v3), g[0], rtol=1e-4, atol=1e-5) and np.allclose(g1(0.1, 0.1, v3), g[1], rtol=1e-4, atol=1e-5)
+        assert np.allclose(g1(0.1, 0.3, v4), g[2], rtol=1e-5) and np.allclose(g1(0.1, 0.1, v4), iso, rtol=1e-5)
+    # test04 / test05: sample(wi, u) on the 6 x 6 grid u1, u2 = meshgrid(linspace(0, 1, 6)) -> (m, pdf), plain sampling
+    u = np.linspace(0, 1, 6).astype(f32)
+    u1, u2 = np.meshgrid(u, u)
+    for typ, key in ((B, "test04_sample_beckmann"), (G, "test05_sample_ggx")):
+        ref_m, ref_pdf = np.array(vec[key][0]), np.array(vec[key][1])
+        got = np.array([_microfacet(3, typ, 0.1, 0.3, False, wi, wi, (a, b)) for a, b in zip(u1.ravel(), u2.ravel())])
+        ok = np.isfinite(ref_pdf) & np.isfinite(got[:, 3])
+        assert ok.sum() >= 30
+        assert np.allclose(got[ok, :3], ref_m[ok], atol=5e-4), np.abs(got[ok, :3] - ref_m[ok]).max()
+        assert np.allclose(got[ok, 3], ref_pdf[ok], atol=1e-4 * max(1.0, np.abs(ref_pdf[ok]).max())), np.abs(got[ok, 3] - ref_pdf[ok]).max()
