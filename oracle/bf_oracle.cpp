@@ -2118,6 +2118,20 @@ bf_status bfo_ray_intersect_full(const bfo_scene *s, const float *r, float *out)
     return BF_OK;
 }
 
+/* Emitter::sample_direction of emitter `index` from a reference point (src/emitters/tests/test_spot.py:45-96,
+ * test_area.py:111-150): out[0..7] = d.xyz, dist, pdf, delta, grey spectrum (radiance / pdf, falloff / dist^2), n.z unused */
+bf_status bfo_emitter_sample_direction(const bfo_scene *s, uint32_t index, const float *ref_p, float sx, float sy, float *out) {
+    if (index >= s->sc.emitters.size()) return BF_ERR_INVALID;
+    SI ref;
+    ref.p = {ref_p[0], ref_p[1], ref_p[2]};
+    ref.time = 0.f;
+    DirectionSample ds;
+    float spec = emitter_sample_direction(s->sc, s->sc.emitters[index], ref, sx, sy, ds);
+    float o[8] = {ds.d.x, ds.d.y, ds.d.z, ds.dist, ds.pdf, ds.delta ? 1.f : 0.f, spec, emitter_pdf_direction(s->sc, s->sc.emitters[index], ds)};
+    std::memcpy(out, o, sizeof(o));
+    return BF_OK;
+}
+
 /* Sensor::sample_ray for one film / aperture sample (src/sensors/tests/test_perspective.py:61-175):
  * out[0..7] = o.xyz, mint, d.xyz, ray weight */
 bf_status bfo_sensor_sample_ray(const bfo_scene *s, float fx, float fy, float ax, float ay, float *out) {

@@ -102,6 +102,13 @@ class OracleScene:
         self.lib.bfo_trace_closest(self.handle, n, _ptr(rays), _ptr(t), _ptr(prim), _ptr(shape), _ptr(uv))
         return t, prim, shape, uv
 
+    def emitter_sample_direction(self, index, ref_p, sample=(0.0, 0.0)):
+        out = np.zeros(8, np.float32)
+        p = np.ascontiguousarray(ref_p, np.float32)
+        self.lib.bfo_emitter_sample_direction.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        assert self.lib.bfo_emitter_sample_direction(self.handle, index, _ptr(p), sample[0], sample[1], _ptr(out)) == 0
+        return dict(d=out[0:3], dist=out[3], pdf=out[4], delta=bool(out[5]), spec=out[6], pdf_direction=out[7])
+
     def sensor_sample_ray(self, fx, fy, ax=0.5, ay=0.5):
         out = np.zeros(8, np.float32)
         self.lib.bfo_sensor_sample_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]

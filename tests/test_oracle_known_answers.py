@@ -420,3 +420,58 @@ def test_microfacet_distribution_golden_vectors():
         assert ok.sum() >= 30
         assert np.allclose(got[ok, :3], ref_m[ok], atol=5e-4), np.abs(got[ok, :3] - ref_m[ok]).max()
         assert np.allclose(got[ok, 3], ref_pdf[ok], atol=1e-4 * max(1.0, np.abs(ref_pdf[ok]).max())), np.abs(got[ok, 3] - ref_pdf[ok]).max()
+
+
+@pytest.mark.parametrize("it_pos", [[2.0, 0.5, 0.0], [1.0, 0.5, -5.0]])
+@pytest.mark.parametrize("cutoff_angle", [20, 80])
+@pytest.mark.parametrize("lookat", [([0, 1, 0], [0, 0, 0], [1, 0, 0]), ([0, 0, 1], [0, 0, 0], [0, -1, 0])])
+def test_spot_sample_direction_known_answers(it_pos, cutoff_angle, lookat):
+    """src/emitters/tests/test_spot.py:45-96: delta direction sample towards the light's position, pdf 1, value =
+    intensity x falloff / dist^2 with beam_width = 0.75 cutoff and a linear falloff between the two angles."""
+    T = Transform4f
+    sd = SceneDesc()
+    sd.add_rectangle(T.scale([1, 1, 1]), sd.add_diffuse(0.5))
+    to_world = T.look_at(*lookat)
+    intensity = 2.5
+    sd.add_spot(to_world, intensity=intensity, cutoff_angle=float(cutoff_angle))
+    sd.set_perspective(T.translate([0, 0, 5]), fov=45.0)
+    sd.finalize()
+    r = OracleScene(sd).emitter_sample_direction(0, it_pos)
+    cutoff, pos = np.radians(cutoff_angle), np.array(lookat[0], float)
+    beam = 0.75 * cutoff
+    d = pos - np.array(it_pos)
+    dist = np.linalg.norm(d)
+    d /= dist
+    local = np.asarray(to_world.inv)[:3, :3] @ (-d)
+    angle = np.arccos(np.clip(local[2] / np.linalg.norm(local), -1, 1))
+    spec = intensity if angle <= beam else intensity * (cutoff - angle) / (cutoff - beam)
+    spec = spec if angle <= cutoff else 0.0
+    assert r["pdf"] == 1.0 and r["delta"] and np.isclose(r["dist"], dist, rtol=1e-6)
+    assert np.allclose(r["d"], d, atol=1e-6)
+    assert np.isclose(r["spec"], spec / dist ** 2, rtol=2e-4, atol=1e-7)
+
+
+def test_area_light_sample_direction_known_answers():
+    """src/emitters/tests/test_area.py:111-150: the area light samples its shape (Shape::sample_direction,
+    shape.cpp:323-342: pdf = dist^2 / (area |cos|)), pdf_direction agrees, value = radiance / pdf."""
+    T = Transform4f
+    sd = SceneDesc()
+    to_world = T.translate([0.3, -0.2, 2.0]) * T.rotate([1, 0, 0], 180) * T.scale([0.5, 0.25, 1])
+    light = sd.add_rectangle(to_world, sd.add_diffuse(0.0))
+    sd.add_area_emitter(light, 7.0)
+    sd.set_perspective(T.translate([0, 0, 5]), fov=45.0)
+    sd.finalize()
+    o = OracleScene(sd)
+    M = np.asarray(to_world.matrix, float)
+    for p in ([0.2, 0.1, 0.2], [0.6, -0.9, 0.2], [0.4, 0.9, -0.2]):
+        for s in ([0.4, 0.5], [0.1, 0.4], [0.3, 0.9]):
+            r = o.emitter_sample_direction(0, p, s)
+            q = (M @ np.array([2 * s[0] - 1, 2 * s[1] - 1, 0, 1.0]))[:3]
+            d = q - np.array(p)
+            dist = np.linalg.norm(d)
+            d /= dist
+            n = np.array([0, 0, -1.0])                       # the rectangle faces down
+            pdf = dist ** 2 / (4 * 0.5 * 0.25 * abs(d @ n))
+            assert np.allclose(r["d"], d, atol=1e-6) and np.isclose(r["dist"], dist, rtol=1e-6) and not r["delta"]
+            assert np.isclose(r["pdf"], pdf, rtol=1e-5) and np.isclose(r["pdf_direction"], r["pdf"], rtol=1e-6)
+            assert np.isclose(r["spec"], 7.0 / pdf, rtol=1e-5)
