@@ -261,6 +261,28 @@ def test_full_size_properties_c2(hiplib):
     assert np.allclose(h2, h, rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.timeout(600)
+def test_bench_step_every_path_bit_exact(hiplib):
+    """The bench workload itself — BASELINE configs[1] at the throughput size: 196 564 triangles, 2^24 paths, 45 M
+    rays — through the default pipeline (16 Mi-slot pool, planned launches, tail kernel): every one of the 16.7 M
+    per-path records (radiance bits, path length bits, validity, ray count) and every counter equal to the oracle's."""
+    sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, bins=256, dr=0.1, seed=1)
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=16)
+    g = capi.Scene(sd)
+    for rep in range(2):                          # the second render of a shape is the planned (host-sync-free) one
+        hg, rg, sg = g.render(lp, records=True)
+        assert np.array_equal(rg["n_rays"], ro["n_rays"]) and np.array_equal(rg["valid"], ro["valid"])
+        assert np.array_equal(rg["aux"].view(np.uint32), ro["aux"].view(np.uint32))
+        assert np.array_equal(rg["L"].view(np.uint32), ro["L"].view(np.uint32))
+        assert (sg.n_rays_closest, sg.n_rays_shadow, sg.n_bounces, sg.n_invalid) == (so.n_rays_closest, so.n_rays_shadow, so.n_bounces, so.n_invalid)
+        n = float(lp.n_paths)
+        assert hg[4] == n - sg.n_invalid
+        rmse = float(np.sqrt(np.mean((hg / n - ho / n) ** 2)))
+        assert rmse < 1e-4                           # BASELINE.json's per-range-bin target
+        assert np.allclose(hg, ho, rtol=2e-4, atol=n * 2.0 ** -24 * float(np.abs(ro["L"]).max()) * 4)
+    assert sg.n_rays_closest + sg.n_rays_shadow > 44_000_000
+
+
 def test_elementary_functions_bit_equal(hiplib):
     """The fp32 sin/cos/acos/exp/log/erf/tan specification evaluates to the same bits on the
     device as in the oracle (the oracle's accuracy against libm is checked on the CPU in
