@@ -187,10 +187,9 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 const uint32_t leader = (n_cl + (uint32_t) __popcll(want_mask & below)) * 4u;
                 occluded = (occl_mask >> leader) & 1ull;
                 ++c_shadow;
-                if (!occluded) {                                  // Scene::ray_test == false (scene.cpp:220-224)
-                    s.result += sh.c;
-                    if (lp.iq) s.phase += sh.c_im;
-                }
+                // an occluded sample still contributes mis * throughput * bsdf * 0 (scene.cpp:220-224): c * 0
+                s.result += occluded ? sh.c * 0.f : sh.c;
+                if (lp.iq) s.phase += occluded ? sh.c_im * 0.f : sh.c_im;
                 sh.want = false;
             }
         } else if (want_mask) {
@@ -234,9 +233,9 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                     ++c_shadow;
                 }
             }
-            if (sh.want && !occluded) {                     // Scene::ray_test == false (scene.cpp:220-224)
-                s.result += sh.c;
-                if (lp.iq) s.phase += sh.c_im;
+            if (sh.want) {                                  // occluded: c * 0 (scene.cpp:220-224)
+                s.result += occluded ? sh.c * 0.f : sh.c;
+                if (lp.iq) s.phase += occluded ? sh.c_im * 0.f : sh.c_im;
             }
             sh.want = false;
         } else if (__ballot(trace_closest)) {

@@ -198,10 +198,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                     Hit tmp;
                     bool found;
                     if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
-                        if (!found) {                        // unoccluded: Scene::ray_test == false (scene.cpp:220-224)
-                            s.result += sh.c;
-                            if (lp.iq) s.phase += sh.c_im;
-                        }
+                        // Scene::sample_emitter_direction zeroes the VALUE of an occluded sample (scene.cpp:220-224) and
+                        // the integrator still adds mis * throughput * bsdf * 0: a NaN / inf BSDF value survives that
+                        // product.  c * 0 is that term (+-0 for every finite c).
+                        s.result += found ? sh.c * 0.f : sh.c;
+                        if (lp.iq) s.phase += found ? sh.c_im * 0.f : sh.c_im;
                         shadowing = false;
                     }
                     sh.want = shadowing;
@@ -417,13 +418,18 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
             if (has && node == kNoNode) {
                 if (any) {
                     // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
-                    if (!found) {
+                    // (an occluded sample contributes c * 0, scene.cpp:220-224: only a non-finite c leaves a trace)
+                    const float c = wf.sh2[job];
+                    if (!found || !__builtin_isfinite(c)) {
                         float4 a = wf.sa[job];
-                        a.w += wf.sh2[job];
+                        a.w += found ? c * 0.f : c;
                         wf.sa[job] = a;
-                        if (wf.iq) {                 // BF_MODE_RECEIVE_IQ: imaginary accumulator lives in se.w
+                    }
+                    if (wf.iq) {                     // BF_MODE_RECEIVE_IQ: imaginary accumulator lives in se.w
+                        const float ci = wf.sh3[job];
+                        if (!found || !__builtin_isfinite(ci)) {
                             float4 e = wf.se[job];
-                            e.w += wf.sh3[job];
+                            e.w += found ? ci * 0.f : ci;
                             wf.se[job] = e;
                         }
                     }
