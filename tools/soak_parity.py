@@ -1,0 +1,66 @@
+"""Parity soak: full-size renders of every configuration family against the oracle, ALL per-path records compared
+bit for bit (radiance, path length / time, validity, ray count) plus the counters.  A few minutes on the GPU box
+(16 oracle threads); prints one line per case and exits non-zero on the first mismatch.
+    python tools/soak_parity.py [n_seeds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from beifong_amd import capi, scenes
+from tests.oracle_lib import OracleScene
+from tests import test_gpu_parity as T
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+fails = 0
+
+
+def check(name, sd, lp, flags=(0,)):
+    global fails
+    t = time.time()
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=16)
+    t_o = time.time() - t
+    g = capi.Scene(sd)
+    for fl in flags:
+        lp.flags = fl
+        hg, rg, sg = g.render(lp, records=True)
+        bad = {k: int((rg[k] != ro[k]).sum()) for k in ("n_rays", "valid")}
+        bad.update({k: int((rg[k].view(np.uint32) != ro[k].view(np.uint32)).sum()) for k in ("aux", "L")})
+        ctr = (sg.n_rays_closest, sg.n_rays_shadow, sg.n_bounces, sg.n_invalid) == (so.n_rays_closest, so.n_rays_shadow, so.n_bounces, so.n_invalid)
+        ok = not any(bad.values()) and ctr
+        fails += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} {name:44s} flags {fl} paths {lp.n_paths:9d} rays {sg.n_rays_closest + sg.n_rays_shadow:10d} "
+              f"invalid {sg.n_invalid:3d} nan {int(np.isnan(ro['L']).sum()):3d} mismatches {bad} counters {ctr}  oracle {t_o:5.1f} s", flush=True)
+        if not ok:
+            i = np.flatnonzero(rg["L"].view(np.uint32) != ro["L"].view(np.uint32))[:3]
+            print("     first:", i, rg[i], ro[i], flush=True)
+    lp.flags = 0
+    g.close()
+
+
+for seed in range(n_seeds):
+    sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=100 + seed)
+    check(f"C2 range bus seed {100 + seed}", sd, lp)
+    sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 22, seed=200 + seed)
+    lp.mode, lp.bin_width, lp.bins = capi.BF_MODE_TIME, 1e-9, 128
+    check(f"C2 time bus seed {200 + seed}", sd, lp, flags=(0, capi.BF_FLAG_MEGAKERNEL))
+    sd, lp = scenes.car_radar(n_tris=1_000_000, n_paths=1 << 22, seed=300 + seed)
+    check(f"C3 car seed {300 + seed}", sd, lp)
+    sd, lp = scenes.multi_mesh_radar(n_paths=1 << 22, seed=400 + seed)
+    check(f"C4 multi-mesh seed {400 + seed}", sd, lp)
+    for tx, rx, sig in (("wigner", "omnidirectional", "pulse"), ("wigner", "wigner", "linfmcw"), ("area", "omnidirectional", "pulse")):
+        sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 22, t_bins=1024, dr=0.03, seed=500 + seed, transmitter=tx, receiver=rx,
+                                    signaltype=sig)
+        check(f"C2-recv {tx}/{rx}/{sig} seed {500 + seed}", sd, lp)
+    sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 22, t_bins=256, dr=0.1, seed=600 + seed)
+    lp.phase_bins = 16
+    check(f"C2-recv phase AOVs seed {600 + seed}", sd, lp)
+    sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 22, t_bins=1024, dr=0.03, seed=700 + seed, lambda_band_nm=(8.6e6 * 0.999, 8.6e6 * 1.001))
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    check(f"C5 pulse I/Q seed {700 + seed}", sd, lp, flags=(0, capi.BF_FLAG_MEGAKERNEL))
+    sd, lp = scenes.phased_receive(n_tris=100_000, n_paths=1 << 21, steer_deg=(10.0, 0.0, 0.0))
+    lp.seed = 800 + seed
+    check(f"phased tx/rx seed {800 + seed}", sd, lp)
+    sd, lp = T._zoo_scene(two_emitters=True, uv=True)
+    lp.n_paths, lp.seed = 1 << 22, 900 + seed
+    check(f"zoo (uv, two emitters) seed {900 + seed}", sd, lp)
+print("FAILED" if fails else "all cases bit-exact")
+sys.exit(1 if fails else 0)
