@@ -36,6 +36,22 @@ def check(name, sd, lp, flags=(0,)):
     g.close()
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "fuzz":
+    # the random scenes of tests/test_gpu_parity.py::_fuzz_scene at 2^21 paths each
+    n = 1 << 21
+    for seed in range(n_seeds):
+        for receive in (False, True):
+            sd, lp = T._fuzz_scene(seed, receive=receive)
+            if lp.spp:
+                lp.spp = n // (lp.film_width * lp.film_height)
+                lp.n_paths = lp.spp * lp.film_width * lp.film_height
+            else:
+                lp.n_paths = n
+            check(f"fuzz {'receive' if receive else 'render'} scene {seed} mode {lp.mode} depth {lp.max_depth} rr {lp.rr_depth}", sd, lp,
+                  flags=(0, capi.BF_FLAG_MEGAKERNEL))
+    print("FAILED" if fails else "all cases bit-exact")
+    sys.exit(1 if fails else 0)
+
 for seed in range(n_seeds):
     sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=100 + seed)
     check(f"C2 range bus seed {100 + seed}", sd, lp)
