@@ -371,7 +371,7 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
     std::memset(&sen, 0, sizeof(sen));
     sen.type = desc->sensor.type;
     sen.rect = -1;
-    if (desc->sensor.type == BF_SENSOR_FLUXMETER || desc->sensor.type == BF_RECEIVER_OMNI ||
+    if (desc->sensor.type == BF_SENSOR_FLUXMETER || desc->sensor.type == BF_SENSOR_IRRADIANCEMETER || desc->sensor.type == BF_RECEIVER_OMNI ||
         desc->sensor.type == BF_RECEIVER_WIGNER || desc->sensor.type == BF_RECEIVER_PHASED) {
         int32_t sh = desc->sensor.shape;
         if (sh < 0 || sh >= (int32_t) desc->n_shapes || desc->shapes[sh].type != BF_SHAPE_RECTANGLE) {

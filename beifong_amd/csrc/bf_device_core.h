@@ -802,7 +802,7 @@ BF_DEV void srgb_to_xyz_grey(float l, float &X, float &Y, float &Z) {
 BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, float ay, V3 &o, V3 &d, float &mint,
                                float &maxt) {
     const DSensor &s = *sc.sensor;
-    if (s.type == BF_SENSOR_FLUXMETER) {
+    if (s.type == BF_SENSOR_FLUXMETER || s.type == BF_SENSOR_IRRADIANCEMETER) {
         const DRect &rc = sc.rects[s.rect];
         o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
         V3 local = square_to_cosine_hemisphere(ax, ay);

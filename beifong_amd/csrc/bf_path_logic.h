@@ -670,7 +670,11 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         rec_aux = lp.iq ? a1 : s.t_rx - se.adc_sampling_start;
     } else {
         const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
-        const float sensor_w = sc.sensor->type == BF_SENSOR_FLUXMETER ? 1.f * kPi : 1.f;   // fluxmeter.cpp:84, perspective.cpp:198
+        // ray weight: fluxmeter.cpp:84 (wav_weight * pi), irradiancemeter.cpp:82 (wav_weight * pi / surface_area),
+        // perspective.cpp:198 (wav_weight)
+        float sensor_w = 1.f;
+        if (sc.sensor->type == BF_SENSOR_FLUXMETER) sensor_w = 1.f * kPi;
+        if (sc.sensor->type == BF_SENSOR_IRRADIANCEMETER) sensor_w = 1.f * kPi / sc.rects[sc.sensor->rect].area;
         float L = sensor_w * s.result;                        // integrator.cpp:286
         float X, Y, Z;
         if (lp.color_mode == BF_COLOR_RGB)

@@ -304,6 +304,11 @@ class SceneDesc:
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_FLUXMETER, shape
         self.shapes[shape].is_sensor = 1
 
+    def set_irradiancemeter(self, shape):
+        """irradiancemeter.cpp: the flux meter's rays, weighted by pi / surface_area."""
+        self.sensor.type, self.sensor.shape = capi.BF_SENSOR_IRRADIANCEMETER, shape
+        self.shapes[shape].is_sensor = 1
+
     def set_perspective(self, to_world, fov=45.0, near_clip=0.01, far_clip=10000.0, film=(1, 1)):
         """film = (width, height) in pixels; fov is the horizontal field of view (fov_axis "x")."""
         s = self.sensor

@@ -134,7 +134,9 @@ enum {
     BF_SENSOR_PERSPECTIVE = 1,   /* src/sensors/perspective.cpp:95-199       */
     BF_RECEIVER_OMNI = 2,        /* src/receivers/omnidirectional.cpp:51-139 */
     BF_RECEIVER_WIGNER = 3,      /* src/receivers/wignerreceiver.cpp:43-299  */
-    BF_RECEIVER_PHASED = 4       /* src/receivers/phasedreceiver.cpp         */
+    BF_RECEIVER_PHASED = 4,      /* src/receivers/phasedreceiver.cpp         */
+    BF_SENSOR_IRRADIANCEMETER = 5 /* src/sensors/irradiancemeter.cpp:63-105: the flux
+                                    meter's rays, weight pi / surface_area      */
 };
 
 typedef struct bf_sensor {

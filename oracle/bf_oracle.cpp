@@ -1165,7 +1165,7 @@ static float scene_pdf_emitter_direction(const OScene &sc, int emitter, const Di
 static float sensor_sample_ray(const OScene &sc, float time, float /*wl_sample*/, float px, float py, float ax, float ay,
                                Ray &ray) {
     const bf_sensor &s = sc.sensor;
-    if (s.type == BF_SENSOR_FLUXMETER) {
+    if (s.type == BF_SENSOR_FLUXMETER || s.type == BF_SENSOR_IRRADIANCEMETER) {
         const Rect &rc = sc.rects[sc.shapes[s.shape].rect];
         V3 p = xf_point(rc.to_world, V3{px * 2.f - 1.f, py * 2.f - 1.f, 0.f});
         V3 local = square_to_cosine_hemisphere(ax, ay);
@@ -1175,6 +1175,7 @@ static float sensor_sample_ray(const OScene &sc, float time, float /*wl_sample*/
         ray.mint = kRayEpsilon;
         ray.maxt = kInf;
         ray.time = time;
+        if (s.type == BF_SENSOR_IRRADIANCEMETER) return 1.f * kPi / rc.area;   // irradiancemeter.cpp:82
         return 1.f * kPi;        // wav_weight (RGB: 1) * Pi
     } else {  // perspective
         V3 near_p = xf_point_proj(sc.sample_to_camera, V3{px, py, 0.f});

@@ -322,6 +322,19 @@ def test_occluded_sample_with_non_finite_bsdf_value_poisons_the_path(hiplib):
         assert np.array_equal(hg.reshape(-1, 3)[:, 2], ho.reshape(-1, 3)[:, 2])
 
 
+def test_irradiancemeter_sensor(hiplib):
+    """irradiancemeter.cpp: area-sampled sensor with ray weight pi / surface_area (python_scripts/trans_image.xml)."""
+    sd, lp = scenes.trans_rad(spp=20000)
+    sd.set_irradiancemeter(sd.sensor.shape)
+    sd.finalize()
+    hg, ho, _ = _render_compare(sd, lp)
+    sdf, _ = scenes.trans_rad(spp=20000)
+    hf = capi.Scene(sdf).render(lp)[0]
+    o = OracleScene(sd)
+    area = o.lib.bfo_rect_area(o.handle, sd.sensor.shape)        # trans_rad holds rectangles only: shape index == rectangle index
+    assert hg[1] > 0 and np.isclose(hg[1] / hf[1], 1.0 / area, rtol=1e-3)
+
+
 def test_elementary_functions_bit_equal(hiplib):
     """The fp32 sin/cos/acos/exp/log/erf/tan specification evaluates to the same bits on the
     device as in the oracle (the oracle's accuracy against libm is checked on the CPU in
