@@ -395,6 +395,8 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
             sen.n_velems = desc->sensor.array.n_velems;
             for (int k = 0; k < 3; ++k) sen.wid[k] = desc->sensor.array.elem_dims[k];
         }
+    } else if (desc->sensor.type == BF_SENSOR_RADIANCEMETER) {
+        m34(desc->sensor.to_world, sen.to_world);
     } else if (desc->sensor.type == BF_SENSOR_PERSPECTIVE) {
         m34(desc->sensor.to_world, sen.to_world);
         std::memcpy(sen.sample_to_camera, desc->sensor.sample_to_camera, 16 * sizeof(float));

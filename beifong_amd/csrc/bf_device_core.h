@@ -813,6 +813,12 @@ BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, f
         mint = kRayEpsilon;
         maxt = BF_INF;
         return 1.f * kPi;
+    } else if (s.type == BF_SENSOR_RADIANCEMETER) {     // radiancemeter.cpp:91-108: position and aperture samples unused
+        o = xf_point(s.to_world, mk(0.f, 0.f, 0.f));
+        d = xf_vector(s.to_world, mk(0.f, 0.f, 1.f));
+        mint = kRayEpsilon;
+        maxt = BF_INF;
+        return 1.f;
     } else {
         V3 near_p = xf_point_proj(s.sample_to_camera, mk(px, py, 0.f));
         V3 dl = normalize(near_p);

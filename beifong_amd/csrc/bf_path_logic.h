@@ -395,7 +395,7 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
     } else {
         // render_sample — integrator.cpp:263-283
-        if (sc.sensor->type != BF_SENSOR_PERSPECTIVE) {   // endpoint.h:241, perspective.cpp:130
+        if (sc.sensor->type != BF_SENSOR_PERSPECTIVE && sc.sensor->type != BF_SENSOR_RADIANCEMETER) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
             ax = next_1d(s.rng);
             ay = next_1d(s.rng);
         }

@@ -304,6 +304,13 @@ class SceneDesc:
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_FLUXMETER, shape
         self.shapes[shape].is_sensor = 1
 
+    def set_radiancemeter(self, to_world):
+        """radiancemeter.cpp: one ray from to_world * 0 along to_world * +z (a pencil beam), weight 1."""
+        s = self.sensor
+        s.type, s.shape = capi.BF_SENSOR_RADIANCEMETER, -1
+        s.film_width = s.film_height = 1
+        s.to_world = _m16(to_world.matrix)
+
     def set_irradiancemeter(self, shape):
         """irradiancemeter.cpp: the flux meter's rays, weighted by pi / surface_area."""
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_IRRADIANCEMETER, shape

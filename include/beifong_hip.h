@@ -135,8 +135,10 @@ enum {
     BF_RECEIVER_OMNI = 2,        /* src/receivers/omnidirectional.cpp:51-139 */
     BF_RECEIVER_WIGNER = 3,      /* src/receivers/wignerreceiver.cpp:43-299  */
     BF_RECEIVER_PHASED = 4,      /* src/receivers/phasedreceiver.cpp         */
-    BF_SENSOR_IRRADIANCEMETER = 5 /* src/sensors/irradiancemeter.cpp:63-105: the flux
-                                    meter's rays, weight pi / surface_area      */
+    BF_SENSOR_IRRADIANCEMETER = 5, /* src/sensors/irradiancemeter.cpp:63-105: the flux
+                                     meter's rays, weight pi / surface_area      */
+    BF_SENSOR_RADIANCEMETER = 6   /* src/sensors/radiancemeter.cpp:49-114: ONE ray from
+                                    to_world * origin along to_world * +z, weight 1 */
 };
 
 typedef struct bf_sensor {

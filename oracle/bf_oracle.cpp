@@ -1177,6 +1177,13 @@ static float sensor_sample_ray(const OScene &sc, float time, float /*wl_sample*/
         ray.time = time;
         if (s.type == BF_SENSOR_IRRADIANCEMETER) return 1.f * kPi / rc.area;   // irradiancemeter.cpp:82
         return 1.f * kPi;        // wav_weight (RGB: 1) * Pi
+    } else if (s.type == BF_SENSOR_RADIANCEMETER) {   // RadianceMeter::sample_ray — src/sensors/radiancemeter.cpp:91-108
+        ray.o = xf_point(sc.cam_to_world, V3{0.f, 0.f, 0.f});
+        ray.d = xf_vector(sc.cam_to_world, V3{0.f, 0.f, 1.f});
+        ray.mint = kRayEpsilon;
+        ray.maxt = kInf;
+        ray.time = time;
+        return 1.f;
     } else {  // perspective
         V3 near_p = xf_point_proj(sc.sample_to_camera, V3{px, py, 0.f});
         V3 d = normalize(near_p);
@@ -1191,7 +1198,7 @@ static float sensor_sample_ray(const OScene &sc, float time, float /*wl_sample*/
 }
 inline bool sensor_needs_aperture_sample(const bf_sensor &s) {
     // endpoint.h:241 default true; perspective.cpp:130 sets false
-    return s.type != BF_SENSOR_PERSPECTIVE;
+    return s.type != BF_SENSOR_PERSPECTIVE && s.type != BF_SENSOR_RADIANCEMETER;   // radiancemeter.cpp:86-87
 }
 
 // ---------------------------------------------------------------------------
@@ -1952,6 +1959,7 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
         }
         sc.emitters.push_back(e);
     }
+    if (d->sensor.type == BF_SENSOR_RADIANCEMETER) std::memcpy(sc.cam_to_world.m, d->sensor.to_world, sizeof(float) * 16);
     if (d->sensor.type == BF_SENSOR_PERSPECTIVE) {
         std::memcpy(sc.cam_to_world.m, d->sensor.to_world, sizeof(float) * 16);
         // m_sample_to_camera (perspective.cpp:104-109) is supplied by the host

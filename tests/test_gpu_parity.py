@@ -335,6 +335,15 @@ def test_irradiancemeter_sensor(hiplib):
     assert hg[1] > 0 and np.isclose(hg[1] / hf[1], 1.0 / area, rtol=1e-3)
 
 
+def test_radiancemeter_sensor(hiplib):
+    """radiancemeter.cpp: every path starts with the same ray (a pencil beam at the bus); no aperture sample is drawn."""
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=20000)
+    sd.set_radiancemeter(Transform4f.look_at([0, 0, 0.3], [10.0, 3.0, 1.5], [0, 0, 1]))
+    sd.finalize()
+    hg, ho, sg = _render_compare(sd, lp)
+    assert hg[3] == lp.n_paths                      # the beam hits the bus every time
+
+
 def test_elementary_functions_bit_equal(hiplib):
     """The fp32 sin/cos/acos/exp/log/erf/tan specification evaluates to the same bits on the
     device as in the oracle (the oracle's accuracy against libm is checked on the CPU in

@@ -75,7 +75,7 @@ def test_every_plugin_exports_the_reference_plugin_abi(mitsuba):
         names.add(n)
     for need in ("path", "pathlength", "range", "pathtime", "time", "pathtimefrequency", "rectangle", "obj", "ply", "diffuse",
                  "twosided", "roughconductor", "spot", "area", "areatransmitter", "wignertransmitter", "fluxmeter",
-                 "irradiancemeter", "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent", "phase",
+                 "irradiancemeter", "radiancemeter", "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent", "phase",
                  "phasedtransmitter", "phasedreceiver"):
         assert need in names, need
 
@@ -536,3 +536,23 @@ def test_irradiancemeter_is_the_flux_meter_per_unit_area(mitsuba):
     assert np.array_equal(rf["n_rays"], ri["n_rays"]) and np.array_equal(rf["aux"], ri["aux"])
     assert np.allclose(ri["L"], rf["L"] / area, rtol=1e-5) and rf["L"].max() > 0
     assert np.allclose(hi[:3], hf[:3] / area, rtol=1e-4) and np.array_equal(hi[3:], hf[3:])
+
+
+def test_radiancemeter_is_a_pencil_beam(mitsuba):
+    """src/sensors/radiancemeter.cpp:49-114 (src/sensors/tests/test_radiancemeter.py): every sample is the one ray
+    origin + t * direction, weight 1, whatever the film / aperture samples are; neither origin-only nor a non-1x1 film is accepted."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    xml = TRANS_RAD_LIKE.replace('<sensor type="fluxmeter">', '<sensor type="radiancemeter"><point name="origin" x="0" y="0" z="0.5"/>'
+                                 '<vector name="direction" x="0" y="-2" z="0"/>')
+    # the sensor is a child of the rx rectangle in that scene: lift it to scene level
+    scene = load_string(xml, spp=500)
+    sensor = scene.sensors()[0]
+    o = OracleScene(scene.flat_desc(sensor))
+    for sample in ((0.1, 0.9), (0.5, 0.5), (0.99, 0.0)):
+        r = o.sensor_sample_ray(*sample)
+        assert np.allclose(r["o"], [0, 0, 0.5], atol=1e-6) and np.allclose(r["d"], [0, -1, 0], atol=1e-6) and r["weight"] == 1.0
+    lp, h, rec = _oracle_on_host_scene(scene, sensor)
+    assert h[4] == 500 and np.all(rec["valid"] == 1)            # the target plate 4 m down the -y axis is hit every time
+    with pytest.raises(HostError, match="both values"):
+        load_string(xml.replace('<vector name="direction" x="0" y="-2" z="0"/>', ''), spp=4)
