@@ -52,6 +52,32 @@ if len(sys.argv) > 2 and sys.argv[2] == "fuzz":
     print("FAILED" if fails else "all cases bit-exact")
     sys.exit(1 if fails else 0)
 
+if len(sys.argv) > 2 and sys.argv[2] == "misc":
+    # corners of the pipeline at scale: multi-pixel films, a pool much smaller than the launch (run with BF_WF_POOL=262144
+    # to exercise regeneration into freed slots), depth / roulette limits, sharded launches, moved geometry
+    from beifong_amd.scenedesc import Transform4f as TF
+    for seed in range(n_seeds):
+        sd, _ = T._zoo_scene(two_emitters=True, uv=True)
+        film = (96, 64)
+        sd.set_perspective(TF.translate([0, 0, 0.3]) * TF.rotate([1, 0, 0], 90) * TF.rotate([0, 1, 0], 90), fov=60.0, near_clip=0.1,
+                           far_clip=100.0, film=film)
+        sd.finalize()
+        for mode, bins, bw in ((capi.BF_MODE_RANGE, 128, 0.1), (capi.BF_MODE_TIME, 40, 1e-9), (capi.BF_MODE_PATH, 0, 0.0)):
+            lp = capi.make_launch(mode, film[0] * film[1] * 512, seed=1000 + seed, bins=bins, bin_width=bw, film=film, spp=512)
+            check(f"film 96x64 mode {mode} seed {1000 + seed}", sd, lp, flags=(0, capi.BF_FLAG_MEGAKERNEL))
+        for md, rr in ((1, 5), (2, 1), (3, 50), (12, 3), (-1, 1), (-1, 200)):
+            sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 22, seed=1100 + seed)
+            lp.max_depth, lp.rr_depth = md, rr
+            check(f"C2 max_depth {md} rr_depth {rr} seed {1100 + seed}", sd, lp)
+        sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=(1 << 22) + 12345, seed=1200 + seed)
+        lp.path_offset = (1 << 33) + 7                       # a shard far into a > 2^32-path job
+        check(f"C2 shard at path 2^33 seed {1200 + seed}", sd, lp)
+        sd, lp = scenes.trans_rad(spp=1 << 22)
+        lp.seed = 1300 + seed
+        check(f"C1 trans_rad fluxmeter + spot seed {1300 + seed}", sd, lp, flags=(0, capi.BF_FLAG_MEGAKERNEL))
+    print("FAILED" if fails else "all cases bit-exact")
+    sys.exit(1 if fails else 0)
+
 for seed in range(n_seeds):
     sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=100 + seed)
     check(f"C2 range bus seed {100 + seed}", sd, lp)
