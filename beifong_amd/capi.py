@@ -15,7 +15,7 @@ BF_OK, BF_ERR_INVALID, BF_ERR_DEVICE, BF_ERR_NOMEM, BF_ERR_UNSUPPORTED = range(5
 BF_BSDF_DIFFUSE, BF_BSDF_ROUGHCONDUCTOR, BF_BSDF_NULL = range(3)
 BF_MF_BECKMANN, BF_MF_GGX = range(2)
 BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
-BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED = range(5)
+BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED, BF_EMITTER_POINT = range(6)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED, BF_SENSOR_IRRADIANCEMETER, BF_SENSOR_RADIANCEMETER = range(7)
 BF_VELEM_FLOATS = 32

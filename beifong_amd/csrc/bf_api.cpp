@@ -329,7 +329,9 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         de.type = e.type;
         de.rect = -1;
         de.radiance = e.radiance;
-        if (e.type == BF_EMITTER_SPOT) {
+        if (e.type == BF_EMITTER_POINT) {
+            m34(e.to_world, de.to_world);
+        } else if (e.type == BF_EMITTER_SPOT) {
             m34(e.to_world, de.to_world);
             m34(e.to_object, de.to_object);
             // SpotLight ctor — src/emitters/spot.cpp:83-93
@@ -903,7 +905,8 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     } else {
         if (is_rx) return fail(BF_ERR_INVALID, "render modes need a sensor (fluxmeter / perspective), not a receiver");
         for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
-            if (scene->emitter_types[i] != BF_EMITTER_SPOT && scene->emitter_types[i] != BF_EMITTER_AREA)
+            if (scene->emitter_types[i] != BF_EMITTER_SPOT && scene->emitter_types[i] != BF_EMITTER_AREA &&
+                scene->emitter_types[i] != BF_EMITTER_POINT)
                 return fail(BF_ERR_INVALID, "render modes: emitter %u is a transmitter (use receive mode)", i);
     }
     if (launch->mode > BF_MODE_RECEIVE_IQ) return fail(BF_ERR_INVALID, "unknown mode %u", launch->mode);

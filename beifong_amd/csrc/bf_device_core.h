@@ -744,7 +744,7 @@ BF_DEV float spot_falloff(const DEmitter &e, V3 d) {
 }
 
 BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
-    if (e.type == BF_EMITTER_SPOT) {
+    if (e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT) {
         V3 p = mk(e.to_world[3], e.to_world[7], e.to_world[11]);
         ds.pdf = 1.f;
         ds.delta = true;
@@ -752,6 +752,7 @@ BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 re
         ds.dist = norm(ds.d);
         float inv_dist = rcp(ds.dist);
         ds.d = ds.d * inv_dist;
+        if (e.type == BF_EMITTER_POINT) return e.radiance * sqr(inv_dist);      // point.cpp:100-103
         V3 local_d = xf_vector(e.to_object, -ds.d);
         return spot_falloff(e, local_d) * (inv_dist * inv_dist);
     } else {
@@ -774,7 +775,7 @@ BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 re
 
 // pdf_emitter_direction for the hit `p_hit` (normal n_hit) seen from `p_ref`
 BF_DEV float emitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
-    if (e.type == BF_EMITTER_SPOT) return 0.f;
+    if (e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT) return 0.f;
     const DRect &rc = sc.rects[e.rect];
     V3 d = p_hit - p_ref;
     float dist = norm(d);

@@ -505,7 +505,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         if (receive)
             ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
         else
-            ev = (e.type == BF_EMITTER_SPOT) ? 0.f : ((si.wi.z > 0.f) ? e.radiance : 0.f);
+            ev = (e.type == BF_EMITTER_AREA) ? ((si.wi.z > 0.f) ? e.radiance : 0.f) : 0.f;
         float contrib = s.emission_weight * s.throughput * ev;
         if (lp.iq) {
             // optical length receiver -> ... -> this transmitter point: c * (t_rx - retarded time)

@@ -202,6 +202,15 @@ class SceneDesc:
         self.emitters.append(e)
         return len(self.emitters) - 1
 
+    def add_point(self, position, intensity=1.0):
+        """point.cpp: isotropic point light at `position`."""
+        e = capi.bf_emitter()
+        e.type, e.shape, e.radiance = capi.BF_EMITTER_POINT, -1, intensity
+        t = Transform4f.translate(list(position))
+        e.to_world, e.to_object = _m16(t.matrix), _m16(t.inv)
+        self.emitters.append(e)
+        return len(self.emitters) - 1
+
     def add_area_emitter(self, shape, radiance=1.0):
         e = capi.bf_emitter()
         e.type, e.shape, e.radiance = capi.BF_EMITTER_AREA, shape, radiance

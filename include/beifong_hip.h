@@ -96,7 +96,9 @@ enum {
     BF_EMITTER_AREA = 1,         /* src/emitters/area.cpp:64-150             */
     BF_TRANSMITTER_AREA = 2,     /* src/transmitters/areatransmitter.cpp     */
     BF_TRANSMITTER_WIGNER = 3,   /* src/transmitters/wignertransmitter.cpp   */
-    BF_TRANSMITTER_PHASED = 4    /* src/transmitters/phasedtransmitter.cpp   */
+    BF_TRANSMITTER_PHASED = 4,   /* src/transmitters/phasedtransmitter.cpp   */
+    BF_EMITTER_POINT = 5         /* src/emitters/point.cpp:60-118: position = to_world
+                                    translation, `radiance` = intensity       */
 };
 enum { BF_SIGNAL_CW = 0, BF_SIGNAL_PULSE = 1, BF_SIGNAL_LINFMCW = 2 };
 

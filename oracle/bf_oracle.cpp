@@ -1080,7 +1080,7 @@ static DirectionSample rect_sample_direction(const Rect &rc, V3 ref_p, float tim
 
 // Emitter::sample_direction: spot.cpp:137-160, area.cpp:117-165
 static float emitter_sample_direction(const OScene &sc, const Emitter &e, const SI &ref, float sx, float sy, DirectionSample &ds) {
-    if (e.d.type == BF_EMITTER_SPOT) {
+    if (e.d.type == BF_EMITTER_SPOT || e.d.type == BF_EMITTER_POINT) {
         ds = DirectionSample();
         ds.p = {e.to_world.m[3], e.to_world.m[7], e.to_world.m[11]};
         ds.pdf = 1.f;
@@ -1090,6 +1090,7 @@ static float emitter_sample_direction(const OScene &sc, const Emitter &e, const 
         ds.dist = norm(ds.d);
         float inv_dist = rcp(ds.dist);
         ds.d = ds.d * inv_dist;
+        if (e.d.type == BF_EMITTER_POINT) return e.d.radiance * sqr(inv_dist);   // PointLight::sample_direction — point.cpp:80-106
         V3 local_d = xf_vector(e.to_object, -ds.d);
         float falloff = spot_falloff(e, local_d);
         return falloff * (inv_dist * inv_dist);
@@ -1103,7 +1104,7 @@ static float emitter_sample_direction(const OScene &sc, const Emitter &e, const 
 }
 // Emitter::pdf_direction: spot.cpp:162-164, area.cpp:167-186 + shape.cpp:344-356
 static float emitter_pdf_direction(const OScene &sc, const Emitter &e, const DirectionSample &ds) {
-    if (e.d.type == BF_EMITTER_SPOT) return 0.f;
+    if (e.d.type == BF_EMITTER_SPOT || e.d.type == BF_EMITTER_POINT) return 0.f;
     const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
     float dp = dot(ds.d, ds.n);
     bool active = dp < 0.f;
@@ -1113,7 +1114,7 @@ static float emitter_pdf_direction(const OScene &sc, const Emitter &e, const Dir
 }
 // Emitter::eval: spot.cpp:166, area.cpp:66-74
 static float emitter_eval(const Emitter &e, const SI &si) {
-    if (e.d.type == BF_EMITTER_SPOT) return 0.f;
+    if (e.d.type == BF_EMITTER_SPOT || e.d.type == BF_EMITTER_POINT) return 0.f;
     return (si.wi.z > 0.f) ? e.d.radiance : 0.f;
 }
 

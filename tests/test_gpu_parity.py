@@ -344,6 +344,16 @@ def test_radiancemeter_sensor(hiplib):
     assert hg[3] == lp.n_paths                      # the beam hits the bus every time
 
 
+def test_point_light(hiplib):
+    """point.cpp: an isotropic point light next to the zoo's other emitters (uniform emitter selection over three kinds)."""
+    sd, lp = _zoo_scene(two_emitters=True)
+    sd.add_point([1.0, -2.0, 3.0], intensity=40.0)
+    sd.finalize()
+    hg, ho, _ = _render_compare(sd, lp)
+    sd0, _ = _zoo_scene(two_emitters=True)
+    assert not np.allclose(capi.Scene(sd0).render(lp)[0], hg)
+
+
 def test_elementary_functions_bit_equal(hiplib):
     """The fp32 sin/cos/acos/exp/log/erf/tan specification evaluates to the same bits on the
     device as in the oracle (the oracle's accuracy against libm is checked on the CPU in

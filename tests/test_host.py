@@ -74,7 +74,7 @@ def test_every_plugin_exports_the_reference_plugin_abi(mitsuba):
         assert len(lib.plugin_descr()) > 0
         names.add(n)
     for need in ("path", "pathlength", "range", "pathtime", "time", "pathtimefrequency", "rectangle", "obj", "ply", "diffuse",
-                 "twosided", "roughconductor", "spot", "area", "areatransmitter", "wignertransmitter", "fluxmeter",
+                 "twosided", "roughconductor", "spot", "point", "area", "areatransmitter", "wignertransmitter", "fluxmeter",
                  "irradiancemeter", "radiancemeter", "perspective", "omnidirectional", "wignerreceiver", "hdrfilm", "hdradc", "box", "independent", "phase",
                  "phasedtransmitter", "phasedreceiver"):
         assert need in names, need

@@ -475,3 +475,20 @@ def test_area_light_sample_direction_known_answers():
             assert np.allclose(r["d"], d, atol=1e-6) and np.isclose(r["dist"], dist, rtol=1e-6) and not r["delta"]
             assert np.isclose(r["pdf"], pdf, rtol=1e-5) and np.isclose(r["pdf_direction"], r["pdf"], rtol=1e-6)
             assert np.isclose(r["spec"], 7.0 / pdf, rtol=1e-5)
+
+
+def test_point_light_sample_direction_known_answers():
+    """src/emitters/tests/test_point.py:64-95: delta sample towards the light, pdf 1, value = intensity / dist^2."""
+    T = Transform4f
+    sd = SceneDesc()
+    sd.add_rectangle(T.scale([1, 1, 1]), sd.add_diffuse(0.5))
+    sd.add_point([10, -1, 2], intensity=3.0)
+    sd.set_perspective(T.translate([0, 0, 5]), fov=45.0)
+    sd.finalize()
+    it_p = np.array([0.0, -2.0, 4.5])
+    r = OracleScene(sd).emitter_sample_direction(0, it_p)
+    d = np.array([10, -1, 2.0]) - it_p
+    dist = np.linalg.norm(d)
+    assert r["pdf"] == 1.0 and r["delta"] and r["pdf_direction"] == 0.0
+    assert np.allclose(r["d"], d / dist, atol=1e-6) and np.isclose(r["dist"], dist, rtol=1e-6)
+    assert np.isclose(r["spec"], 3.0 / dist ** 2, rtol=1e-6)
