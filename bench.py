@@ -104,7 +104,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # algorithmic bytes per ray: V_n * 64 + V_t * 48 + 48, with
+    # algorithmic bytes per ray: V_n * S_n + V_t * 48 + 48 (S_n = 128-byte four-wide nodes), with
     # V_n / V_t counted by the instrumented kernels on exactly this workload.
     # wf_trace only sees the rays that enter the mesh BVH (wf_shade resolves the
     # others against the rectangles + the BVH root boxes), so its roofline uses
