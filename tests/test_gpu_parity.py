@@ -886,7 +886,11 @@ def _fuzz_scene(seed, receive=False):
         sd.add_mesh(v, f, material(), normals=n, texcoords=_planar_uv(v) if rng.random() < 0.4 else None)
     if receive:
         return _fuzz_receive_endpoints(sd, rng)
-    em = int(rng.integers(3))
+    em = int(rng.integers(4))
+    if em == 3:
+        sd.add_point(list(rng.uniform(-3, 3, 2)) + [float(rng.uniform(1.5, 4))], intensity=float(rng.uniform(5, 50)))
+        if rng.random() < 0.5:
+            em = 1                                     # ... plus an area light
     if em in (0, 2):
         sd.add_spot(T.look_at(list(rng.uniform(-3, 3, 2)) + [float(rng.uniform(2, 4))], list(rng.uniform(-1, 1, 3)), [0, 0, 1]),
                     intensity=float(rng.uniform(5, 50)), cutoff_angle=float(rng.uniform(15, 60)), beam_width=float(rng.uniform(5, 14)))
@@ -895,10 +899,16 @@ def _fuzz_scene(seed, receive=False):
                              T.scale([float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0)), 1]), sd.add_diffuse(0.0))
         sd.add_area_emitter(r, float(rng.uniform(1, 40)))
     film, spp = None, 0
-    if rng.random() < 0.5:
+    kind = rng.random()
+    if kind < 0.4:
         rx = sd.add_rectangle(T.translate([0.2, -0.3, 1.0]) * T.rotate([1, 0, 0], float(rng.uniform(90, 270))) * T.scale([0.05, 0.08, 1]),
                               sd.add_diffuse(0.5))
-        sd.set_fluxmeter(rx)
+        if rng.random() < 0.5:
+            sd.set_fluxmeter(rx)
+        else:
+            sd.set_irradiancemeter(rx)
+    elif kind < 0.5:
+        sd.set_radiancemeter(T.look_at(list(rng.uniform(-3, 3, 2)) + [float(rng.uniform(0.5, 3))], list(rng.uniform(-1, 1, 2)) + [0.5], [0, 0, 1]))
     else:
         if rng.random() < 0.5:
             film = (int(rng.integers(1, 7)), int(rng.integers(1, 5)))
