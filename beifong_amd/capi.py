@@ -18,6 +18,7 @@ BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
 BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED, BF_EMITTER_POINT = range(6)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED, BF_SENSOR_IRRADIANCEMETER, BF_SENSOR_RADIANCEMETER = range(7)
+BF_ABI_VERSION = 1          # include/beifong_hip.h: BF_ABI_VERSION
 BF_VELEM_FLOATS = 32
 BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
@@ -137,6 +138,8 @@ def load_library(path=None):
     lib = C.CDLL(p)
     vp = C.c_void_p
     lib.bf_version.restype = C.c_int
+    if lib.bf_version() != BF_ABI_VERSION:
+        raise BeifongError(f"{p}: ABI version {lib.bf_version()}, this binding is for {BF_ABI_VERSION} (include/beifong_hip.h) — rebuild")
     lib.bf_last_error.restype = C.c_char_p
     lib.bf_device_count.restype = C.c_int
     lib.bf_set_device.argtypes = [C.c_int]
