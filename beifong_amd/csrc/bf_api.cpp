@@ -21,7 +21,8 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
                                         hipStream_t stream);
 extern "C" float bfk_host_cos(float x);
 extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
-                                           float4 *nodes, uint32_t n_nodes, const float *d, hipStream_t stream);
+                                           float4 *nodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
+                                           uint32_t n_wchildren, const float *d, hipStream_t stream);
 extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y);
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
                                        uint32_t *out_prim, uint32_t *out_shape, float *out_uv, uint8_t *out_hit,
@@ -107,7 +108,7 @@ struct bf_scene {
     uint32_t n_materials = 0;
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
-    float4 *tris0 = nullptr, *nodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
+    float4 *tris0 = nullptr, *nodes0 = nullptr, *wnodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
     std::vector<bfd::DShape> shapes_host;         // as created: mesh triangles carry their shape's material / emitter index
     std::vector<float *> array_dev;
@@ -183,6 +184,7 @@ bf_status bf_scene_destroy(bf_scene *s) {
     return BF_OK;
 }
 
+static int32_t bfd_no_node() { return INT32_MIN; }
 static_assert(bf::kTopNodes == bfd::kTopNodes, "the builder's breadth-first prefix is what wf_trace caches");
 
 namespace {
@@ -468,6 +470,11 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     bf::build_bvh(btris, bvh, origin_scale);
     bf::BVH4 bvh4;
     bf::collapse_bvh4(bvh, bvh4);
+    // sixteen-wide collapse of the same tree for the tail kernel's row traversal (bf_bvh.h: Node16)
+    bf::BVH16 bvh16;
+    bf::collapse_bvh16(bvh, bvh16);
+    const bool use_wide = !btris.empty() && bvh16.stack_need <= (uint32_t) bfd::kWideStack && btris.size() < (1u << 27) &&
+                          !getenv("BF_NO_WIDE_BVH");
     for (int k = 0; k < 3 && !btris.empty(); ++k)
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
@@ -507,6 +514,12 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     }
     std::vector<float4> node_data(8 * bvh4.nodes.size());
     if (!bvh4.nodes.empty()) std::memcpy(node_data.data(), bvh4.nodes.data(), bvh4.nodes.size() * sizeof(bf::Node4));
+    std::vector<float4> wnode_data;
+    if (use_wide) {
+        // one spare node of padding: a row's speculative third load of a child record may touch the next 16 bytes
+        wnode_data.assign(32 * (bvh16.nodes.size() + 1), make_float4(0, 0, 0, 0));
+        if (!bvh16.nodes.empty()) std::memcpy(wnode_data.data(), bvh16.nodes.data(), bvh16.nodes.size() * sizeof(bf::Node16));
+    }
     std::vector<bf_material> mats(desc->materials, desc->materials + desc->n_materials);
 
     (void) hipGetDevice(&sc->device);
@@ -538,6 +551,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         return st;                                                  \
     }
     UP(node_data, nodes);
+    UP(wnode_data, wnodes);
     UP(tri_data, tris);
     UP(nrm_data, normals);
     UP(uv_data, uvs);
@@ -556,6 +570,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     for (const auto &e : emitters) sc->emitter_types.push_back(e.type);
     sc->d.n_nodes = (uint32_t) bvh4.nodes.size();
     sc->d.root = bvh4.root_child;
+    sc->d.wroot = use_wide ? bvh16.root_child : bfd_no_node();
+    sc->d.n_wnodes = use_wide ? (uint32_t) bvh16.nodes.size() : 0u;
     sc->d.c = desc->physics.c;
     sc->d.lambda_min = desc->physics.lambda_min_nm;
     sc->d.lambda_max = desc->physics.lambda_max_nm;
@@ -637,6 +653,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
     if (scene->d.n_tris == 0) return BF_OK;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const size_t tri_bytes = (size_t) scene->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
+    const size_t wnode_bytes = scene->d.wnodes ? (size_t) scene->d.n_wnodes * 32 * sizeof(float4) : 0;
     if (!scene->tris0) {
         // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
         void *p = nullptr;
@@ -650,9 +667,16 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
             scene->nodes0 = (float4 *) p;
             HIP_TRY(hipMemcpyAsync(scene->nodes0, scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
         }
+        if (wnode_bytes) {
+            HIP_TRY(hipMalloc(&p, wnode_bytes));
+            scene->owned.push_back(p);
+            scene->wnodes0 = (float4 *) p;
+            HIP_TRY(hipMemcpyAsync(scene->wnodes0, scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
+        }
     }
     HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
-                                 const_cast<float4 *>(scene->d.nodes), scene->d.n_nodes, offset, stream));
+                                 const_cast<float4 *>(scene->d.nodes), scene->d.n_nodes, scene->wnodes0,
+                                 const_cast<float4 *>(scene->d.wnodes), wnode_bytes ? scene->d.n_wnodes * 16u : 0u, offset, stream));
     return BF_OK;
 }
 
@@ -735,6 +759,8 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         const char *e3 = getenv("BF_SHADE_CHAIN");
         wf.shade_chain = std::max(1, e3 ? atoi(e3) : (int) bfd::kShadeChain);
         wf.iq = lp.iq;
+        const char *e4 = getenv("BF_TAIL_ROWJOBS");
+        wf.row_jobs = e4 ? (uint32_t) atoi(e4) : bfd::kTailRowJobs;
     }
     const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce

@@ -369,4 +369,111 @@ void collapse_bvh4(const BVH &in, BVH4 &out) {
     out.nodes.swap(moved);
 }
 
+namespace {
+
+struct Collapser16 {
+    const BVH &in;
+    BVH16 &out;
+    std::vector<uint32_t> first, count;      // triangle range of every binary node's subtree (contiguous by construction)
+
+    void range_of(int32_t ref, uint32_t &f, uint32_t &c) const {
+        if (ref >= 0) {
+            f = first[(size_t) ref];
+            c = count[(size_t) ref];
+        } else {
+            const uint32_t enc = ~(uint32_t) ref;
+            f = enc >> 3;
+            c = (enc & 7u) + 1u;
+        }
+    }
+    void ranges(int32_t node) {
+        const Node &n = in.nodes[(size_t) node];
+        for (int k = 0; k < 2; ++k)
+            if (n.child[k] >= 0) ranges(n.child[k]);
+        uint32_t f0, c0, f1, c1;
+        range_of(n.child[0], f0, c0);
+        range_of(n.child[1], f1, c1);
+        first[(size_t) node] = std::min(f0, f1);
+        count[(size_t) node] = c0 + c1;
+    }
+    bool expandable(const ChildRef &c) const { return c.ref >= 0 && count[(size_t) c.ref] > kWideLeaf; }
+
+    uint32_t emit(int32_t node2, uint32_t self, uint32_t depth) {
+        out.max_depth = std::max(out.max_depth, depth);
+        ChildRef c[16];
+        int n = 2;
+        children_of(in.nodes[(size_t) node2], c);
+        while (n < 16) {
+            int best = -1;
+            float best_area = -1.f;
+            for (int i = 0; i < n; ++i)
+                if (expandable(c[i]) && c[i].area() > best_area) {
+                    best_area = c[i].area();
+                    best = i;
+                }
+            if (best < 0) break;
+            ChildRef g[2];
+            children_of(in.nodes[(size_t) c[best].ref], g);
+            c[best] = g[0];
+            c[n++] = g[1];
+        }
+        int32_t refs[16];
+        uint32_t need_below = 0;
+        for (int i = 0; i < n; ++i) {
+            if (expandable(c[i])) {
+                uint32_t idx = (uint32_t) out.nodes.size();
+                out.nodes.emplace_back();
+                refs[i] = (int32_t) idx;
+                need_below = std::max(need_below, emit(c[i].ref, idx, depth + 1));
+            } else {
+                uint32_t f, k;
+                range_of(c[i].ref, f, k);
+                refs[i] = ~(int32_t) ((f << 4) | (k - 1u));
+            }
+        }
+        Node16 &w = out.nodes[self];
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int i = 0; i < 16; ++i) {
+            const bool used = i < n;
+            float *q = w.c[i];
+            q[0] = used ? c[i].lo[0] : inf;
+            q[1] = used ? c[i].lo[1] : inf;
+            q[2] = used ? c[i].lo[2] : inf;
+            q[3] = used ? c[i].hi[0] : -inf;
+            q[4] = used ? c[i].hi[1] : -inf;
+            q[5] = used ? c[i].hi[2] : -inf;
+            const int32_t r = used ? refs[i] : kEmptyChild;
+            std::memcpy(&q[6], &r, 4);
+            q[7] = 0.f;
+        }
+        return (uint32_t) n + need_below;
+    }
+};
+
+}  // namespace
+
+void collapse_bvh16(const BVH &in, BVH16 &out) {
+    out.nodes.clear();
+    out.root_child = kEmptyChild;
+    out.stack_need = 0;
+    out.max_depth = 0;
+    if (in.order.empty()) return;
+    if (in.nodes.empty() || in.root_child < 0) {
+        // a single binary leaf (<= kMaxLeaf triangles)
+        const uint32_t enc = ~(uint32_t) in.root_child;
+        out.root_child = ~(int32_t) (((enc >> 3) << 4) | (enc & 7u));
+        return;
+    }
+    Collapser16 c{in, out, std::vector<uint32_t>(in.nodes.size(), 0u), std::vector<uint32_t>(in.nodes.size(), 0u)};
+    c.ranges(in.root_child);
+    if (c.count[(size_t) in.root_child] <= kWideLeaf) {
+        out.root_child = ~(int32_t) ((c.first[(size_t) in.root_child] << 4) | (c.count[(size_t) in.root_child] - 1u));
+        return;
+    }
+    out.nodes.reserve(in.nodes.size() / 8 + 1);
+    out.nodes.emplace_back();
+    out.root_child = 0;
+    out.stack_need = c.emit(in.root_child, 0, 1);
+}
+
 }  // namespace bf

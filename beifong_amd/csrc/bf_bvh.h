@@ -80,6 +80,26 @@ struct BVH4 {
 // levels of children - 1) is reported so that the kernels' stacks can be sized.
 void collapse_bvh4(const BVH &in, BVH4 &out);
 
+// Sixteen-wide collapse of the SAME binary tree (same leaf order, same padded boxes) for the tail kernel's row
+// traversal: one ray per 16-lane DPP row, lane j tests child j of a node or triangle j of a leaf, so the serial
+// depth of a lone ray is ~log16 instead of ~log4 of the triangle count.  512 bytes per node:
+//   child j = float4 (lo.x, lo.y, lo.z, hi.x), float4 (hi.y, hi.z, bits(ref), 0)
+// ref >= 0: node index; ref < 0: leaf, ~ref = (first_triangle << 4) | (count - 1) with up to 16 triangles in
+// contiguous slots (a whole binary subtree); kEmptyChild: unused slot (inverted box).
+struct alignas(16) Node16 {
+    float c[16][8];
+};
+static_assert(sizeof(Node16) == 512, "sixteen-wide node must be 512 bytes");
+constexpr uint32_t kWideLeaf = 16;
+
+struct BVH16 {
+    std::vector<Node16> nodes;        // nodes[0] is the root if root_child >= 0
+    int32_t root_child;               // >= 0: node index, < 0: the whole mesh is one leaf (Node16 leaf encoding)
+    uint32_t stack_need;              // worst-case traversal stack entries (all hit children are pushed: sum of children per level)
+    uint32_t max_depth;
+};
+void collapse_bvh16(const BVH &in, BVH16 &out);
+
 // Binned SAH build (16 bins, leaf <= kMaxLeaf triangles).  Boxes are padded by a few
 // ulps so that a fp32 Moeller-Trumbore hit distance never falls outside the
 // box that holds its triangle.  `origin_scale`: largest |coordinate| a ray origin

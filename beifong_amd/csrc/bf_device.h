@@ -21,6 +21,7 @@ namespace bfd {
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kStackDepth = 32;      // per-lane traversal stack entries in LDS
 constexpr int kMaxLdsHist = 12288;   // floats of LDS-privatised histogram (48 KiB)
+constexpr int kWideStack = 512;      // row-traversal stack entries per 16-lane row (aliases the 16 lanes' LDS stack columns)
 constexpr uint32_t kTopNodes = 85;   // == bf::kTopNodes (bf_bvh.h): nodes of the tree's top levels kept in LDS by wf_trace
 
 struct DRect {
@@ -89,6 +90,11 @@ struct DScene {
     uint32_t spill_stride;
     uint32_t stack_need;      // BVH4::stack_need: kernels whose LDS stack holds that many entries compile the overflow path out
     float c, lambda_min, lambda_max;   // MTS_C, MTS_WAVELENGTH_MIN/MAX as run-time physics
+    // sixteen-wide collapse of the same tree (bf_bvh.h: Node16, 32 float4 per node) for the tail kernel's row traversal;
+    // nullptr when the scene has no triangles or its worst-case stack exceeds kWideStack
+    const float4 *wnodes;
+    int32_t wroot;
+    uint32_t n_wnodes;
     const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
 };
 

@@ -385,6 +385,161 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
     }
 }
 
+// ---------------------------------------------------------------------------
+// Row-cooperative traversal for the deep tail: ONE ray per 16-lane DPP row on the sixteen-wide tree (bf_bvh.h:
+// Node16).  Lane j of the row tests child j of a node, triangle j of a leaf (up to 16 per leaf), rectangle j.
+// A lone path's bounce is a chain of dependent fetches; with four-wide nodes and two-triangle leaves that chain is
+// ~25 steps long, here it is ~log16 of the triangle count.  Every loop iteration issues ONE batch of loads per row
+// (child box or triangle, same registers), so rows at nodes and rows at leaves share a single memory round trip.
+// Box tests only select triangles; triangle tests and the tie rule are those of traverse_dyn, so hits are bit-equal.
+// The row's stack lives in the LDS columns of its 16 lanes (entry e of the row whose first thread is `b` at
+// lds[(e / 16) * kBlock + b + e % 16]): kStackDepth * 16 = kWideStack entries; the host only enables the wide tree
+// when its worst case fits.
+// ---------------------------------------------------------------------------
+template <int N> BF_DEV int row_ror(int v) { return __builtin_amdgcn_mov_dpp(v, 0x120 + N, 0xf, 0xf, true); }
+template <int N> BF_DEV uint32_t row_ror(uint32_t v) { return (uint32_t) row_ror<N>((int) v); }
+template <int N> BF_DEV float row_ror(float v) { return __int_as_float(row_ror<N>(__float_as_int(v))); }
+
+template <int N> BF_DEV void row_merge_step(Hit &best) {
+    const float t = row_ror<N>(best.t), u = row_ror<N>(best.u), v = row_ror<N>(best.v);
+    const uint32_t prim = row_ror<N>(best.prim);
+    const int32_t slot = row_ror<N>(best.slot);
+    if (t != BF_INF) consider(best, t, u, v, prim, slot);
+}
+// after the four steps every lane of the row holds the row's best hit (consider() is a total order)
+BF_DEV void row_merge_hit(Hit &best) {
+    row_merge_step<8>(best);
+    row_merge_step<4>(best);
+    row_merge_step<2>(best);
+    row_merge_step<1>(best);
+}
+
+#ifdef BF_TAIL_PROF
+struct RowProf {
+    unsigned long long steps, rect, mem, cmp;
+};
+#define BF_ROWPROF_ARG , RowProf &rp
+#define BF_ROWPROF_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define BF_ROWPROF_ARG
+#define BF_ROWPROF_STAMP(v)
+#endif
+template <bool STATS>
+BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, float mint, float maxt, int *lds_block_stack,
+                           Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris BF_ROWPROF_ARG) {
+    BF_ROWPROF_STAMP(rp_t0);
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row_shift = lane & 48u;
+    int *const stk = lds_block_stack + (threadIdx.x & ~15u);      // + (e >> 4) * kBlock + (e & 15)
+    best.t = BF_INF;
+    best.u = best.v = 0.f;
+    best.prim = 0;
+    best.slot = 0;
+    found = false;
+    bool rect_hit = false;
+    if (active) {
+        for (uint32_t i = j; i < sc.n_rects; i += 16u) {
+            const DRect &rc = sc.rects[i];
+            float t, lx, ly;
+            if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
+                rect_hit = true;
+                consider(best, t, lx, ly, rc.prim, -(int32_t) (i + 1));
+            }
+        }
+    }
+    {
+        const unsigned long long m = __ballot(rect_hit);
+        if ((m >> row_shift) & 0xFFFFull) {
+            if (any) found = true;
+            row_merge_hit(best);
+        }
+    }
+    int node = (active && !found && sc.n_tris != 0) ? sc.wroot : kNoNode;
+    V3 id, oid;
+    ray_inverse(o, d, id, oid);
+    int sp = 0;
+#ifdef BF_TAIL_PROF
+    rp.rect += __builtin_amdgcn_s_memtime() - rp_t0;
+#endif
+    while (__ballot(node != kNoNode)) {
+        BF_ROWPROF_STAMP(rp_t1);
+        const bool is_node = node >= 0, is_leaf = node < 0 && node != kNoNode;
+        // ---- one batch of loads per row: child box j, or triangle j of the leaf ----------------
+        const uint32_t enc = ~(uint32_t) node;
+        const uint32_t first = enc >> 4, cnt = (enc & 15u) + 1u;
+        const float4 *ptr = sc.tris;
+        bool ld = false;
+        if (is_node) {
+            ptr = sc.wnodes + (32u * (uint32_t) node + 2u * j);
+            ld = true;
+        } else if (is_leaf) {
+            ptr = sc.tris + 3u * (first + j);
+            ld = j < cnt;
+        }
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa, qc = qa;
+        if (ld) {
+            qa = ptr[0];
+            qb = ptr[1];
+            if (is_leaf) qc = ptr[2];
+        }
+#ifdef BF_TAIL_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BF_ROWPROF_STAMP(rp_t2);
+#endif
+        if (is_node) {
+            if (STATS && j == 0u) ++n_nodes;
+            const int child = __float_as_int(qb.z);
+            float tn;
+            const float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
+            const bool h = slab_fma(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, id, oid, mint, tmax, tn) && child != kNoNode;
+            // distinct sortable keys: entry distance (non-negative: bit pattern orders like the value), child slot in the low bits
+            const uint32_t key = h ? ((min(__float_as_uint(tn), 0x7f000000u) & ~15u) | j) : 0xffffffffu;
+            uint32_t rank = 0;
+#define BF_RANK(N) rank += row_ror<N>(key) < key ? 1u : 0u;
+            BF_RANK(1) BF_RANK(2) BF_RANK(3) BF_RANK(4) BF_RANK(5) BF_RANK(6) BF_RANK(7) BF_RANK(8)
+            BF_RANK(9) BF_RANK(10) BF_RANK(11) BF_RANK(12) BF_RANK(13) BF_RANK(14) BF_RANK(15)
+#undef BF_RANK
+            const uint32_t n_hit = (uint32_t) __popcll((__ballot(h) >> row_shift) & 0xFFFFull);
+            // far-to-near: the nearest child ends up on top and is popped right away
+            if (h) {
+                const int e = sp + (int) (n_hit - 1u - rank);
+                stk[(e >> 4) * kBlock + (e & 15)] = child;
+            }
+            sp += (int) n_hit;
+        }
+        if (is_leaf) {
+            bool tri_hit = false;
+            if (ld) {
+                if (STATS) ++n_tris;
+                float t, u, v;
+                if (tri_intersect(mk(qa.x, qa.y, qa.z), mk(qb.x, qb.y, qb.z), mk(qc.x, qc.y, qc.z), o, d, mint, maxt, t, u, v)) {
+                    tri_hit = true;
+                    consider(best, t, u, v, __float_as_uint(qa.w), (int32_t) (first + j));
+                }
+            }
+            if ((__ballot(tri_hit) >> row_shift) & 0xFFFFull) {
+                if (any) found = true;
+                row_merge_hit(best);
+            }
+        }
+        if (is_node || is_leaf) {
+            if (found || sp == 0) {
+                node = kNoNode;
+            } else {
+                --sp;
+                node = stk[(sp >> 4) * kBlock + (sp & 15)];
+            }
+        }
+#ifdef BF_TAIL_PROF
+        {
+            const unsigned long long rp_t3 = __builtin_amdgcn_s_memtime();
+            rp.steps += 1;
+            rp.mem += rp_t2 - rp_t1;
+            rp.cmp += rp_t3 - rp_t2;
+        }
+#endif
+    }
+}
+
 template <bool ANY, bool STATS, bool SPILL>
 BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
                      uint32_t &n_tris) {

@@ -29,6 +29,13 @@ namespace bfd {
 #ifndef BF_TAIL_WAVES
 #define BF_TAIL_WAVES 3
 #endif
+#ifdef BF_TAIL_PROF
+// developer build (make prof): per-wave cycle breakdown of the tail kernel, read back by bfdbg_tail_profile
+__device__ unsigned long long g_tail_prof[8192 * 16];
+#define BF_PROF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define BF_PROF_STAMP(var)
+#endif
 template <bool STATS, bool RESUME, bool SPILL>
 __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
@@ -81,7 +88,14 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
         cursor_init(rcur, wf.m_alive[wf_it & 1], b0, b1, lane);
     }
 
+#ifdef BF_TAIL_PROF
+    unsigned long long pf_iters = 0, pf_regen = 0, pf_trav = 0, pf_film = 0, pf_shade = 0, pf_quad = 0, pf_rowpass = 0;
+    RowProf pf_row = {0, 0, 0, 0};
+    ShadeProf pf_sp = {0, 0, 0, 0};
+    const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
+        BF_PROF_STAMP(pf_t0);
         // ---- 1. path regeneration: dead lanes pull new path indices -------
         unsigned long long need = __ballot(!alive && !done);
         if (need && RESUME) {
@@ -136,6 +150,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             }
         }
         if (__ballot(alive) == 0ull) break;
+        BF_PROF_STAMP(pf_t1);
 
         // ---- 2. traversal phase ------------------------------------------------------
         // Every lane may hold a closest-hit ray (new path, or the continuation ray of the vertex it
@@ -149,7 +164,64 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
         bool occluded = false;
         const unsigned long long closest_mask = __ballot(trace_closest);
         const uint32_t n_cl = (uint32_t) __popcll(closest_mask), n_sh = (uint32_t) __popcll(want_mask);
-        if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= 16u) {
+#ifdef BF_TAIL_PROF
+        if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= 16u) ++pf_quad;
+#endif
+        if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= wf.row_jobs && sc.wnodes != nullptr) {
+            // ---- deep tail: ONE ray per 16-lane row on the sixteen-wide tree (traverse_row16), four rays per pass ------
+            // job k < n_cl: closest-hit ray of the k-th lane of closest_mask; job n_cl + k: shadow ray of the k-th lane of
+            // want_mask; row r of pass p serves job 4 p + r
+            const uint32_t n_jobs = n_cl + n_sh;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t my_cl_job = (uint32_t) __popcll(closest_mask & below);
+            const uint32_t my_sh_job = n_cl + (uint32_t) __popcll(want_mask & below);
+            for (uint32_t base = 0; base < n_jobs; base += 4u) {
+                const uint32_t job = base + ((uint32_t) lane >> 4);
+                const bool job_active = job < n_jobs;
+                const bool job_any = job >= n_cl;
+                int src = lane;
+                if (job_active) src = (int) (job_any ? nth_set_bit(want_mask, job - n_cl) : nth_set_bit(closest_mask, job));
+                const V3 co = mk(__shfl(s.ro.x, src), __shfl(s.ro.y, src), __shfl(s.ro.z, src));
+                const V3 cd = mk(__shfl(s.rd.x, src), __shfl(s.rd.y, src), __shfl(s.rd.z, src));
+                const float cmint = __shfl(s.rmint, src), cmaxt = __shfl(s.rmaxt, src);
+                const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
+                const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
+                const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
+                Hit qbest;
+                bool qfound;
+                traverse_row16<STATS>(sc, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
+                                      job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_nodes, c_tris
+#ifdef BF_TAIL_PROF
+                                      , pf_row
+#endif
+                );
+#ifdef BF_TAIL_PROF
+                ++pf_rowpass;
+#endif
+                // deliver: closest hits to their lanes, occlusion verdicts to the requesters
+                const int cl_row = (int) (((my_cl_job - base) & 3u) << 4);
+                const float ht = __shfl(qbest.t, cl_row), hu = __shfl(qbest.u, cl_row), hv = __shfl(qbest.v, cl_row);
+                const int hs = __shfl(qbest.slot, cl_row);
+                const uint32_t hp = (uint32_t) __shfl((int) qbest.prim, cl_row);
+                if (trace_closest && my_cl_job >= base && my_cl_job < base + 4u) {
+                    hit.t = ht;
+                    hit.u = hu;
+                    hit.v = hv;
+                    hit.slot = hs;
+                    hit.prim = hp;
+                    ++c_closest;
+                }
+                const unsigned long long occl_mask = __ballot(job_active && job_any && qfound);
+                if (sh.want && my_sh_job >= base && my_sh_job < base + 4u) {
+                    occluded = (occl_mask >> (((my_sh_job - base) & 3u) << 4)) & 1ull;
+                    ++c_shadow;
+                    // an occluded sample still contributes mis * throughput * bsdf * 0 (scene.cpp:220-224): c * 0
+                    s.result += occluded ? sh.c * 0.f : sh.c;
+                    if (lp.iq) s.phase += occluded ? sh.c_im * 0.f : sh.c_im;
+                    sh.want = false;
+                }
+            }
+        } else if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= 16u) {
             // ---- sparse wave (the deep tail): four lanes per ray (traverse_quad) -----------------------
             // job k < n_cl: closest-hit ray of the k-th lane of closest_mask; job n_cl + k: shadow ray of the k-th
             // lane of want_mask; quad k = lanes 4k .. 4k + 3 serves job k
@@ -245,6 +317,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             }
         }
         if (trace_closest) need_closest = false;
+        BF_PROF_STAMP(pf_t2);
 
         // ---- 3. film: paths that ended at the vertex shaded last iteration (their last shadow ray
         //         has resolved by now) ---------------------------------------------------------------
@@ -263,9 +336,14 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             }
         }
 
+        BF_PROF_STAMP(pf_t3);
         // ---- 4. vertex logic for the lanes that hold a fresh hit ---------------------------------
         if (alive && !need_closest) {
-            if (!shade_vertex(sc, lp, s, hit, sh, c_bounces)) {
+            if (!shade_vertex(sc, lp, s, hit, sh, c_bounces
+#ifdef BF_TAIL_PROF
+                              , &pf_sp
+#endif
+                              )) {
                 film = true;                                   // ended at the head of the iteration: no new rays
             } else if (s.flags & kFlagTermPending) {
                 film = true;                                   // ended by the BSDF sample: its NEE ray is still to trace
@@ -273,7 +351,62 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 need_closest = true;
             }
         }
+#ifdef BF_TAIL_PROF
+        {
+            const unsigned long long pf_t4 = __builtin_amdgcn_s_memtime();
+            ++pf_iters;
+            pf_regen += pf_t1 - pf_t0;
+            pf_trav += pf_t2 - pf_t1;
+            pf_film += pf_t3 - pf_t2;
+            pf_shade += pf_t4 - pf_t3;
+        }
+#endif
     }
+#ifdef BF_TAIL_PROF
+    {   // the lane that shaded most vertices (the wave's longest path) speaks for the shading breakdown
+        unsigned long long key = pf_sp.si + pf_sp.head + pf_sp.nee + pf_sp.bsdf, best = key;
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = wave_read_u64(best, (lane + off) & 63);
+            best = o > best ? o : best;
+        }
+        best = wave_read_u64(best, 0);
+        // after the rotation-reduction lane 0 holds the max over all lanes only if every lane took part: recompute plainly
+        unsigned long long m = key;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long o = wave_read_u64(m, lane ^ off);
+            m = o > m ? o : m;
+        }
+        const unsigned long long who = __ballot(key == m);
+        const int srcl = __ffsll((unsigned long long) who) - 1;
+        pf_sp.si = wave_read_u64(pf_sp.si, srcl);
+        pf_sp.head = wave_read_u64(pf_sp.head, srcl);
+        pf_sp.nee = wave_read_u64(pf_sp.nee, srcl);
+        pf_sp.bsdf = wave_read_u64(pf_sp.bsdf, srcl);
+        (void) best;
+    }
+    if (RESUME && lane == 0) {
+        const uint32_t w = blockIdx.x * (kBlock / 64) + (tid >> 6);
+        if (w < 8192u) {
+            unsigned long long *q = g_tail_prof + 16u * w;
+            q[8] = pf_rowpass;
+            q[9] = pf_row.steps;
+            q[10] = pf_row.rect;
+            q[11] = pf_row.mem;
+            q[12] = pf_row.cmp;
+            q[13] = pf_sp.si;
+            q[14] = pf_sp.head;
+            q[15] = pf_sp.nee;
+            q[7] = pf_sp.bsdf;
+            q[0] = pf_iters;
+            q[1] = pf_regen;
+            q[2] = pf_trav;
+            q[3] = pf_film;
+            q[4] = pf_shade;
+            q[5] = pf_quad;
+            q[6] = __builtin_amdgcn_s_memtime() - pf_begin;
+        }
+    }
+#endif
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
     // statistics: wave-reduce then one atomic per counter per wave
@@ -423,8 +556,9 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
 namespace bfd {
 // bf_scene_translate_meshes: triangles and node boxes of the pristine copies shifted by `d`.
 __global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__restrict__ tris, uint32_t n_tri_rows,
-                                    const float4 *__restrict__ nodes0, float4 *__restrict__ nodes, uint32_t n_nodes, float dx,
-                                    float dy, float dz) {
+                                    const float4 *__restrict__ nodes0, float4 *__restrict__ nodes, uint32_t n_nodes,
+                                    const float4 *__restrict__ wnodes0, float4 *__restrict__ wnodes, uint32_t n_wchildren,
+                                    float dx, float dy, float dz) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_tri_rows) {                       // one float4 row (a vertex + tag) per thread
         float4 v = tris0[i];
@@ -451,17 +585,46 @@ __global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__
         o[6] = s[6];
         o[7] = s[7];
     }
+    if (i < n_wchildren) {                      // one child record of a sixteen-wide node (bf_bvh.h: Node16), same re-padding
+        const float4 a = wnodes0[2u * i], b = wnodes0[2u * i + 1u];
+        float lo[3] = {a.x + dx, a.y + dy, a.z + dz}, hi[3] = {a.w + dx, b.x + dy, b.y + dz};
+        for (int k = 0; k < 3; ++k) {
+            const float e = 2.4e-7f * __builtin_fmaxf(__builtin_fabsf(lo[k]), __builtin_fabsf(hi[k]));
+            lo[k] -= e;
+            hi[k] += e;
+        }
+        wnodes[2u * i] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        wnodes[2u * i + 1u] = make_float4(hi[1], hi[2], b.z, b.w);
+    }
 }
 }  // namespace bfd
 
 extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
-                                           float4 *nodes, uint32_t n_nodes, const float *d, hipStream_t stream) {
+                                           float4 *nodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
+                                           uint32_t n_wchildren, const float *d, hipStream_t stream) {
     uint32_t n = n_tri_rows > n_nodes ? n_tri_rows : n_nodes;
+    n = n > n_wchildren ? n : n_wchildren;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(bfd::bf_translate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tris0, tris, n_tri_rows, nodes0, nodes,
-                       n_nodes, d[0], d[1], d[2]);
+                       n_nodes, wnodes0, wnodes, n_wchildren, d[0], d[1], d[2]);
     return hipGetLastError();
 }
+
+#ifdef BF_TAIL_PROF
+extern "C" int bfdbg_tail_profile(unsigned long long *out, int n_waves) {
+    if (n_waves > 8192) n_waves = 8192;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bfd::g_tail_prof), sizeof(unsigned long long) * 16 * (size_t) n_waves) != hipSuccess) return -1;
+    unsigned long long zero[8] = {0};
+    (void) zero;
+    return n_waves;
+}
+extern "C" int bfdbg_tail_profile_clear(void) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(bfd::g_tail_prof)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8192) == hipSuccess ? 0 : -1;
+}
+#endif
 
 /* Host-side evaluation of the engine's fp32 cosine (bf_device_math.h), used by scene setup so that
  * precomputed emitter constants follow the same specification as the kernels. */

@@ -455,8 +455,19 @@ BF_DEV void path_phasor(float length, float lambda_nm, float &re, float &im) {
 // the BSDF sample kills the path (path.cpp:171-173) the function returns true
 // with kFlagTermPending set and an empty ray interval: the film write has to
 // wait for the shadow ray of this very iteration.
+#ifdef BF_TAIL_PROF
+struct ShadeProf {
+    unsigned long long si, head, nee, bsdf;
+};
+#define BF_SHADEPROF_ARG , ShadeProf *spf = nullptr
+#define BF_SHADEPROF_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define BF_SHADEPROF_ARG
+#define BF_SHADEPROF_STAMP(v)
+#endif
 BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
-                         uint32_t &c_bounces) {
+                         uint32_t &c_bounces BF_SHADEPROF_ARG) {
+    BF_SHADEPROF_STAMP(spf_t0);
     const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
     const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
     const uint32_t n_emit = sc.n_emitters;
@@ -468,6 +479,10 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         make_si(sc, s.ro, s.rd, hit, si);
         emitter = si.emitter;
     }
+#ifdef BF_TAIL_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    BF_SHADEPROF_STAMP(spf_t1);
     uint32_t depth = s.flags & kDepthMask;
     if (depth == 0) {
         // first intersection — path.cpp:115-117, pathlength.cpp:138-146,
@@ -528,6 +543,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
 
     const bf_material &mat = sc.materials[si.material];
     ++c_bounces;
+    BF_SHADEPROF_STAMP(spf_t2);
     if (bsdf_smooth(mat)) {
         // Scene::sample_emitter_direction / sample_transmitter_direction — scene.cpp:180-230, 249-299
         float sx = next_1d(s.rng), sy = next_1d(s.rng);
@@ -577,6 +593,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         }
         if (is_range) s.aux += si.t;                                // pathlength.cpp:209
     }
+    BF_SHADEPROF_STAMP(spf_t3);
     (void) next_1d(s.rng);                                          // sample1 (unused by these BSDFs)
     float s2x = next_1d(s.rng), s2y = next_1d(s.rng);
     BSDFSample bs;
@@ -597,6 +614,15 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     s.prev_p = si.p;
     s.bs_pdf = bs.pdf;
     ++s.n_rays;
+#ifdef BF_TAIL_PROF
+    if (spf) {
+        const unsigned long long spf_t4 = __builtin_amdgcn_s_memtime();
+        spf->si += spf_t1 - spf_t0;
+        spf->head += spf_t2 - spf_t1;
+        spf->nee += spf_t3 - spf_t2;
+        spf->bsdf += spf_t4 - spf_t3;
+    }
+#endif
     return true;
 }
 

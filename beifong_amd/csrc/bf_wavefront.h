@@ -25,6 +25,7 @@ constexpr uint32_t kShadeChain = 3;
 constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
 constexpr uint32_t kTraceBlocksPerCU = 8;
+constexpr uint32_t kTailRowJobs = 12;      // tail: up to three passes of four row-traversed rays beat one quad pass of sixteen
 
 struct WF {
     // path state [n_slots]
@@ -50,6 +51,7 @@ struct WF {
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)
     uint32_t iq;                               // BF_MODE_RECEIVE_IQ
     uint32_t shade_chain;                      // wf_shade: vertices a lane may shade per visit while its rays resolve early
+    uint32_t row_jobs;                         // tail: waves holding at most this many rays trace them one per 16-lane row (traverse_row16)
     uint32_t n_slots;               // slots in use this render (multiple of 64)
     uint32_t capacity;              // slots allocated
 };

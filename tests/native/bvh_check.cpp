@@ -118,3 +118,95 @@ extern "C" int bvh_check(uint32_t n, const float *verts /* n*9 */, uint32_t out[
     out[7] = (uint32_t) bf::kMaxLeaf;
     return 0;
 }
+
+// Sixteen-wide collapse (bf::collapse_bvh16): every triangle slot in exactly one leaf of at most 16 contiguous slots,
+// triangles inside their leaf's box, child boxes inside their parent's (up to the padding), reported stack need =
+// the worst case of "push every hit child" (sum over levels of the children count).
+namespace {
+struct Ctx16 {
+    const std::vector<bf::BuildTri> *tris;
+    const bf::BVH *bvh2;
+    const bf::BVH16 *w;
+    std::vector<uint32_t> seen;
+    uint32_t max_leaf = 0, n_leaves = 0, n_internal = 0, max_depth = 0;
+    int error = 0;
+};
+uint32_t walk16(Ctx16 &c, int32_t ref, const float lo[3], const float hi[3], uint32_t depth) {
+    c.max_depth = std::max(c.max_depth, depth);
+    if (ref < 0) {
+        const uint32_t enc = ~(uint32_t) ref, first = enc >> 4, cnt = (enc & 15u) + 1u;
+        c.max_leaf = std::max(c.max_leaf, cnt);
+        ++c.n_leaves;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            if (first + i >= c.seen.size()) {
+                c.error = 12;
+                return 0;
+            }
+            ++c.seen[first + i];
+            if (!tri_in_box((*c.tris)[c.bvh2->order[first + i]], lo, hi)) c.error = 13;
+        }
+        return 0;
+    }
+    if ((size_t) ref >= c.w->nodes.size()) {
+        c.error = 14;
+        return 0;
+    }
+    ++c.n_internal;
+    const bf::Node16 &n = c.w->nodes[(size_t) ref];
+    uint32_t used = 0, below = 0;
+    for (int k = 0; k < 16; ++k) {
+        int32_t child;
+        std::memcpy(&child, &n.c[k][6], 4);
+        if (child == bf::kEmptyChild) {
+            if (k < 2) c.error = 15;
+            continue;
+        }
+        ++used;
+        const float *clo = &n.c[k][0], *chi = &n.c[k][3];
+        for (int a = 0; a < 3; ++a) {
+            float pad = 1e-5f * std::max({1.f, std::fabs(lo[a]), std::fabs(hi[a])});
+            if (clo[a] < lo[a] - pad || chi[a] > hi[a] + pad) c.error = 16;
+        }
+        below = std::max(below, walk16(c, child, clo, chi, depth + 1));
+    }
+    return used + below;
+}
+}  // namespace
+
+extern "C" int bvh16_check(uint32_t n, const float *verts /* n*9 */, uint32_t out[8]) {
+    std::vector<bf::BuildTri> tris(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(tris[i].p0, verts + 9 * i, 12);
+        std::memcpy(tris[i].p1, verts + 9 * i + 3, 12);
+        std::memcpy(tris[i].p2, verts + 9 * i + 6, 12);
+    }
+    bf::BVH bvh2;
+    bf::build_bvh(tris, bvh2, 0.f);
+    bf::BVH16 w;
+    bf::collapse_bvh16(bvh2, w);
+    Ctx16 c;
+    c.tris = &tris;
+    c.bvh2 = &bvh2;
+    c.w = &w;
+    c.seen.assign(n, 0);
+    uint32_t need = 0;
+    if (n) {
+        need = walk16(c, w.root_child, bvh2.lo, bvh2.hi, 1);
+        if (c.error) return c.error;
+        for (uint32_t i = 0; i < n; ++i)
+            if (c.seen[i] != 1) return 17;
+        if (need != w.stack_need) return 18;
+    } else if (w.root_child != bf::kEmptyChild) {
+        return 19;
+    }
+    out[0] = (uint32_t) w.nodes.size();
+    out[1] = c.n_leaves;
+    out[2] = c.max_leaf;
+    out[3] = c.max_depth;
+    out[4] = w.stack_need;
+    out[5] = c.n_internal;
+    out[6] = 0;
+    out[7] = 0;
+    return 0;
+}
+

@@ -21,6 +21,7 @@ def checker(tmp_path_factory):
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", str(out)] + src, check=True)
     lib = C.CDLL(str(out))
     lib.bvh_check.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32 * 8)]
+    lib.bvh16_check.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     return lib
 
 
@@ -60,3 +61,27 @@ def test_random_soup_and_degenerate_inputs(checker):
     for n in (1, 2, 3, 5):
         v, f = meshgen.triangle_soup(n, seed=n)
         _check(checker, v, f)
+
+
+def _check16(lib, v, f):
+    tri = np.ascontiguousarray(np.asarray(v, np.float32)[np.asarray(f)].reshape(-1, 9))
+    out = (C.c_uint32 * 8)()
+    rc = lib.bvh16_check(tri.shape[0], tri.ctypes.data, C.byref(out))
+    assert rc == 0, f"sixteen-wide invariant {rc} violated"
+    return dict(zip(("nodes16", "leaves", "max_leaf", "depth16", "stack_need", "internal"), list(out)[:6]))
+
+
+def test_sixteen_wide_collapse_for_the_tail_kernel(checker):
+    """bf::collapse_bvh16 (the tail kernel's row traversal, DESIGN.md 3.3): same leaf order as the four-wide tree, leaves
+    of at most 16 contiguous slots, a much shallower tree, and a worst-case stack that fits the kernels' 512 entries."""
+    for v, f in (meshgen.bus(20000, seed=1), meshgen.car_body(30000, seed=2)[:2], meshgen.motorbike(10000, seed=5),
+                 meshgen.triangle_soup(5000, seed=3)):
+        s4 = _check(checker, v, f)
+        s = _check16(checker, v, f)
+        assert s["max_leaf"] <= 16 and s["leaves"] >= len(f) / 16
+        assert s["depth16"] < s4["depth4"]
+        assert s["stack_need"] <= 16 * s["depth16"] and s["stack_need"] <= 512
+    for n in (1, 2, 3, 5, 16, 17, 40):
+        v, f = meshgen.triangle_soup(n, seed=n)
+        s = _check16(checker, v, f)
+        assert s["nodes16"] == (0 if n <= 16 else s["internal"])
