@@ -18,7 +18,7 @@ BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
 BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED, BF_EMITTER_POINT = range(6)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED, BF_SENSOR_IRRADIANCEMETER, BF_SENSOR_RADIANCEMETER = range(7)
-BF_ABI_VERSION = 1          # include/beifong_hip.h: BF_ABI_VERSION
+BF_ABI_VERSION = 2          # include/beifong_hip.h: BF_ABI_VERSION
 BF_VELEM_FLOATS = 32
 BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
@@ -111,10 +111,15 @@ class bf_scene_info(C.Structure):
                 ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32)]
 
 
+class bf_batch(C.Structure):
+    _fields_ = [("n_renders", C.c_uint32), ("seeds", C.POINTER(C.c_uint64)), ("mesh_offsets", C.POINTER(C.c_float))]
+
+
 # every symbol include/beifong_hip.h declares
 EXPORTED_SYMBOLS = [
     "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
-    "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_launch_channels", "bf_render_device", "bf_render",
+    "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_scene_clone", "bf_launch_channels", "bf_render_device", "bf_render",
+    "bf_render_batch_device", "bf_render_batch",
     "bf_trace_closest", "bf_trace_any", "bf_ray_intersect", "bf_eval_elementary",
 ]
 
@@ -146,12 +151,15 @@ def load_library(path=None):
     lib.bf_scene_create.argtypes = [C.POINTER(bf_scene_desc), C.POINTER(vp)]
     lib.bf_scene_destroy.argtypes = [vp]
     lib.bf_scene_get_info.argtypes = [vp, C.POINTER(bf_scene_info)]
+    lib.bf_scene_clone.argtypes = [vp, C.POINTER(vp)]
     lib.bf_scene_update_endpoints.argtypes = [vp, C.POINTER(bf_scene_desc), vp]
     lib.bf_scene_translate_meshes.argtypes = [vp, C.POINTER(C.c_float * 3), vp]
     lib.bf_launch_channels.argtypes = [C.POINTER(bf_launch)]
     lib.bf_launch_channels.restype = C.c_uint32
     lib.bf_render_device.argtypes = [vp, C.POINTER(bf_launch), vp, vp, vp, C.POINTER(bf_stats)]
     lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
+    lib.bf_render_batch_device.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, vp, C.POINTER(bf_stats)]
+    lib.bf_render_batch.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
     lib.bf_trace_any.argtypes = [vp, C.c_uint64, vp, vp]
     lib.bf_ray_intersect.argtypes = [vp, C.c_uint64, vp, vp, vp, vp]
@@ -200,6 +208,16 @@ class Scene:
             self.lib.bf_scene_destroy(self.handle)
             self.handle = None
 
+    def clone(self):
+        """bf_scene_clone: another handle on the same geometry (own endpoint tables, path pool, counters) for another stream."""
+        other = Scene.__new__(Scene)
+        other.lib = self.lib
+        other.holder = self.holder
+        h = C.c_void_p()
+        check(self.lib, self.lib.bf_scene_clone(self.handle, C.byref(h)), "bf_scene_clone")
+        other.handle = h
+        return other
+
     def __del__(self):
         try:
             self.close()
@@ -243,6 +261,45 @@ class Scene:
                                                   C.c_void_p(records_ptr) if records_ptr else None,
                                                   C.c_void_p(stream) if stream else None,
                                                   C.byref(st) if st is not None else None), "bf_render_device")
+        return st
+
+    @staticmethod
+    def _batch(n_renders, seeds, offsets):
+        """bf_batch + the arrays it points to (keep the tuple alive for the duration of the call)."""
+        b = bf_batch()
+        b.n_renders = int(n_renders)
+        sa = oa = None
+        if seeds is not None:
+            sa = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(-1)
+            assert sa.size == b.n_renders, "one seed per render"
+            b.seeds = sa.ctypes.data_as(C.POINTER(C.c_uint64))
+        if offsets is not None:
+            oa = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1, 3)
+            assert oa.shape[0] == b.n_renders, "one mesh offset per render"
+            b.mesh_offsets = oa.ctypes.data_as(C.POINTER(C.c_float))
+        return b, sa, oa
+
+    def render_batch(self, launch, n_renders, seeds=None, offsets=None, records=False):
+        """bf_render_batch: n_renders renders of `launch` in one launch sequence -> float32[n_renders, channels]
+        (+ records [n_renders, n_paths], stats)."""
+        n = self.channels(launch)
+        hist = np.zeros((n_renders, n), dtype=np.float32)
+        rec = np.zeros((n_renders, launch.n_paths), dtype=PATH_RECORD_DTYPE) if records else None
+        st = bf_stats()
+        b, sa, oa = self._batch(n_renders, seeds, offsets)
+        check(self.lib, self.lib.bf_render_batch(self.handle, C.byref(launch), C.byref(b), _ptr(hist), _ptr(rec), C.byref(st)),
+              "bf_render_batch")
+        return hist, rec, st
+
+    def render_batch_device(self, launch, n_renders, hist_ptr, seeds=None, offsets=None, stream=0, records_ptr=None,
+                            want_stats=False):
+        """bf_render_batch_device: accumulate n_renders renders into hist_ptr[n_renders * channels] (device memory)."""
+        st = bf_stats() if want_stats else None
+        b, sa, oa = self._batch(n_renders, seeds, offsets)
+        check(self.lib, self.lib.bf_render_batch_device(self.handle, C.byref(launch), C.byref(b), C.c_void_p(hist_ptr),
+                                                        C.c_void_p(records_ptr) if records_ptr else None,
+                                                        C.c_void_p(stream) if stream else None,
+                                                        C.byref(st) if st is not None else None), "bf_render_batch_device")
         return st
 
     def trace_closest(self, rays):

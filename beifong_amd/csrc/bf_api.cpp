@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -93,9 +94,20 @@ inline V3 normalize(V3 a) {
 
 }  // namespace
 
+// The big read-only arrays of a scene (BVH nodes, triangles, normals, texture coordinates): shared by a scene and its
+// clones (bf_scene_clone), freed with the last of them.
+struct bf_geometry {
+    std::vector<void *> owned;
+    ~bf_geometry() {
+        for (void *p : owned) (void) hipFree(p);
+    }
+};
+
 struct bf_scene {
     bfd::DScene d;
-    std::vector<void *> owned;
+    std::shared_ptr<bf_geometry> geom;     // nodes / wnodes / tris / normals / uvs as created
+    bool geom_private = false;             // d.tris / d.nodes / d.wnodes point at this handle's own translated copies
+    std::vector<void *> owned;             // this handle's own allocations (small tables, spill columns, private geometry)
     bf_scene_info info;
     int device = 0;
     int n_cus = 256;
@@ -132,6 +144,20 @@ struct bf_scene {
         uint32_t iters = 0, tail_live = 0;
     };
     mutable WfPlan wf_plan;
+    mutable uint32_t *wf_render_buf = nullptr;   // per-slot render index of batched launches (WF::render when a batch runs)
+    // Pinned staging for small host tables that travel with a launch (batch seeds / mesh offsets, endpoint records):
+    // a ring of slots, each with its own device mirror and an event recorded behind the copy, so the caller's arrays
+    // and our stack locals are free again when the call returns and nothing blocks unless kStageSlots launches are in
+    // flight on this scene.
+    static constexpr int kStageSlots = 8;
+    struct Stage {
+        void *host = nullptr, *dev = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool busy = false;
+    };
+    mutable Stage stage[kStageSlots];
+    mutable int stage_next = 0;
     mutable uint32_t *wf_feedback = nullptr;     // pinned: n_live[0 .. wf_fb_iters) of the last planned render
     mutable hipEvent_t wf_fb_event = nullptr;
     mutable bool wf_fb_pending = false;
@@ -180,7 +206,51 @@ bf_status bf_scene_destroy(bf_scene *s) {
     if (s->wf_fb_event) (void) hipEventDestroy(s->wf_fb_event);
     for (hipEvent_t e : s->wf_timing) (void) hipEventDestroy(e);
     if (s->counters) (void) hipFree(s->counters);
+    for (auto &st : s->stage) {
+        if (st.ev) {
+            (void) hipEventSynchronize(st.ev);
+            (void) hipEventDestroy(st.ev);
+        }
+        if (st.host) (void) hipHostFree(st.host);
+        if (st.dev) (void) hipFree(st.dev);
+    }
     delete s;
+    return BF_OK;
+}
+
+// Next staging slot with room for `bytes` (see bf_scene::Stage): *host is pinned memory the caller fills, *dev its
+// device mirror; stage_commit() enqueues the copy and the slot's event.
+static bf_status stage_acquire(const bf_scene *sc, size_t bytes, bf_scene::Stage **out) {
+    bf_scene::Stage &st = sc->stage[sc->stage_next];
+    sc->stage_next = (sc->stage_next + 1) % bf_scene::kStageSlots;
+    if (st.busy) {
+        HIP_TRY(hipEventSynchronize(st.ev));
+        st.busy = false;
+    }
+    if (st.cap < bytes) {
+        if (st.host) (void) hipHostFree(st.host);
+        if (st.dev) (void) hipFree(st.dev);
+        st.host = st.dev = nullptr;
+        st.cap = 0;
+        const size_t cap = std::max<size_t>(4096, (bytes + 4095) & ~size_t(4095));
+        HIP_TRY(hipHostMalloc(&st.host, cap));
+        HIP_TRY(hipMalloc(&st.dev, cap));
+        st.cap = cap;
+    }
+    if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    *out = &st;
+    return BF_OK;
+}
+static bf_status stage_commit(bf_scene::Stage *st, size_t bytes, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(st->dev, st->host, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(st->ev, stream));
+    st->busy = true;
+    return BF_OK;
+}
+// the slot only lends its pinned buffer: copies to other device addresses were enqueued by the caller
+static bf_status stage_release_after(bf_scene::Stage *st, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(st->ev, stream));
+    st->busy = true;
     return BF_OK;
 }
 
@@ -455,6 +525,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     std::memset(&sc->d, 0, sizeof(sc->d));
     std::memset(&sc->info, 0, sizeof(sc->info));
     std::memset(&sc->wf, 0, sizeof(sc->wf));
+    sc->geom = std::make_shared<bf_geometry>();
     {
         bf_status ast = bind_arrays(sc, flat, nullptr, true);
         if (ast != BF_OK) {
@@ -473,8 +544,13 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     // sixteen-wide collapse of the same tree for the tail kernel's row traversal (bf_bvh.h: Node16)
     bf::BVH16 bvh16;
     bf::collapse_bvh16(bvh, bvh16);
-    const bool use_wide = !btris.empty() && bvh16.stack_need <= (uint32_t) bfd::kWideStack && btris.size() < (1u << 27) &&
-                          !getenv("BF_NO_WIDE_BVH");
+    // a gang of R rows pops R entries per step: its stack holds at most one block of 16 R children per tree level
+    // (blocks are consumed last-in first-out and a block's shallowest entry lies deeper than the block below it)
+    uint32_t wide_rlog = 2;
+    while (wide_rlog > 0 && (16u << wide_rlog) * std::max(1u, bvh16.max_depth) > (uint32_t) bfd::kWideStack) --wide_rlog;
+    const bool use_wide = !btris.empty() && 16u * std::max(1u, bvh16.max_depth) <= (uint32_t) bfd::kWideStack &&
+                          btris.size() < (1u << 27) && !getenv("BF_NO_WIDE_BVH");
+    if (const char *e = getenv("BF_WIDE_ROWS_LOG")) wide_rlog = std::min<uint32_t>(wide_rlog, (uint32_t) atoi(e));
     for (int k = 0; k < 3 && !btris.empty(); ++k)
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
@@ -550,11 +626,17 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         bf_scene_destroy(sc);                                       \
         return st;                                                  \
     }
-    UP(node_data, nodes);
-    UP(wnode_data, wnodes);
-    UP(tri_data, tris);
-    UP(nrm_data, normals);
-    UP(uv_data, uvs);
+#define UPG(vec, field)                                                   \
+    if ((st = upload(vec, &sc->d.field, sc->geom->owned, bytes)) != BF_OK) { \
+        bf_scene_destroy(sc);                                             \
+        return st;                                                        \
+    }
+    UPG(node_data, nodes);
+    UPG(wnode_data, wnodes);
+    UPG(tri_data, tris);
+    UPG(nrm_data, normals);
+    UPG(uv_data, uvs);
+#undef UPG
     UP(rects, rects);
     UP(shapes, shapes);
     UP(mats, materials);
@@ -572,6 +654,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->d.root = bvh4.root_child;
     sc->d.wroot = use_wide ? bvh16.root_child : bfd_no_node();
     sc->d.n_wnodes = use_wide ? (uint32_t) bvh16.nodes.size() : 0u;
+    sc->d.wrows_log = wide_rlog;
     sc->d.c = desc->physics.c;
     sc->d.lambda_min = desc->physics.lambda_min_nm;
     sc->d.lambda_max = desc->physics.lambda_max_nm;
@@ -654,25 +737,42 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const size_t tri_bytes = (size_t) scene->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
     const size_t wnode_bytes = scene->d.wnodes ? (size_t) scene->d.n_wnodes * 32 * sizeof(float4) : 0;
-    if (!scene->tris0) {
-        // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
+    const bool shared = scene->geom.use_count() > 1 && !scene->geom_private;
+    auto own_copy = [&](size_t bytes, float4 **out) -> bf_status {
+        *out = nullptr;
+        if (!bytes) return BF_OK;
         void *p = nullptr;
-        HIP_TRY(hipMalloc(&p, tri_bytes));
+        HIP_TRY(hipMalloc(&p, bytes));
         scene->owned.push_back(p);
-        scene->tris0 = (float4 *) p;
+        *out = (float4 *) p;
+        return BF_OK;
+    };
+    if (shared) {
+        // copy on write: the arrays are shared with clones (bf_scene_clone) — this handle gets its own translated
+        // copies; the source of the translation is the geometry as created if this handle has it (it translated in
+        // place before it was cloned), else the shared arrays themselves
+        float4 *t = nullptr, *n = nullptr, *w = nullptr;
+        bf_status cst;
+        if ((cst = own_copy(tri_bytes, &t)) != BF_OK || (cst = own_copy(node_bytes, &n)) != BF_OK || (cst = own_copy(wnode_bytes, &w)) != BF_OK)
+            return cst;
+        if (!scene->tris0) {
+            scene->tris0 = const_cast<float4 *>(scene->d.tris);
+            scene->nodes0 = const_cast<float4 *>(scene->d.nodes);
+            scene->wnodes0 = const_cast<float4 *>(scene->d.wnodes);
+        }
+        scene->d.tris = t;
+        scene->d.nodes = n;
+        scene->d.wnodes = w;
+        scene->geom_private = true;
+    } else if (!scene->tris0) {
+        // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
+        bf_status cst;
+        if ((cst = own_copy(tri_bytes, &scene->tris0)) != BF_OK || (cst = own_copy(node_bytes, &scene->nodes0)) != BF_OK ||
+            (cst = own_copy(wnode_bytes, &scene->wnodes0)) != BF_OK)
+            return cst;
         HIP_TRY(hipMemcpyAsync(scene->tris0, scene->d.tris, tri_bytes, hipMemcpyDeviceToDevice, stream));
-        if (node_bytes) {
-            HIP_TRY(hipMalloc(&p, node_bytes));
-            scene->owned.push_back(p);
-            scene->nodes0 = (float4 *) p;
-            HIP_TRY(hipMemcpyAsync(scene->nodes0, scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
-        }
-        if (wnode_bytes) {
-            HIP_TRY(hipMalloc(&p, wnode_bytes));
-            scene->owned.push_back(p);
-            scene->wnodes0 = (float4 *) p;
-            HIP_TRY(hipMemcpyAsync(scene->wnodes0, scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
-        }
+        if (node_bytes) HIP_TRY(hipMemcpyAsync(scene->nodes0, scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
+        if (wnode_bytes) HIP_TRY(hipMemcpyAsync(scene->wnodes0, scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
     }
     HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
                                  const_cast<float4 *>(scene->d.nodes), scene->d.n_nodes, scene->wnodes0,
@@ -683,6 +783,106 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
     if (!scene || !info) return fail(BF_ERR_INVALID, "null argument");
     *info = scene->info;
+    return BF_OK;
+}
+
+bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
+    if (!src || !out) return fail(BF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipDeviceSynchronize());      // pending endpoint updates / translations of `src` are part of what is cloned
+    bf_scene *sc = new (std::nothrow) bf_scene();
+    if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
+    sc->d = src->d;                        // geometry pointers shared (as they stand now); the rest replaced below
+    sc->geom = src->geom;
+    std::memset(&sc->wf, 0, sizeof(sc->wf));
+    sc->info = src->info;
+    sc->device = src->device;
+    sc->n_cus = src->n_cus;
+    sc->emitter_types = src->emitter_types;
+    sc->n_materials = src->n_materials;
+    sc->sensor_host = src->sensor_host;
+    sc->film_w = src->film_w;
+    sc->film_h = src->film_h;
+    sc->shapes_host = src->shapes_host;
+    sc->origin_scale_built = src->origin_scale_built;
+    bf_status st = BF_OK;
+    auto fail_out = [&](bf_status s) {
+        bf_scene_destroy(sc);
+        return s;
+    };
+    // own small tables (endpoints may differ per clone), own spill columns and counters
+    auto dup = [&](const void *from, size_t bytes, const void **to) -> bf_status {
+        *to = nullptr;
+        if (!from || !bytes) return BF_OK;
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        sc->owned.push_back(p);
+        HIP_TRY(hipMemcpy(p, from, bytes, hipMemcpyDeviceToDevice));
+        *to = p;
+        return BF_OK;
+    };
+    if (src->tris0 || src->geom_private) {
+        // `src` has been translated (in place, or into its own copies): the clone takes a snapshot of the geometry
+        // src renders now as ITS geometry "as created"; normals / texture coordinates stay shared
+        const size_t tri_bytes = (size_t) src->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) src->d.n_nodes * 8 * sizeof(float4);
+        const size_t wnode_bytes = src->d.wnodes ? (size_t) src->d.n_wnodes * 32 * sizeof(float4) : 0;
+        if ((st = dup(src->d.tris, tri_bytes, (const void **) &sc->d.tris)) != BF_OK) return fail_out(st);
+        if ((st = dup(src->d.nodes, node_bytes, (const void **) &sc->d.nodes)) != BF_OK) return fail_out(st);
+        if ((st = dup(src->d.wnodes, wnode_bytes, (const void **) &sc->d.wnodes)) != BF_OK) return fail_out(st);
+        sc->geom_private = true;
+    }
+    if ((st = dup(src->d.rects, sizeof(bfd::DRect) * src->d.n_rects, (const void **) &sc->d.rects)) != BF_OK) return fail_out(st);
+    if ((st = dup(src->d.shapes, sizeof(bfd::DShape) * src->info.n_shapes, (const void **) &sc->d.shapes)) != BF_OK) return fail_out(st);
+    if ((st = dup(src->d.materials, sizeof(bf_material) * src->n_materials, (const void **) &sc->d.materials)) != BF_OK) return fail_out(st);
+    if ((st = dup(src->d.sensor, sizeof(bfd::DSensor), (const void **) &sc->d.sensor)) != BF_OK) return fail_out(st);
+    // emitters carry device pointers to their phased-array tables: duplicate the tables and re-point the records
+    std::vector<bfd::DEmitter> em(src->d.n_emitters);
+    if (!em.empty()) {
+        hipError_t e = hipMemcpy(em.data(), src->d.emitters, sizeof(bfd::DEmitter) * em.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: %s", hipGetErrorString(e)));
+    }
+    sc->array_dev.assign(em.size(), nullptr);
+    sc->array_n = src->array_n;
+    sc->array_n.resize(em.size(), 0u);
+    for (size_t i = 0; i < em.size(); ++i) {
+        if (em[i].type != BF_TRANSMITTER_PHASED || i >= src->array_dev.size() || !src->array_dev[i]) continue;
+        const void *p = nullptr;
+        if ((st = dup(src->array_dev[i], sizeof(float) * BF_VELEM_FLOATS * src->array_n[i], &p)) != BF_OK) return fail_out(st);
+        sc->array_dev[i] = (float *) const_cast<void *>(p);
+        em[i].velems = sc->array_dev[i];
+    }
+    if (!em.empty()) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, sizeof(bfd::DEmitter) * em.size());
+        if (e == hipSuccess) {
+            sc->owned.push_back(p);
+            e = hipMemcpy(p, em.data(), sizeof(bfd::DEmitter) * em.size(), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: %s", hipGetErrorString(e)));
+        sc->d.emitters = (const bfd::DEmitter *) p;
+    }
+    if (src->sensor_array_dev) {
+        const void *p = nullptr;
+        if ((st = dup(src->sensor_array_dev, sizeof(float) * BF_VELEM_FLOATS * src->sensor_array_n, &p)) != BF_OK) return fail_out(st);
+        sc->sensor_array_dev = (float *) const_cast<void *>(p);
+        sc->sensor_array_n = src->sensor_array_n;
+        sc->sensor_host.velems = sc->sensor_array_dev;
+        hipError_t e = hipMemcpy((void *) sc->d.sensor, &sc->sensor_host, sizeof(bfd::DSensor), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: %s", hipGetErrorString(e)));
+    }
+    {
+        const uint32_t depth = src->d.stack_need > 16 ? src->d.stack_need - 16 : 1;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (size_t) src->d.spill_stride * depth * sizeof(int));
+        if (e != hipSuccess) return fail_out(fail(BF_ERR_NOMEM, "bf_scene_clone: traversal spill: %s", hipGetErrorString(e)));
+        sc->owned.push_back(p);
+        sc->d.spill = (int *) p;
+    }
+    {
+        hipError_t e = hipMalloc((void **) &sc->counters, sizeof(unsigned long long) * bfd::CTR_COUNT);
+        if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: counters: %s", hipGetErrorString(e)));
+    }
+    *out = sc;
     return BF_OK;
 }
 
@@ -721,6 +921,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sh1, n * 16));
     HIP_TRY(alloc((void **) &wf.sh2, n * 4));
     HIP_TRY(alloc((void **) &wf.sh3, n * 4));
+    HIP_TRY(alloc((void **) &scene->wf_render_buf, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.counters = scene->counters;
@@ -759,6 +960,9 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         const char *e3 = getenv("BF_SHADE_CHAIN");
         wf.shade_chain = std::max(1, e3 ? atoi(e3) : (int) bfd::kShadeChain);
         wf.iq = lp.iq;
+        wf.render = lp.batch != 0u ? scene->wf_render_buf : nullptr;
+        wf.offsets = lp.batch_offsets;
+        wf.box_slack = lp.box_slack;
         const char *e4 = getenv("BF_TAIL_ROWJOBS");
         wf.row_jobs = e4 ? (uint32_t) atoi(e4) : bfd::kTailRowJobs;
     }
@@ -769,7 +973,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         wf.m_shadow[b] = scene->wf_masks + (3 * b + 2) * nb;
     }
     HIP_TRY(hipMemsetAsync(wf.n_live, 0, (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
-    size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan + 15) & ~size_t(15)) : 0;
+    size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan_all + 15) & ~size_t(15)) : 0;
     size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
     static const int shade_waves = [] {
         const char *e = getenv("BF_SHADE_WAVES");
@@ -913,9 +1117,17 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     return fail(BF_ERR_UNSUPPORTED, "path depth exceeded the wavefront iteration limit (%u bounces)", bfd::kWfMaxIter);
 }
 
-bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
-                           void *stream_, bf_stats *stats_out) {
+static bf_status render_common(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_dev,
+                               bf_path_record *records_dev, void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
+    const uint32_t n_renders = batch ? batch->n_renders : 1u;
+    if (batch) {
+        if (n_renders == 0) return fail(BF_ERR_INVALID, "bf_render_batch: n_renders is 0");
+        if (launch->spp && launch->film_width && launch->film_height)
+            return fail(BF_ERR_UNSUPPORTED, "bf_render_batch: multi-pixel films are rendered one launch at a time");
+        if ((uint64_t) n_renders * bf_launch_channels(launch) > (1ull << 31) || (uint64_t) n_renders * launch->n_paths >= (1ull << 48))
+            return fail(BF_ERR_UNSUPPORTED, "bf_render_batch: %u renders x %llu paths is too large", n_renders, (unsigned long long) launch->n_paths);
+    }
     const bool is_rx = scene->sensor_host.type == BF_RECEIVER_OMNI || scene->sensor_host.type == BF_RECEIVER_WIGNER ||
                        scene->sensor_host.type == BF_RECEIVER_PHASED;
     const bool receive_mode = launch->mode == BF_MODE_RECEIVE_RAW || launch->mode == BF_MODE_RECEIVE_IQ;
@@ -978,12 +1190,51 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);
     lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
-    lp.lds_hist = (lp.n_chan <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
-    size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan : 0);
+    lp.n_chan_all = lp.n_chan * n_renders;
+    lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
+    size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);
     lds = (lds + 15) & ~size_t(15);
+    if (batch) {
+        // one launch sequence over n_renders * n_paths global path indices (DLaunch::batch); the per-render seeds and
+        // mesh offsets travel through the scene's pinned staging ring, so the caller's arrays are free on return
+        lp.batch = n_renders;
+        lp.batch_paths = launch->n_paths;
+        lp.n_paths = launch->n_paths * n_renders;
+        // the offsets are read as float4 on both sides: keep them 16-byte aligned behind the seeds
+        const size_t seed_bytes = batch->seeds ? ((sizeof(uint64_t) * n_renders + 15) & ~size_t(15)) : 0;
+        const size_t off_bytes = batch->mesh_offsets ? sizeof(float4) * n_renders : 0;
+        if (seed_bytes + off_bytes) {
+            bf_scene::Stage *stg = nullptr;
+            bf_status sst = stage_acquire(scene, seed_bytes + off_bytes, &stg);
+            if (sst != BF_OK) return sst;
+            if (seed_bytes) {
+                std::memcpy(stg->host, batch->seeds, sizeof(uint64_t) * n_renders);
+                lp.batch_seeds = (const uint64_t *) stg->dev;
+            }
+            if (off_bytes) {
+                float4 *o = (float4 *) ((char *) stg->host + seed_bytes);
+                float dmax = 0.f;
+                for (uint32_t k = 0; k < n_renders; ++k) {
+                    const float *q = batch->mesh_offsets + 3 * k;
+                    if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])))
+                        return fail(BF_ERR_INVALID, "bf_render_batch: non-finite mesh offset of render %u", k);
+                    o[k] = make_float4(q[0], q[1], q[2], 0.f);
+                    dmax = std::max({dmax, std::fabs(q[0]), std::fabs(q[1]), std::fabs(q[2])});
+                }
+                if (scene->d.n_tris) {
+                    lp.batch_offsets = (const float4 *) ((char *) stg->dev + seed_bytes);
+                    // bf_device_core.h: Shift — the roundings of o - d and p + d move a box plane by at most
+                    // 1.8e-7 (S + 2 |d|), S = the bound the boxes were padded for
+                    lp.box_slack = 1e-6f * (scene->origin_scale_built + 2.f * dmax);
+                }
+            }
+            sst = stage_commit(stg, seed_bytes + off_bytes, stream);
+            if (sst != BF_OK) return sst;
+        }
+    }
 
     // persistent grid: enough workgroups to fill the chip, never more than the work
-    uint64_t want = (launch->n_paths + bfd::kBlock - 1) / bfd::kBlock;
+    uint64_t want = (lp.n_paths + bfd::kBlock - 1) / bfd::kBlock;
     unsigned blocks_per_cu = (unsigned) std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
     unsigned grid = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t) scene->n_cus * blocks_per_cu));
 
@@ -1010,7 +1261,7 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
         unsigned long long c[bfd::CTR_COUNT];
         HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
         std::memset(stats_out, 0, sizeof(*stats_out));
-        stats_out->n_paths = launch->n_paths;
+        stats_out->n_paths = lp.n_paths;
         stats_out->n_rays_closest = c[bfd::CTR_CLOSEST];
         stats_out->n_rays_shadow = c[bfd::CTR_SHADOW];
         stats_out->n_nodes_visited = c[bfd::CTR_NODES];
@@ -1036,32 +1287,56 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float
     return BF_OK;
 }
 
-bf_status bf_render(const bf_scene *scene, const bf_launch *launch, float *hist_out, bf_path_record *records_out,
-                    bf_stats *stats_out) {
+bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
+                           void *stream, bf_stats *stats_out) {
+    return render_common(scene, launch, nullptr, hist_dev, records_dev, stream, stats_out);
+}
+
+bf_status bf_render_batch_device(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_dev,
+                                 bf_path_record *records_dev, void *stream, bf_stats *stats_out) {
+    if (!batch) return fail(BF_ERR_INVALID, "bf_render_batch_device: null batch");
+    return render_common(scene, launch, batch, hist_dev, records_dev, stream, stats_out);
+}
+
+static bf_status render_host(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_out,
+                             bf_path_record *records_out, bf_stats *stats_out) {
     if (!scene || !launch || !hist_out) return fail(BF_ERR_INVALID, "null argument");
-    uint32_t nchan = bf_launch_channels(launch);
+    const uint64_t n_renders = batch ? batch->n_renders : 1u;
+    if (n_renders == 0) return fail(BF_ERR_INVALID, "bf_render_batch: n_renders is 0");
+    const uint64_t nchan = (uint64_t) bf_launch_channels(launch) * n_renders, n_rec = launch->n_paths * n_renders;
     if (nchan == 0) return fail(BF_ERR_INVALID, "unknown mode");
     float *d_hist = nullptr;
     bf_path_record *d_rec = nullptr;
     HIP_TRY(hipMalloc((void **) &d_hist, nchan * sizeof(float)));
     hipError_t e = hipMemset(d_hist, 0, nchan * sizeof(float));
-    if (e == hipSuccess && records_out && launch->n_paths)
-        e = hipMalloc((void **) &d_rec, launch->n_paths * sizeof(bf_path_record));
+    if (e == hipSuccess && records_out && n_rec)
+        e = hipMalloc((void **) &d_rec, n_rec * sizeof(bf_path_record));
     if (e != hipSuccess) {
         (void) hipFree(d_hist);
         return fail(BF_ERR_DEVICE, "bf_render: %s", hipGetErrorString(e));
     }
     bf_stats local;
-    bf_status st = bf_render_device(scene, launch, d_hist, d_rec, nullptr, stats_out ? stats_out : &local);
+    bf_status st = render_common(scene, launch, batch, d_hist, d_rec, nullptr, stats_out ? stats_out : &local);
     if (st == BF_OK) {
         e = hipMemcpy(hist_out, d_hist, nchan * sizeof(float), hipMemcpyDeviceToHost);
         if (e == hipSuccess && d_rec)
-            e = hipMemcpy(records_out, d_rec, launch->n_paths * sizeof(bf_path_record), hipMemcpyDeviceToHost);
+            e = hipMemcpy(records_out, d_rec, n_rec * sizeof(bf_path_record), hipMemcpyDeviceToHost);
         if (e != hipSuccess) st = fail(BF_ERR_DEVICE, "bf_render copy back: %s", hipGetErrorString(e));
     }
     (void) hipFree(d_hist);
     if (d_rec) (void) hipFree(d_rec);
     return st;
+}
+
+bf_status bf_render(const bf_scene *scene, const bf_launch *launch, float *hist_out, bf_path_record *records_out,
+                    bf_stats *stats_out) {
+    return render_host(scene, launch, nullptr, hist_out, records_out, stats_out);
+}
+
+bf_status bf_render_batch(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_out,
+                          bf_path_record *records_out, bf_stats *stats_out) {
+    if (!batch) return fail(BF_ERR_INVALID, "bf_render_batch: null batch");
+    return render_host(scene, launch, batch, hist_out, records_out, stats_out);
 }
 
 static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *rays, int any_hit, float *out_t,

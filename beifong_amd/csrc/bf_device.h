@@ -95,6 +95,7 @@ struct DScene {
     const float4 *wnodes;
     int32_t wroot;
     uint32_t n_wnodes;
+    uint32_t wrows_log;       // log2 of the most rows a gang may have: 16 * rows * depth stack entries must fit kWideStack
     const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
 };
 
@@ -110,6 +111,15 @@ struct DLaunch {
     uint32_t film_w, film_h;  // render modes: film size in pixels (>= 1)
     uint32_t spp;             // paths per pixel; 0 = single-pixel film (every path samples pixel 0)
     uint32_t chan_px;         // channels per pixel (n_chan = film_w * film_h * chan_px)
+    // Batched launch (bf_render_batch_device): `batch` renders of batch_paths paths each in ONE launch sequence.
+    // n_paths = batch * batch_paths global path indices g; render k = g / batch_paths renders its local path
+    // g - k * batch_paths with seed batch_seeds[k] into g_hist + k * n_chan, its meshes shifted by batch_offsets[k].
+    uint32_t batch;                 // 0: a plain launch
+    uint32_t n_chan_all;            // batch * n_chan (the LDS-privatised histogram covers all renders when it fits)
+    uint64_t batch_paths;
+    const uint64_t *batch_seeds;    // device [batch], or nullptr: `seed` for every render (common random numbers)
+    const float4 *batch_offsets;    // device [batch] (x, y, z, -), or nullptr: meshes as built
+    float box_slack;                // offsets only: node boxes widened by this much on the ray's side (bf_device_core.h: RayBox)
 };
 
 // device counters (uint64 each)

@@ -73,11 +73,15 @@ BF_DEV bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
 // adds an absolute error of ~6e-8 * |o| to the plane distances; node boxes are
 // padded by 2e-6 * max|coordinate| (bf_bvh.cpp), 30x that, so the test stays
 // conservative.  Box tests only decide WHICH triangles get tested, never a hit value.
-BF_DEV bool slab_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 id, V3 oid, float mint, float tmax,
+//
+// `oid` / `ohi`: the origin term of the lo planes and of the hi planes.  They are the same vector except in batched
+// launches with moving meshes (Shift below), where oid = -o/d - slack/d and ohi = -o/d + slack/d widen every box by
+// `slack` on the ray's side at no extra instruction.
+BF_DEV bool slab_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 id, V3 oid, V3 ohi, float mint, float tmax,
                      float &tn) {
-    float t0x = fmadd(lox, id.x, oid.x), t1x = fmadd(hix, id.x, oid.x);
-    float t0y = fmadd(loy, id.y, oid.y), t1y = fmadd(hiy, id.y, oid.y);
-    float t0z = fmadd(loz, id.z, oid.z), t1z = fmadd(hiz, id.z, oid.z);
+    float t0x = fmadd(lox, id.x, oid.x), t1x = fmadd(hix, id.x, ohi.x);
+    float t0y = fmadd(loy, id.y, oid.y), t1y = fmadd(hiy, id.y, ohi.y);
+    float t0z = fmadd(loz, id.z, oid.z), t1z = fmadd(hiz, id.z, ohi.z);
     tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                          __builtin_fmaxf(__builtin_fminf(t0z, t1z), mint));
     float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
@@ -99,6 +103,33 @@ BF_DEV void ray_inverse(V3 o, V3 d, V3 &id, V3 &oid) {
     id.y = __builtin_fminf(__builtin_fmaxf(id.y, -1.0e30f), 1.0e30f);
     id.z = __builtin_fminf(__builtin_fmaxf(id.z, -1.0e30f), 1.0e30f);
     oid = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+}
+
+// Mesh shift of a batched launch (bf_render_batch_device, DLaunch::batch_offsets): the render's meshes stand at
+// fl(p + d) — the very vertices bf_scene_translate_meshes stores, so hits are bit-equal to a render of the
+// translated scene — while the BVH stays as built.  For the box tests the RAY is moved the other way (o - d) and
+// every box is widened by `slack` on the ray's side (slab_fma): the roundings of o - d and of p + d move a plane by
+// at most 2^-23 (|o| + |d|) + 2^-24 (|p| + |d|), and the host sets slack = 1e-6 (scene bound + largest |d|), several
+// times that.  Box tests only select triangles.  `on` is wave-uniform.
+struct Shift {
+    bool on;
+    V3 d;
+    float slack;
+};
+BF_DEV Shift no_shift() { return Shift{false, mk(0.f, 0.f, 0.f), 0.f}; }
+BF_DEV Shift make_shift(const float4 *__restrict__ offsets, uint32_t render, float slack) {
+    if (!offsets) return no_shift();
+    const float4 q = offsets[render];
+    return Shift{true, mk(q.x, q.y, q.z), slack};
+}
+BF_DEV V3 shifted(V3 p, const Shift &sh) { return sh.on ? p + sh.d : p; }
+BF_DEV void ray_inverse_shift(V3 o, V3 d, const Shift &sh, V3 &id, V3 &oid, V3 &ohi) {
+    ray_inverse(sh.on ? o - sh.d : o, d, id, oid);
+    ohi = oid;
+    if (sh.on) {
+        oid = mk(fnmadd(sh.slack, id.x, oid.x), fnmadd(sh.slack, id.y, oid.y), fnmadd(sh.slack, id.z, oid.z));
+        ohi = mk(fmadd(sh.slack, id.x, ohi.x), fmadd(sh.slack, id.y, ohi.y), fmadd(sh.slack, id.z, ohi.z));
+    }
 }
 
 // Entry distance and child slot packed into one sortable word (distances are >= mint >= 0,
@@ -152,12 +183,12 @@ BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
 // stack entry, or kNoNode when the traversal is finished).
 template <class Stack>
 BF_DEV int node4_decide(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz,
-                        const float4 ch, V3 id, V3 oid, float mint, float tmax, Stack &st) {
+                        const float4 ch, V3 id, V3 oid, V3 ohi, float mint, float tmax, Stack &st) {
     float t0, t1, t2, t3;
-    const bool h0 = slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, mint, tmax, t0);
-    const bool h1 = slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, mint, tmax, t1);
-    const bool h2 = slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, mint, tmax, t2) && __float_as_int(ch.z) != kNoNode;
-    const bool h3 = slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, mint, tmax, t3) && __float_as_int(ch.w) != kNoNode;
+    const bool h0 = slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, ohi, mint, tmax, t0);
+    const bool h1 = slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, ohi, mint, tmax, t1);
+    const bool h2 = slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, ohi, mint, tmax, t2) && __float_as_int(ch.z) != kNoNode;
+    const bool h3 = slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, ohi, mint, tmax, t3) && __float_as_int(ch.w) != kNoNode;
     const uint32_t k0 = child_key(h0, t0, 0u), k1 = child_key(h1, t1, 1u), k2 = child_key(h2, t2, 2u), k3 = child_key(h3, t3, 3u);
     // 5-comparator sorting network
     const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
@@ -170,10 +201,10 @@ BF_DEV int node4_decide(const float4 lx, const float4 ly, const float4 lz, const
     return st.pop_or_none();
 }
 template <class Stack>
-BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, float mint, float tmax, Stack &st) {
+BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, V3 ohi, float mint, float tmax, Stack &st) {
     const float4 *np = nodes + 8u * (uint32_t) node;
     const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
-    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, mint, tmax, st);
+    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, ohi, mint, tmax, st);
 }
 
 // The top of the tree — its first n_top nodes, breadth-first (bf_bvh.h: kTopNodes) — is walked by every ray; a
@@ -191,7 +222,7 @@ BF_DEV void load_top_nodes(const float4 *__restrict__ nodes, uint32_t n_top, flo
     }
 }
 template <class Stack>
-BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, int n_top, int node, V3 id, V3 oid, float mint,
+BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, int n_top, int node, V3 id, V3 oid, V3 ohi, float mint,
                           float tmax, Stack &st) {
     float4 lx, ly, lz, hx, hy, hz, ch;
     if (node < n_top) {
@@ -204,12 +235,13 @@ BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, i
         const float4 *np = nodes + 8u * (uint32_t) node;
         lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
     }
-    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, mint, tmax, st);
+    return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, ohi, mint, tmax, st);
 }
 
 // all triangles of one leaf; returns true when an any-hit query is decided
 template <bool STATS>
-BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, uint32_t &n_tris) {
+BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, uint32_t &n_tris,
+                           const Shift &sh = no_shift()) {
     const uint32_t enc = ~(uint32_t) node;
     const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
@@ -217,7 +249,7 @@ BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, flo
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) ++n_tris;
         float t, u, v;
-        if (tri_intersect(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, mint, maxt, t, u, v)) {
+        if (tri_intersect(shifted(mk(a.x, a.y, a.z), sh), shifted(mk(b.x, b.y, b.z), sh), shifted(mk(c.x, c.y, c.z), sh), o, d, mint, maxt, t, u, v)) {
             if (any) return true;
             consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (first + i));
         }
@@ -231,7 +263,7 @@ BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, flo
 // wave (closest-hit and any-hit queries share the traversal loop).
 template <bool STATS, bool SPILL>
 BF_DEV bool traverse_dyn(const DScene &sc, bool any, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
-                         uint32_t &n_tris) {
+                         uint32_t &n_tris, const Shift &sh = no_shift()) {
     best.t = BF_INF;
     best.u = best.v = 0.f;
     best.prim = 0;
@@ -247,16 +279,16 @@ BF_DEV bool traverse_dyn(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     }
     if (sc.n_tris == 0) return best.t != BF_INF;
 
-    V3 id, oid;
-    ray_inverse(o, d, id, oid);
+    V3 id, oid, ohi;
+    ray_inverse_shift(o, d, sh, id, oid, ohi);
     LaneStack<kStackDepth, SPILL> st = make_stack<kStackDepth, SPILL>(sc, stack);
     int node = sc.root;
     while (node != kNoNode) {
         if (node >= 0) {
             if (STATS) ++n_nodes;
-            node = node4_step(sc.nodes, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
+            node = node4_step(sc.nodes, node, id, oid, ohi, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
         } else {
-            if (leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, n_tris)) return true;
+            if (leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, n_tris, sh)) return true;
             node = st.pop_or_none();
         }
     }
@@ -294,7 +326,7 @@ BF_DEV void quad_merge_hit(Hit &best) {
 
 template <bool STATS, bool SPILL>
 BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, float mint, float maxt, int *lds_leader_column,
-                          Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris) {
+                          Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris, const Shift &sh = no_shift()) {
     const int lane = threadIdx.x & 63, q = lane & 3, base = lane & ~3;
     best.t = BF_INF;
     best.u = best.v = 0.f;
@@ -320,8 +352,8 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
         quad_merge_hit(best);
     }
     int node = (active && !found && sc.n_tris != 0) ? sc.root : kNoNode;
-    V3 id, oid;
-    ray_inverse(o, d, id, oid);
+    V3 id, oid, ohi;
+    ray_inverse_shift(o, d, sh, id, oid, ohi);
     LaneStack<kStackDepth, SPILL> st;
     st.lds = lds_leader_column;
     st.spill = sc.spill + ((size_t) blockIdx.x * kBlock + (threadIdx.x & ~3u));
@@ -335,7 +367,7 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
             const int child = __float_as_int(nf[24 + q]);
             float tn;
             const float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
-            const bool h = slab_fma(lox, loy, loz, hix, hiy, hiz, id, oid, mint, tmax, tn) && child != kNoNode;
+            const bool h = slab_fma(lox, loy, loz, hix, hiy, hiz, id, oid, ohi, mint, tmax, tn) && child != kNoNode;
             const uint32_t key = child_key(h, tn, (uint32_t) q);
             const uint32_t k0 = quad_bcast<0>(key), k1 = quad_bcast<1>(key), k2 = quad_bcast<2>(key), k3 = quad_bcast<3>(key);
             const int c0 = quad_bcast<0>(child), c1 = quad_bcast<1>(child), c2 = quad_bcast<2>(child), c3 = quad_bcast<3>(child);
@@ -367,7 +399,8 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 if (STATS) ++n_tris;
                 float t, u, v;
-                if (tri_intersect(mk(ta.x, ta.y, ta.z), mk(tb.x, tb.y, tb.z), mk(tc.x, tc.y, tc.z), o, d, mint, maxt, t, u, v)) {
+                if (tri_intersect(shifted(mk(ta.x, ta.y, ta.z), sh), shifted(mk(tb.x, tb.y, tb.z), sh), shifted(mk(tc.x, tc.y, tc.z), sh), o, d,
+                                  mint, maxt, t, u, v)) {
                     tri_hit = true;
                     consider(best, t, u, v, __float_as_uint(ta.w), (int32_t) (first + i));
                 }
@@ -424,12 +457,27 @@ struct RowProf {
 #define BF_ROWPROF_ARG
 #define BF_ROWPROF_STAMP(v)
 #endif
+// hit exchange between the rows of a gang (lane ^ 16, lane ^ 32): executed by every lane of the wave
+template <int XOR> BF_DEV void gang_merge_step(Hit &best) {
+    const float t = __shfl_xor(best.t, XOR), u = __shfl_xor(best.u, XOR), v = __shfl_xor(best.v, XOR);
+    const uint32_t prim = (uint32_t) __shfl_xor((int) best.prim, XOR);
+    const int32_t slot = __shfl_xor(best.slot, XOR);
+    if (t != BF_INF) consider(best, t, u, v, prim, slot);
+}
+
+// `rlog`: log2 of the rows per ray (wave-uniform): a gang of 1, 2 or 4 rows shares one ray, one stack (in the LDS
+// columns of its first row) and one best hit, and pops up to that many stack entries per step — the serial depth of a
+// lone ray drops from "every node it visits" towards the depth of the tree, at the price of a little less culling.
+// All lanes of a gang pass the same ray.
 template <bool STATS>
-BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, float mint, float maxt, int *lds_block_stack,
-                           Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris BF_ROWPROF_ARG) {
+BF_DEV void traverse_row16(const DScene &sc, uint32_t rlog, bool active, bool any, V3 o, V3 d, float mint, float maxt,
+                           int *lds_block_stack, Hit &best, bool &found, uint32_t &n_nodes, uint32_t &n_tris, const Shift &sh BF_ROWPROF_ARG) {
     BF_ROWPROF_STAMP(rp_t0);
-    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, row_shift = lane & 48u;
-    int *const stk = lds_block_stack + (threadIdx.x & ~15u);      // + (e >> 4) * kBlock + (e & 15)
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u;
+    const uint32_t rows = 1u << rlog, row = (lane >> 4) & (rows - 1u);          // this lane's row inside its gang
+    const uint32_t gang_shift = lane & ~(16u * rows - 1u) & 63u;                // first lane of the gang
+    const unsigned long long gang_mask = rows == 4u ? ~0ull : ((1ull << (16u * rows)) - 1ull);
+    int *const stk = lds_block_stack + (threadIdx.x & ~(16u * rows - 1u));    // + (e >> 4) * kBlock + (e & 15)
     best.t = BF_INF;
     best.u = best.v = 0.f;
     best.prim = 0;
@@ -437,7 +485,7 @@ BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, 
     found = false;
     bool rect_hit = false;
     if (active) {
-        for (uint32_t i = j; i < sc.n_rects; i += 16u) {
+        for (uint32_t i = j + 16u * row; i < sc.n_rects; i += 16u * rows) {
             const DRect &rc = sc.rects[i];
             float t, lx, ly;
             if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
@@ -448,20 +496,30 @@ BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, 
     }
     {
         const unsigned long long m = __ballot(rect_hit);
-        if ((m >> row_shift) & 0xFFFFull) {
-            if (any) found = true;
+        if (m) {                                   // wave-uniform: some gang has a rectangle hit
+            if (any && ((m >> gang_shift) & gang_mask)) found = true;
             row_merge_hit(best);
+            if (rlog >= 1u) gang_merge_step<16>(best);
+            if (rlog >= 2u) gang_merge_step<32>(best);
         }
     }
-    int node = (active && !found && sc.n_tris != 0) ? sc.wroot : kNoNode;
-    V3 id, oid;
-    ray_inverse(o, d, id, oid);
-    int sp = 0;
+    V3 id, oid, ohi;
+    ray_inverse_shift(o, d, sh, id, oid, ohi);
+    int sp = (active && !found && sc.n_tris != 0) ? 1 : 0;
+    if (sp && row == 0u && j == 0u) stk[0] = sc.wroot;
 #ifdef BF_TAIL_PROF
     rp.rect += __builtin_amdgcn_s_memtime() - rp_t0;
 #endif
-    while (__ballot(node != kNoNode)) {
+    while (__ballot(sp > 0)) {
         BF_ROWPROF_STAMP(rp_t1);
+        // ---- pop: row r of the gang takes the r-th entry from the top ---------------------------
+        const int n_take = min((int) rows, sp);
+        int node = kNoNode;
+        if ((int) row < n_take) {
+            const int e = sp - 1 - (int) row;
+            node = stk[(e >> 4) * kBlock + (e & 15)];
+        }
+        sp -= n_take;
         const bool is_node = node >= 0, is_leaf = node < 0 && node != kNoNode;
         // ---- one batch of loads per row: child box j, or triangle j of the leaf ----------------
         const uint32_t enc = ~(uint32_t) node;
@@ -485,50 +543,56 @@ BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BF_ROWPROF_STAMP(rp_t2);
 #endif
+        bool h = false, tri_hit = false;
+        int child = kNoNode;
+        uint32_t rank = 0;
         if (is_node) {
             if (STATS && j == 0u) ++n_nodes;
-            const int child = __float_as_int(qb.z);
+            child = __float_as_int(qb.z);
             float tn;
             const float tmax = any ? maxt : __builtin_fminf(maxt, best.t);
-            const bool h = slab_fma(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, id, oid, mint, tmax, tn) && child != kNoNode;
+            h = slab_fma(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, id, oid, ohi, mint, tmax, tn) && child != kNoNode;
             // distinct sortable keys: entry distance (non-negative: bit pattern orders like the value), child slot in the low bits
             const uint32_t key = h ? ((min(__float_as_uint(tn), 0x7f000000u) & ~15u) | j) : 0xffffffffu;
-            uint32_t rank = 0;
 #define BF_RANK(N) rank += row_ror<N>(key) < key ? 1u : 0u;
             BF_RANK(1) BF_RANK(2) BF_RANK(3) BF_RANK(4) BF_RANK(5) BF_RANK(6) BF_RANK(7) BF_RANK(8)
             BF_RANK(9) BF_RANK(10) BF_RANK(11) BF_RANK(12) BF_RANK(13) BF_RANK(14) BF_RANK(15)
 #undef BF_RANK
-            const uint32_t n_hit = (uint32_t) __popcll((__ballot(h) >> row_shift) & 0xFFFFull);
-            // far-to-near: the nearest child ends up on top and is popped right away
+        }
+        if (is_leaf && ld) {
+            if (STATS) ++n_tris;
+            float t, u, v;
+            if (tri_intersect(shifted(mk(qa.x, qa.y, qa.z), sh), shifted(mk(qb.x, qb.y, qb.z), sh), shifted(mk(qc.x, qc.y, qc.z), sh), o, d, mint,
+                              maxt, t, u, v)) {
+                tri_hit = true;
+                consider(best, t, u, v, __float_as_uint(qa.w), (int32_t) (first + j));
+            }
+        }
+        // ---- all lanes again: triangle hits are merged over the gang, hit children pushed far-to-near ----
+        const unsigned long long tm = __ballot(tri_hit);
+        if (tm) {
+            if (any && ((tm >> gang_shift) & gang_mask)) found = true;
+            row_merge_hit(best);
+            if (rlog >= 1u) gang_merge_step<16>(best);
+            if (rlog >= 2u) gang_merge_step<32>(best);
+        }
+        const unsigned long long hm = (__ballot(h) >> gang_shift) & gang_mask;
+        if (hm) {
+            // the row that popped the top entry (row 0) pushes last, so the nearest child of the nearest node ends on top
+            uint32_t above = 0, mine = 0, total = 0;
+            for (uint32_t r = 0; r < rows; ++r) {
+                const uint32_t c = (uint32_t) __popcll((hm >> (16u * r)) & 0xFFFFull);
+                total += c;
+                above += r > row ? c : 0u;
+                mine = r == row ? c : mine;
+            }
             if (h) {
-                const int e = sp + (int) (n_hit - 1u - rank);
+                const int e = sp + (int) (above + mine - 1u - rank);
                 stk[(e >> 4) * kBlock + (e & 15)] = child;
             }
-            sp += (int) n_hit;
+            sp += (int) total;
         }
-        if (is_leaf) {
-            bool tri_hit = false;
-            if (ld) {
-                if (STATS) ++n_tris;
-                float t, u, v;
-                if (tri_intersect(mk(qa.x, qa.y, qa.z), mk(qb.x, qb.y, qb.z), mk(qc.x, qc.y, qc.z), o, d, mint, maxt, t, u, v)) {
-                    tri_hit = true;
-                    consider(best, t, u, v, __float_as_uint(qa.w), (int32_t) (first + j));
-                }
-            }
-            if ((__ballot(tri_hit) >> row_shift) & 0xFFFFull) {
-                if (any) found = true;
-                row_merge_hit(best);
-            }
-        }
-        if (is_node || is_leaf) {
-            if (found || sp == 0) {
-                node = kNoNode;
-            } else {
-                --sp;
-                node = stk[(sp >> 4) * kBlock + (sp & 15)];
-            }
-        }
+        if (found) sp = 0;
 #ifdef BF_TAIL_PROF
         {
             const unsigned long long rp_t3 = __builtin_amdgcn_s_memtime();
@@ -542,8 +606,8 @@ BF_DEV void traverse_row16(const DScene &sc, bool active, bool any, V3 o, V3 d, 
 
 template <bool ANY, bool STATS, bool SPILL>
 BF_DEV bool traverse(const DScene &sc, V3 o, V3 d, float mint, float maxt, int *stack, Hit &best, uint32_t &n_nodes,
-                     uint32_t &n_tris) {
-    return traverse_dyn<STATS, SPILL>(sc, ANY, o, d, mint, maxt, stack, best, n_nodes, n_tris);
+                     uint32_t &n_tris, const Shift &sh = no_shift()) {
+    return traverse_dyn<STATS, SPILL>(sc, ANY, o, d, mint, maxt, stack, best, n_nodes, n_tris, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -570,7 +634,8 @@ struct SIGeom {
     V3 n, dp_du, dp_dv;
 };
 
-template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si, SIGeom *geom = nullptr) {
+template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si, SIGeom *geom = nullptr,
+                                                 const Shift &sh = no_shift()) {
     si.t = h.t;
     V3 dp_du;
     if (h.slot < 0) {
@@ -600,7 +665,7 @@ template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, c
         }
         float4 duv = make_float4(0, 0, 0, 0);   // (uv1 - uv0, uv2 - uv0), same speculation
         if (sc.uvs) duv = sc.uvs[h.slot];
-        V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
+        V3 p0 = shifted(mk(a.x, a.y, a.z), sh), p1 = shifted(mk(b.x, b.y, b.z), sh), p2 = shifted(mk(c.x, c.y, c.z), sh);
         si.shape = __float_as_uint(b.w);
         const uint32_t tag = __float_as_uint(c.w);
         si.material = tri_tag_material(tag);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
     const int lane = tid & 63;
     const bool lds_hist = lp.lds_hist != 0;
     if (lds_hist) {
-        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) s_hist[i] = 0.f;
+        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
     int *stack = s_stack + tid;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
     hit.slot = 0;
     PathState s;
     s.flags = 0;
+    s.render = 0u;                     // lanes without a path still index the batch tables (path_shift)
     s.rmint = 0.f;
     s.rmaxt = 0.f;
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
@@ -175,8 +176,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t my_cl_job = (uint32_t) __popcll(closest_mask & below);
             const uint32_t my_sh_job = n_cl + (uint32_t) __popcll(want_mask & below);
-            for (uint32_t base = 0; base < n_jobs; base += 4u) {
-                const uint32_t job = base + ((uint32_t) lane >> 4);
+            // a lone ray gets all four rows, two rays two rows each (gangs pop several stack entries per step)
+            const uint32_t rlog = min(n_jobs == 1u ? 2u : (n_jobs == 2u ? 1u : 0u), sc.wrows_log);
+            const uint32_t per_pass = 4u >> rlog, gshift = 4u + rlog;
+            for (uint32_t base = 0; base < n_jobs; base += per_pass) {
+                const uint32_t job = base + ((uint32_t) lane >> gshift);
                 const bool job_active = job < n_jobs;
                 const bool job_any = job >= n_cl;
                 int src = lane;
@@ -187,10 +191,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
                 const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
                 const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
+                const Shift jshift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
                 Hit qbest;
                 bool qfound;
-                traverse_row16<STATS>(sc, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
-                                      job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_nodes, c_tris
+                traverse_row16<STATS>(sc, rlog, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
+                                      job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_nodes, c_tris, jshift
 #ifdef BF_TAIL_PROF
                                       , pf_row
 #endif
@@ -199,11 +204,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 ++pf_rowpass;
 #endif
                 // deliver: closest hits to their lanes, occlusion verdicts to the requesters
-                const int cl_row = (int) (((my_cl_job - base) & 3u) << 4);
-                const float ht = __shfl(qbest.t, cl_row), hu = __shfl(qbest.u, cl_row), hv = __shfl(qbest.v, cl_row);
-                const int hs = __shfl(qbest.slot, cl_row);
-                const uint32_t hp = (uint32_t) __shfl((int) qbest.prim, cl_row);
-                if (trace_closest && my_cl_job >= base && my_cl_job < base + 4u) {
+                const int cl_lane = (int) (((my_cl_job - base) & (per_pass - 1u)) << gshift);
+                const float ht = __shfl(qbest.t, cl_lane), hu = __shfl(qbest.u, cl_lane), hv = __shfl(qbest.v, cl_lane);
+                const int hs = __shfl(qbest.slot, cl_lane);
+                const uint32_t hp = (uint32_t) __shfl((int) qbest.prim, cl_lane);
+                if (trace_closest && my_cl_job >= base && my_cl_job < base + per_pass) {
                     hit.t = ht;
                     hit.u = hu;
                     hit.v = hv;
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                     ++c_closest;
                 }
                 const unsigned long long occl_mask = __ballot(job_active && job_any && qfound);
-                if (sh.want && my_sh_job >= base && my_sh_job < base + 4u) {
-                    occluded = (occl_mask >> (((my_sh_job - base) & 3u) << 4)) & 1ull;
+                if (sh.want && my_sh_job >= base && my_sh_job < base + per_pass) {
+                    occluded = (occl_mask >> (((my_sh_job - base) & (per_pass - 1u)) << gshift)) & 1ull;
                     ++c_shadow;
                     // an occluded sample still contributes mis * throughput * bsdf * 0 (scene.cpp:220-224): c * 0
                     s.result += occluded ? sh.c * 0.f : sh.c;
@@ -236,10 +241,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
             const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
             const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
+            const Shift jshift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
             Hit qbest;
             bool qfound;
             traverse_quad<STATS, SPILL>(sc, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
-                                        job_any ? smaxt : cmaxt, s_stack + (tid & ~3), qbest, qfound, c_nodes, c_tris);
+                                        job_any ? smaxt : cmaxt, s_stack + (tid & ~3), qbest, qfound, c_nodes, c_tris, jshift);
             const unsigned long long below = (1ull << lane) - 1ull;
             // deliver: closest hits to their lanes, occlusion verdicts to the requesters
             const int my_cl_quad = (int) __popcll(closest_mask & below) * 4;
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             V3 ho = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
             V3 hd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
             const float hmint = __shfl(sh.mint, src), hmaxt = __shfl(sh.maxt, src);
+            const Shift own_shift = path_shift(lp, s.render), helper_shift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
             // first walk: closest-hit rays, delegated shadow rays (on their helpers), and the own shadow
             // ray of a lane that has no closest-hit ray to trace
             const bool own_first = sh.want && !delegated && !trace_closest;
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 V3 o1 = trace_closest ? s.ro : ho, d1 = trace_closest ? s.rd : hd;
                 float mint1 = trace_closest ? s.rmint : hmint, maxt1 = trace_closest ? s.rmaxt : hmaxt;
                 Hit h1;
-                r1 = traverse_dyn<STATS, SPILL>(sc, any1, o1, d1, mint1, maxt1, stack, h1, c_nodes, c_tris);
+                r1 = traverse_dyn<STATS, SPILL>(sc, any1, o1, d1, mint1, maxt1, stack, h1, c_nodes, c_tris,
+                                                trace_closest ? own_shift : helper_shift);
                 if (trace_closest) {
                     hit = h1;
                     ++c_closest;
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             if (__ballot(own_second)) {
                 if (own_second) {
                     Hit tmp;
-                    occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris);
+                    occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris, own_shift);
                     ++c_shadow;
                 }
             }
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
             sh.want = false;
         } else if (__ballot(trace_closest)) {
             if (trace_closest) {
-                traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris);
+                traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris, path_shift(lp, s.render));
                 ++c_closest;
             }
         }

@@ -35,7 +35,8 @@ struct PathState {
     uint32_t flags;      // depth | kFlag*
     uint32_t n_rays;
     Rng rng;
-    uint64_t path_i;
+    uint64_t path_i;     // index within the launch; batched launches: global index over all renders (render * batch_paths + local)
+    uint32_t render;     // batched launches: which render of the batch this path belongs to (0 otherwise)
     // gen-3 (receive) only
     float time;          // ray.time: retarded time carried along the path (ray.h:89-93)
     float t_rx;          // sampled receive time (integrator.cpp:1556-1561)
@@ -62,6 +63,7 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     s.rng.state = ((uint64_t) d.y << 32) | d.x;
     s.path_i = ((uint64_t) d.w << 32) | d.z;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
+    s.render = wf.render ? wf.render[i] : 0u;
     if (receive) {
         float4 e = wf.se[i];
         s.time = e.x;
@@ -78,7 +80,10 @@ BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState 
     wf.sd[j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
                           (uint32_t) (s.path_i >> 32));
     if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, s.phase);
+    if (wf.render) wf.render[j] = s.render;
 }
+// the mesh shift of the path's render (batched launches with moving meshes; off otherwise)
+BF_DEV Shift path_shift(const DLaunch &lp, uint32_t render) { return make_shift(lp.batch_offsets, render, lp.box_slack); }
 
 // ---------------------------------------------------------------------------
 // on-the-fly compaction: a cursor over a segment of 64-bit batch masks hands the
@@ -373,8 +378,16 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
 BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, PathState &s) {
     const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
     s.path_i = path_i;
+    s.render = 0u;
+    uint64_t seed = lp.seed;
+    if (lp.batch != 0u) {
+        // batched launch: global index -> (render, local path); every render is an ordinary render of its own seed
+        s.render = (uint32_t) (path_i / lp.batch_paths);
+        path_i -= (uint64_t) s.render * lp.batch_paths;
+        if (lp.batch_seeds) seed = lp.batch_seeds[s.render];
+    }
     // per-path stream: sampler->seed(base_seed + path) (sampler.cpp:83-96)
-    pcg_seed(s.rng, lp.seed + lp.path_offset + path_i);
+    pcg_seed(s.rng, seed + lp.path_offset + path_i);
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
     float ax = .5f, ay = .5f;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
@@ -476,7 +489,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     const bool si_valid = hit.t != BF_INF;
     int emitter = -1;
     if (si_valid) {
-        make_si(sc, s.ro, s.rd, hit, si);
+        make_si(sc, s.ro, s.rd, hit, si, nullptr, path_shift(lp, s.render));
         emitter = si.emitter;
     }
 #ifdef BF_TAIL_PROF
@@ -645,6 +658,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                      FilmAcc &acc, bf_path_record *records) {
     const bool valid = (s.flags & kFlagValid) != 0;
     float rec_L, rec_aux;
+    const uint32_t hb = lp.batch != 0u ? s.render * lp.n_chan : 0u;      // this render's block of the histogram
     if (lp.mode == BF_MODE_RECEIVE_RAW) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
@@ -682,7 +696,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
         ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
         if (ok) {
-            uint32_t off = (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
+            uint32_t off = hb + (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
             if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 0u, a0);
             if (a1 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 1u, a1);
             hist_add(s_hist, g_hist, lds_hist, off + 2u, 1.f);
@@ -713,7 +727,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
         // multi-pixel film: every channel of the sample goes to its pixel's block of the histogram; the 1 x 1 film
         // keeps the five base channels in registers until film_flush
-        uint32_t pix = 0u;
+        uint32_t pix = hb;
         if (lp.spp) {
             const uint64_t q = (lp.path_offset + s.path_i) / lp.spp;
             const uint32_t px = (uint32_t) (q % lp.film_w) - ((s.flags & kFlagFilmLeft) ? 1u : 0u);
@@ -727,6 +741,14 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 2u, Z);
                 if (valid) hist_add(s_hist, g_hist, lds_hist, pix + 3u, 1.f);
                 hist_add(s_hist, g_hist, lds_hist, pix + 4u, 1.f);
+            } else if (lp.batch != 0u) {
+                // batched launch: the wave's lanes hold paths of different renders, so the base channels cannot be
+                // summed in registers; each sample goes to its render's block
+                if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 0u, X);
+                if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 1u, Y);
+                if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 2u, Z);
+                if (valid) hist_add(s_hist, g_hist, lds_hist, hb + 3u, 1.f);
+                hist_add(s_hist, g_hist, lds_hist, hb + 4u, 1.f);
             } else {
                 acc.X += X;
                 acc.Y += Y;
@@ -783,7 +805,7 @@ BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_
             acc.A += __shfl_down(acc.A, off);
             acc.W += __shfl_down(acc.W, off);
         }
-        if (lane == 0 && acc.W != 0.f && !lp.spp) {
+        if (lane == 0 && acc.W != 0.f && !lp.spp && lp.batch == 0u) {
             hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
             hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
             hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);
@@ -793,7 +815,7 @@ BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_
     }
     if (lds_hist) {
         __syncthreads();
-        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
+        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) {
             float v = s_hist[i];
             if (v != 0.f) atomicAdd(&g_hist[i], v);
         }

@@ -42,6 +42,9 @@ struct WF {
     float4 *sh1;        // d.xyz, maxt
     float *sh2;         // contribution released when unoccluded
     float *sh3;         // BF_MODE_RECEIVE_IQ: its imaginary part
+    uint32_t *render;   // batched launches: render index of the slot's current path (selects the mesh offset)
+    const float4 *offsets;   // batched launches with moving meshes: DLaunch::batch_offsets (wf_trace has no DLaunch)
+    float box_slack;
     // batch masks, double buffered by bounce parity: [2][n_slots / 64]
     unsigned long long *m_alive[2];
     unsigned long long *m_trace[2];

@@ -46,7 +46,7 @@ BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, uint32_t batc
 // their starting point), which keeps that kernel's waves filled with comparable
 // work instead of mixing 3-step misses with 60-step hits.
 //   returns true if the ray still needs BVH traversal
-BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, bool &found) {
+BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, bool &found, const Shift &shf) {
     best.t = BF_INF;
     best.u = best.v = 0.f;
     best.prim = 0;
@@ -67,13 +67,13 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     if (sc.root < 0) return true;                 // the whole mesh is one leaf
     const float4 *np = sc.nodes + 8u * (uint32_t) sc.root;
     const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
-    V3 id, oid;
-    ray_inverse(o, d, id, oid);
+    V3 id, oid, ohi;
+    ray_inverse_shift(o, d, shf, id, oid, ohi);
     float tmax = any ? maxt : __builtin_fminf(maxt, best.t), tn;
-    return slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, mint, tmax, tn) ||
-           slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, mint, tmax, tn) ||
-           (__float_as_int(ch.z) != kNoNode && slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, mint, tmax, tn)) ||
-           (__float_as_int(ch.w) != kNoNode && slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, mint, tmax, tn));
+    return slab_fma(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, id, oid, ohi, mint, tmax, tn) ||
+           slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, ohi, mint, tmax, tn) ||
+           (__float_as_int(ch.z) != kNoNode && slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, ohi, mint, tmax, tn)) ||
+           (__float_as_int(ch.w) != kNoNode && slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, ohi, mint, tmax, tn));
 }
 
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     const int tid = threadIdx.x, lane = tid & 63;
     const bool lds_hist = lp.lds_hist != 0;
     if (lds_hist) {
-        for (uint32_t i = tid; i < lp.n_chan; i += kBlock) s_hist[i] = 0.f;
+        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
     const int cur = it & 1, nxt = cur ^ 1;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         const uint32_t batch0 = slot >> 6;
 
         PathState s;
+        s.render = 0u;                 // lanes without a path still index the batch tables (path_shift)
         ShadowReq sh;
         sh.want = false;
         bool need_gen = false, cont = false, have_hit = false;
@@ -194,10 +195,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             if (!settled) {
                 tracing = cont && !(s.flags & kFlagTermPending);
                 shadowing = cont && sh.want;
+                const Shift shf = path_shift(lp, s.render);
                 if (shadowing) {
                     Hit tmp;
                     bool found;
-                    if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found)) {
+                    if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found, shf)) {
                         // Scene::sample_emitter_direction zeroes the VALUE of an occluded sample (scene.cpp:220-224) and
                         // the integrator still adds mis * throughput * bsdf * 0: a NaN / inf BSDF value survives that
                         // product.  c * 0 is that term (+-0 for every finite c).
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 }
                 if (tracing) {
                     bool found;
-                    tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found);
+                    tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found, shf);
                 }
             }
             // ---- chain or settle ----------------------------------------------------------------
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 // 32 lifts the kernel from 5 to 8 waves/SIMD.
 constexpr int kLdsStack = 16;
 
-template <bool STATS, int W>
+template <bool STATS, int W, bool SHIFT>
 __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t it) {
     __shared__ int s_stack[kLdsStack * kBlock];
     __shared__ float4 s_top[kTopNodes * kTopStride];
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
 
     bool has = false, any = false;
     uint32_t job = 0;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), id = mk(0, 0, 0), oid = mk(0, 0, 0);
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), id = mk(0, 0, 0), oid = mk(0, 0, 0), ohi = mk(0, 0, 0);
+    Shift shf = no_shift();          // SHIFT: batched launch with moving meshes (the ray's render selects the offset)
     float mint = 0.f, maxt = 0.f;
     Hit best;
     best.t = BF_INF;
@@ -373,7 +376,12 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                         best.slot = __float_as_int(hq.w);
                         best.prim = wf.hit_prim[slot];
                     }
-                    ray_inverse(o, d, id, oid);
+                    if (SHIFT) {
+                        shf = make_shift(wf.offsets, wf.render[slot], wf.box_slack);
+                        ray_inverse_shift(o, d, shf, id, oid, ohi);
+                    } else {
+                        ray_inverse(o, d, id, oid);
+                    }
                     node = sc.root;
                     st.sp = 0;
                 }
@@ -406,12 +414,14 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                         ++c_nodes;
                         c_top += node < n_top ? 1u : 0u;
                     }
-                    node = node4_step_top(sc.nodes, s_top, n_top, node, id, oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
+                    node = node4_step_top(sc.nodes, s_top, n_top, node, id, oid, SHIFT ? ohi : oid, mint,
+                                          any ? maxt : __builtin_fminf(maxt, best.t), st);
                 }
             }
             // (b) intersect the postponed leaves together
             if (has && node < 0 && node != kNoNode) {
-                found = leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, c_tris);
+                found = SHIFT ? leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, c_tris, shf)
+                              : leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, c_tris);
                 node = found ? kNoNode : st.pop_or_none();
             }
             // (c) retire finished rays
@@ -484,11 +494,17 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 
 extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
                                    hipStream_t stream, int waves) {
-#define BF_TRACE_LAUNCH(W)                                                                                          \
-    if (stats)                                                                                                      \
-        hipLaunchKernelGGL((bfd::wf_trace<true, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);        \
-    else                                                                                                            \
-        hipLaunchKernelGGL((bfd::wf_trace<false, W>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
+    const bool shift = wf->offsets != nullptr;
+#define BF_TRACE_LAUNCH(W)                                                                                              \
+    if (shift) {                                                                                                        \
+        if (stats)                                                                                                      \
+            hipLaunchKernelGGL((bfd::wf_trace<true, W, true>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((bfd::wf_trace<false, W, true>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it); \
+    } else if (stats)                                                                                                   \
+        hipLaunchKernelGGL((bfd::wf_trace<true, W, false>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);     \
+    else                                                                                                                \
+        hipLaunchKernelGGL((bfd::wf_trace<false, W, false>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
     // 28.6 KiB of LDS per workgroup (stacks + the tree's top levels): five workgroups per CU is the most that fit
     if (waves >= 5) {
         BF_TRACE_LAUNCH(5);

@@ -78,48 +78,72 @@ def _shard_launch(launch, off, cnt):
 
 
 class PulseSweeper:
-    """Device-resident state of a pulse sweep: `n_streams` scene handles (one BVH build and one path pool each) and
-    their HIP streams, kept across sweeps — the second sweep of the same scene pays no build, no allocation and no
-    host synchronisation (the handles' launch plans are learnt by the first one).  See render_pulse_sweep."""
+    """Device-resident state of a pulse sweep: ONE scene (one BVH build) and `n_streams` HIP streams, kept across
+    sweeps.  The pulses of a sweep are rendered as `n_streams` BATCHES (bf_render_batch_device): each batch is one
+    launch sequence over its pulses — the pulse's mesh offset is added to the triangles on the fly and the cube is
+    accumulated with atomics — so a sweep pays one latency-bound tail per batch instead of one per pulse, and the
+    batches' tails overlap each other's heads.  See render_pulse_sweep."""
 
-    def __init__(self, sd, launch, n_streams=3, lib=None, device=None):
+    def __init__(self, sd, launch, n_streams=2, lib=None, device=None):
         import torch
         self.lib = lib or capi.load_library()
         self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.launch = launch
         self.n_streams = max(1, int(n_streams))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n_streams)]
-        self.handles = [capi.Scene(sd, self.lib) for _ in range(self.n_streams)]
+        # one handle per stream: a handle owns the path pool its renders run in (the BVH build is shared work only
+        # through bf_scene_clone, see capi.Scene.clone)
+        first = capi.Scene(sd, self.lib)
+        self.handles = [first] + [first.clone() for _ in range(self.n_streams - 1)]
         self.n_chan = self.handles[0].channels(launch)
 
-    def render(self, offsets, group=None):
-        """float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W) for target offsets float[n_pulses, 3]."""
+    def render(self, offsets, group=None, per_pulse=False):
+        """float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W) for target offsets float[n_pulses, 3].
+        per_pulse=True renders pulse by pulse (bf_scene_translate_meshes + one render each): the round-1 path, kept
+        as the reference the batched path is tested against."""
         import torch
         import torch.distributed as tdist
         from .dist import render_cube_sharded
-        offsets = np.asarray(offsets, dtype=np.float32).reshape(-1, 3)
+        offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.float32).reshape(-1, 3))
+        n = len(offsets)
 
         def render(path_off, count, cube):
             lp = _shard_launch(self.launch, path_off, count)
-            for k, off in enumerate(offsets):
-                j = k % self.n_streams
-                with torch.cuda.stream(self.streams[j]):
-                    self.handles[j].translate_meshes(off, stream=self.streams[j].cuda_stream)
-                    self.handles[j].render_device(lp, cube[k].data_ptr(), stream=self.streams[j].cuda_stream)
+            # the cube was zero-filled on the current stream: the side streams must not start before that
+            for s in self.streams:
+                s.wait_stream(torch.cuda.current_stream(self.dev))
+            if per_pulse:
+                for k, off in enumerate(offsets):
+                    j = k % self.n_streams
+                    with torch.cuda.stream(self.streams[j]):
+                        self.handles[j].translate_meshes(off, stream=self.streams[j].cuda_stream)
+                        self.handles[j].render_device(lp, cube[k].data_ptr(), stream=self.streams[j].cuda_stream)
+                for j in range(self.n_streams):         # leave the handles as built
+                    with torch.cuda.stream(self.streams[j]):
+                        self.handles[j].translate_meshes((0.0, 0.0, 0.0), stream=self.streams[j].cuda_stream)
+            else:
+                bounds = [n * j // self.n_streams for j in range(self.n_streams + 1)]
+                for j in range(self.n_streams):
+                    k0, k1 = bounds[j], bounds[j + 1]
+                    if k1 == k0:
+                        continue
+                    with torch.cuda.stream(self.streams[j]):
+                        self.handles[j].render_batch_device(lp, k1 - k0, cube[k0].data_ptr(), offsets=offsets[k0:k1],
+                                                            stream=self.streams[j].cuda_stream)
             for s in self.streams:
                 s.synchronize()
 
-        cube, _ = render_cube_sharded(render, int(self.launch.n_paths), (len(offsets), self.n_chan), device=self.dev,
+        cube, _ = render_cube_sharded(render, int(self.launch.n_paths), (n, self.n_chan), device=self.dev,
                                       group=group if tdist.is_initialized() else None)
-        return cube.cpu().numpy().reshape(len(offsets), -1, 3)
+        return cube.cpu().numpy().reshape(n, -1, 3)
 
     def close(self):
-        for h in self.handles:
+        for h in reversed(self.handles):
             h.close()
         self.handles = []
 
 
-def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None, group=None):
+def render_pulse_sweep(sd, launch, offsets, n_streams=2, lib=None, device=None, group=None):
     """Coherent pulse sweep over a rigidly moving target (BASELINE configs[4]).
 
     `sd`      scene description whose meshes are the target (rectangles — ground, antennas — stay put);
@@ -127,8 +151,8 @@ def render_pulse_sweep(sd, launch, offsets, n_streams=3, lib=None, device=None, 
               path keeps its geometry from pulse to pulse and only its optical length — its phase — moves;
     `offsets` float[n_pulses, 3]: target offset of each pulse, relative to the scene as built.
 
-    The BVH is built once per stream handle and re-fitted per pulse on the device
-    (bf_scene_translate_meshes); pulses rotate over the streams.  Returns the slow-time x fast-time
+    The BVH is built once; the pulses are rendered in `n_streams` batches (bf_render_batch_device: the pulse's offset
+    is applied to the triangles on the fly, every path bit-identical to a render of the translated scene).  Returns the slow-time x fast-time
     cube float32[n_pulses, f_bins * t_bins, 3] of (I, Q, W).  One-shot form of PulseSweeper (which keeps the
     handles for further sweeps).
 

@@ -20,8 +20,9 @@
  *
  * Ownership: the caller owns every input array for the duration of
  * bf_scene_create (they are deep-copied to the device) and owns every output
- * buffer.  A bf_scene is immutable after creation and may be shared by
- * threads; bf_render is re-entrant per (scene, stream).
+ * buffer.  A bf_scene handle runs ONE render at a time (it owns the path pool
+ * the render's state lives in); concurrent renders of one scene on several
+ * streams use one handle each — bf_scene_clone shares the geometry.
  *
  * Conventions: all arithmetic fp32, indices uint32, RNG state uint64.
  * Matrices are row-major float[16].  Spectra are a single grey lane (all
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 1
+#define BF_ABI_VERSION 2
 
 typedef int bf_status;
 enum {
@@ -298,6 +299,17 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
 bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void *stream);
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info);
 
+/* A second handle on the same scene for another stream: the big read-only arrays (BVH, triangles,
+ * normals, texture coordinates) are SHARED with `scene` and freed with the last handle; the clone
+ * has its own endpoint tables (rectangles, emitters / transmitters, sensor / receiver, materials —
+ * bf_scene_update_endpoints on one handle does not touch the others), its own path pool and
+ * counters, so renders on different handles may run concurrently on different streams.  The
+ * reference shares one Scene object between its worker threads the same way
+ * (src/librender/integrator.cpp:125-159: every thread renders blocks of the same scene).
+ * bf_scene_translate_meshes on a handle that shares its geometry copies on write.  A clone of a
+ * scene that has been translated starts from the geometry that scene renders at that moment. */
+bf_status bf_scene_clone(const bf_scene *scene, bf_scene **out);
+
 /* number of floats the given launch accumulates into: 5 (+bins | +3*bins) for
  * the 1x1 film modes, f_bins*t_bins*3 ([y=f][x=t][Y,A,W]) for receive */
 uint32_t bf_launch_channels(const bf_launch *launch);
@@ -315,6 +327,34 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch,
 bf_status bf_render(const bf_scene *scene, const bf_launch *launch,
                     float *hist_out, bf_path_record *records_out,
                     bf_stats *stats_out);
+
+/* MANY renders of one scene in ONE launch sequence: the frames of a sweep, the pulses of a
+ * coherent processing interval, the shards of a sharded render.  The reference runs such loops
+ * one render() / receive() call per frame and rebuilds the scene in between
+ * (python_scripts/animated_trans_rad.py:307-384, Receive.ipynb cell 30; the sample loop itself
+ * is src/librender/integrator.cpp:659-663); on the GPU every render ends in a latency-bound tail
+ * of a few long paths, so K renders issued one by one pay K tails.  Here render k of
+ * batch->n_renders is an ordinary render of `launch` (same n_paths, path_offset, mode, bins)
+ *   - with sampler seed batch->seeds[k]          (NULL: launch->seed for every render — common
+ *                                                 random numbers, what a coherent sweep wants),
+ *   - with all meshes at batch->mesh_offsets[3k..] (NULL: as built) — the vertices
+ *     bf_scene_translate_meshes(offset) would store, added on the fly while the BVH stays put,
+ *   - accumulating into hist + k * bf_launch_channels(launch),
+ * and every path of every render is bit-identical to that stand-alone render.  Path records
+ * (optional) are [n_renders][n_paths].  Multi-pixel films are not batched.  The arrays of
+ * `batch` are host memory and are free again when the call returns. */
+typedef struct bf_batch {
+    uint32_t n_renders;
+    const uint64_t *seeds;        /* [n_renders] or NULL                         */
+    const float *mesh_offsets;    /* [n_renders][3] metres, or NULL              */
+} bf_batch;
+bf_status bf_render_batch_device(const bf_scene *scene, const bf_launch *launch,
+                                 const bf_batch *batch, float *hist_dev,
+                                 bf_path_record *records_dev, void *stream,
+                                 bf_stats *stats_out);
+bf_status bf_render_batch(const bf_scene *scene, const bf_launch *launch,
+                          const bf_batch *batch, float *hist_out,
+                          bf_path_record *records_out, bf_stats *stats_out);
 
 /* Scene::ray_intersect / ray_test over a batch of HOST rays (tests, tools).
  * rays: [n][8] = o.xyz, mint, d.xyz, maxt.  Outputs may be NULL.

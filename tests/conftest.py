@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:
+    # torch's libamdhip64 must be the one HIP runtime of the process: load it before libbeifong_hip.so (a test file that
+    # touches the product library first and torch later otherwise sees "No HIP GPUs are available")
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

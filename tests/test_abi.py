@@ -28,22 +28,22 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(capi.LIB_PATH)
     for name in capi.EXPORTED_SYMBOLS:
         assert hasattr(lib, name), name
-    assert lib.bf_version() == 1
+    assert lib.bf_version() == capi.BF_ABI_VERSION
 
 
 def test_struct_sizes_match_header():
     # compile a tiny C program against the header and compare sizeof()
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "beifong_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include "beifong_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(bf_material),sizeof(bf_shape),sizeof(bf_emitter),sizeof(bf_sensor),sizeof(bf_scene_desc),' \
-          'sizeof(bf_launch),sizeof(bf_path_record),sizeof(bf_stats),sizeof(bf_scene_info));return 0;}'
+          'sizeof(bf_launch),sizeof(bf_path_record),sizeof(bf_stats),sizeof(bf_scene_info),sizeof(bf_batch));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()
     sizes = [C.sizeof(t) for t in (capi.bf_material, capi.bf_shape, capi.bf_emitter, capi.bf_sensor, capi.bf_scene_desc,
-                                   capi.bf_launch, capi.bf_path_record, capi.bf_stats, capi.bf_scene_info)]
+                                   capi.bf_launch, capi.bf_path_record, capi.bf_stats, capi.bf_scene_info, capi.bf_batch)]
     assert [int(x) for x in out] == sizes
 
 

@@ -14,7 +14,7 @@ sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=n_paths, t_bins=1024, dr=0.0
                             lambda_band_nm=(lam0 * 0.999, lam0 * 1.001))
 lp.mode = capi.BF_MODE_RECEIVE_IQ
 offsets = (np.arange(n_pulses)[:, None] * pri * v[None, :]).astype(np.float32)
-sweep.render_pulse_sweep(sd, lp, offsets[:3], n_streams=3)          # warm-up (library, allocator)
+sweep.render_pulse_sweep(sd, lp, offsets[:3], n_streams=2)          # warm-up (library, allocator)
 t = time.time()
 h = capi.Scene(sd)
 print(f"one scene build (BVH + upload): {(time.time() - t) * 1e3:.1f} ms", flush=True)
@@ -29,8 +29,17 @@ for n_streams in [int(x) for x in os.environ.get("STREAMS", "1,3").split(",")]:
         cube = sw.render(offsets)
         times.append(time.time() - t)
     sw.close()
-    print(f"streams={n_streams}: setup {t_setup * 1e3:.0f} ms ({n_streams} scene builds); {n_pulses} pulses x {n_paths} paths: first sweep "
-          f"{times[0] * 1e3:.1f} ms, then {min(times[1:]) * 1e3:.1f} ms = {min(times[1:]) / n_pulses * 1e3:.2f} ms per pulse", flush=True)
+    print(f"streams={n_streams}: setup {t_setup * 1e3:.0f} ms (one BVH build, {n_streams - 1} clones); {n_pulses} pulses x {n_paths} paths in "
+          f"{n_streams} batches: first sweep {times[0] * 1e3:.1f} ms, then {min(times[1:]) * 1e3:.1f} ms = {min(times[1:]) / n_pulses * 1e3:.2f} ms per pulse", flush=True)
+    if os.environ.get("PER_PULSE"):
+        t = time.time()
+        sw2 = sweep.PulseSweeper(sd, lp, n_streams)
+        sw2.render(offsets, per_pulse=True)
+        t = time.time()
+        cube_pp = sw2.render(offsets, per_pulse=True)
+        print(f"   per-pulse loop (round 1): {(time.time() - t) * 1e3:.1f} ms; max |cube - cube_pp| / max|cube| = "
+              f"{np.abs(cube - cube_pp).max() / np.abs(cube).max():.2e}", flush=True)
+        sw2.close()
 rd = np.abs(sweep.range_doppler(cube))
 lam = 0.5 * (sd.physics.lambda_min_nm + sd.physics.lambda_max_nm) * 1e-9
 far = rd[:, 200:]                            # fast-time cells beyond 6 m: the bus, not the ground under the antenna
