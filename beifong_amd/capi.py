@@ -98,7 +98,10 @@ class bf_stats(C.Structure):
                 ("n_bounces", C.c_uint64), ("kernel_ms", C.c_float), ("trace_ms", C.c_float),
                 ("shade_ms", C.c_float), ("tail_ms", C.c_float), ("n_launches_trace", C.c_uint32),
                 ("n_bounce_iters", C.c_uint32), ("n_rays_tail", C.c_uint64), ("n_rays_traced", C.c_uint64),
-                ("n_nodes_lds", C.c_uint64)]
+                ("n_nodes_lds", C.c_uint64), ("n_nodes_tail", C.c_uint64), ("n_wnodes_tail", C.c_uint64),
+                ("n_tris_tail", C.c_uint64), ("n_bounces_tail", C.c_uint64), ("n_shade_loads", C.c_uint64),
+                ("n_shade_stores", C.c_uint64), ("n_shade_shadow", C.c_uint64), ("n_shade_rays", C.c_uint64),
+                ("n_guard", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

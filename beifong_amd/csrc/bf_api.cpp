@@ -292,7 +292,17 @@ static bf_status bind_arrays(bf_scene *sc, Flat &f, hipStream_t stream, bool cre
         } else if (!dev || dev_n != n) {
             return fail(BF_ERR_INVALID, "bf_scene_update_endpoints: phased array size changed (%u -> %u virtual elements)", dev_n, n);
         }
-        HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
+        if (creating) {
+            HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        } else {
+            // the caller's table goes through the scene's pinned staging ring: free again when the call returns
+            bf_scene::Stage *stg = nullptr;
+            bf_status sst = stage_acquire(sc, bytes, &stg);
+            if (sst != BF_OK) return sst;
+            std::memcpy(stg->host, host, bytes);
+            HIP_TRY(hipMemcpyAsync(dev, stg->host, bytes, hipMemcpyHostToDevice, stream));
+            if ((sst = stage_release_after(stg, stream)) != BF_OK) return sst;
+        }
         return BF_OK;
     };
     if (creating) {
@@ -708,16 +718,33 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         bf_status ast = bind_arrays(scene, f, stream, false);
         if (ast != BF_OK) return ast;
     }
-    // small tables, copied in stream order (pageable sources are staged by the runtime before the call returns)
-    if (!f.rects.empty())
-        HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, f.rects.data(), f.rects.size() * sizeof(bfd::DRect), hipMemcpyHostToDevice, stream));
-    if (!f.shapes.empty())
-        HIP_TRY(hipMemcpyAsync((void *) scene->d.shapes, f.shapes.data(), f.shapes.size() * sizeof(bfd::DShape), hipMemcpyHostToDevice, stream));
-    if (!f.emitters.empty())
-        HIP_TRY(hipMemcpyAsync((void *) scene->d.emitters, f.emitters.data(), f.emitters.size() * sizeof(bfd::DEmitter), hipMemcpyHostToDevice, stream));
-    if (desc->n_materials)
-        HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, desc->materials, desc->n_materials * sizeof(bf_material), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync((void *) scene->d.sensor, &f.sensor, sizeof(bfd::DSensor), hipMemcpyHostToDevice, stream));
+    // small tables: packed into one pinned staging slot owned by the scene (the flattened records above are stack
+    // locals and `desc` is the caller's), then copied to their device tables in stream order — no host-blocking copy,
+    // nothing read after this call returns
+    {
+        const size_t b_rects = f.rects.size() * sizeof(bfd::DRect), b_shapes = f.shapes.size() * sizeof(bfd::DShape);
+        const size_t b_emit = f.emitters.size() * sizeof(bfd::DEmitter), b_mat = (size_t) desc->n_materials * sizeof(bf_material);
+        const size_t b_sensor = sizeof(bfd::DSensor);
+        auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+        const size_t o_rects = 0, o_shapes = o_rects + up16(b_rects), o_emit = o_shapes + up16(b_shapes), o_mat = o_emit + up16(b_emit),
+                     o_sensor = o_mat + up16(b_mat), total = o_sensor + up16(b_sensor);
+        bf_scene::Stage *stg = nullptr;
+        bf_status sst = stage_acquire(scene, total, &stg);
+        if (sst != BF_OK) return sst;
+        char *h = (char *) stg->host;
+        if (b_rects) std::memcpy(h + o_rects, f.rects.data(), b_rects);
+        if (b_shapes) std::memcpy(h + o_shapes, f.shapes.data(), b_shapes);
+        if (b_emit) std::memcpy(h + o_emit, f.emitters.data(), b_emit);
+        if (b_mat) std::memcpy(h + o_mat, desc->materials, b_mat);
+        std::memcpy(h + o_sensor, &f.sensor, b_sensor);
+        if (b_rects) HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, h + o_rects, b_rects, hipMemcpyHostToDevice, stream));
+        if (b_shapes) HIP_TRY(hipMemcpyAsync((void *) scene->d.shapes, h + o_shapes, b_shapes, hipMemcpyHostToDevice, stream));
+        if (b_emit) HIP_TRY(hipMemcpyAsync((void *) scene->d.emitters, h + o_emit, b_emit, hipMemcpyHostToDevice, stream));
+        if (b_mat) HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, h + o_mat, b_mat, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((void *) scene->d.sensor, h + o_sensor, b_sensor, hipMemcpyHostToDevice, stream));
+        sst = stage_release_after(stg, stream);
+        if (sst != BF_OK) return sst;
+    }
     scene->sensor_host = f.sensor;
     scene->film_w = desc->sensor.film_width;
     scene->film_h = desc->sensor.film_height;
@@ -1037,6 +1064,10 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     if (fb_ready) {
         // live counts of the last planned render: move the switch to the tail to where it belongs
         scene->wf_fb_pending = false;
+        const unsigned long long lost = reinterpret_cast<volatile unsigned long long *>(scene->wf_host)[1];
+        if (lost)
+            return fail(BF_ERR_DEVICE, "the previous planned render of this scene dropped %llu rays at wf_trace's iteration guard: "
+                                       "its histogram is wrong (a traversal bug; please report the scene)", lost);
         const uint32_t *nl = scene->wf_feedback;
         uint32_t k = 0;
         while (k < scene->wf_fb_iters && nl[k] > plan.tail_max) ++k;
@@ -1068,6 +1099,8 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         HIP_TRY(toc());
         if (!scene->wf_fb_pending) {
             HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live, plan.iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<unsigned long long *>(scene->wf_host) + 1, wf.counters + bfd::CTR_GUARD,
+                                   sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
             scene->wf_fb_pending = true;
             scene->wf_fb_iters = plan.iters;
@@ -1271,6 +1304,21 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
         stats_out->n_bounces = c[bfd::CTR_BOUNCES];
         stats_out->n_rays_tail = c[bfd::CTR_TAIL_RAYS];
         stats_out->n_rays_traced = c[bfd::CTR_TRACED];
+        stats_out->n_nodes_tail = c[bfd::CTR_TAIL_NODES];
+        stats_out->n_wnodes_tail = c[bfd::CTR_TAIL_WNODES];
+        stats_out->n_tris_tail = c[bfd::CTR_TAIL_TRIS];
+        stats_out->n_bounces_tail = c[bfd::CTR_TAIL_BOUNCES];
+        stats_out->n_shade_loads = c[bfd::CTR_SHADE_LOADS];
+        stats_out->n_shade_stores = c[bfd::CTR_SHADE_STORES];
+        stats_out->n_shade_shadow = c[bfd::CTR_SHADE_SHADOW];
+        stats_out->n_shade_rays = c[bfd::CTR_SHADE_RAYS];
+        stats_out->n_guard = c[bfd::CTR_GUARD];
+        if (c[bfd::CTR_GUARD]) {
+            (void) hipEventDestroy(ev0);
+            (void) hipEventDestroy(ev1);
+            return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays: the histogram is wrong (a traversal bug; please "
+                                       "report the scene)", c[bfd::CTR_GUARD]);
+        }
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         stats_out->kernel_ms = ms;

@@ -123,6 +123,20 @@ struct DLaunch {
 };
 
 // device counters (uint64 each)
-enum { CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_TRACED, CTR_NODES_LDS, CTR_COUNT };
+enum {
+    CTR_NEXT_PATH = 0, CTR_CLOSEST, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_INVALID, CTR_BOUNCES, CTR_TAIL_RAYS, CTR_STARTED, CTR_TRACED,
+    CTR_NODES_LDS,
+    // per-kernel breakdown of the algorithmic bytes (bench.py's roofline entries)
+    CTR_TAIL_NODES,        // four-wide node visits of the tail kernel (BF_FLAG_STATS)
+    CTR_TAIL_WNODES,       // sixteen-wide node visits of the tail kernel (BF_FLAG_STATS)
+    CTR_TAIL_TRIS,         // triangle tests of the tail kernel (BF_FLAG_STATS)
+    CTR_TAIL_BOUNCES,      // vertices shaded by the tail kernel
+    CTR_SHADE_LOADS,       // path-state rows wf_shade read (slots visited)
+    CTR_SHADE_STORES,      // path-state rows wf_shade wrote back
+    CTR_SHADE_SHADOW,      // shadow requests wf_shade queued for wf_trace
+    CTR_SHADE_RAYS,        // rays generated by wf_shade (each one tests the rectangles and the root node's boxes)
+    CTR_GUARD,             // rays dropped by wf_trace's iteration guard (a bug if ever non-zero: bf_render reports BF_ERR_DEVICE)
+    CTR_COUNT
+};
 
 }  // namespace bfd

@@ -1,14 +1,19 @@
-// Hand-written gfx950 kernels for beifong's transient-radar hot path.
+// Hand-written gfx950 kernels for beifong's transient-radar hot path: the one-kernel estimator loop, the batch
+// ray queries, the mesh-translation kernel.
 //
-// One persistent wave64 megakernel with path regeneration: every lane owns one
-// path at a time; a lane whose path ended pulls the next global path index
-// from a device-wide queue head (wave-aggregated with __ballot/__popcll, one
-// returning atomic per refill) and starts over, so all 64 lanes enter every
-// BVH traversal.  Traversal keeps a per-lane stack in LDS (lane-strided, so a
-// wave's push/pop is bank-conflict free), reads 128-B four-child nodes and 48-B
-// triangles from HBM, and path-length returns are binned into an
-// LDS-privatised histogram that is flushed with one global atomic per
-// non-empty bin per workgroup.  No MFMA: the path is pointer chasing.
+// bf_render_kernel<STATS, RESUME, SPILL> runs the whole estimator loop per lane (generate -> trace -> shade -> ...):
+//   RESUME = false : the one-kernel variant of a render (BF_FLAG_MEGAKERNEL, an ablation of the wavefront pipeline
+//                    of bf_wavefront.hip): lanes take path indices from wave-local pools of 256 refilled by one
+//                    returning atomic, traverse with a 32-entry LDS stack per lane.
+//   RESUME = true  : the wavefront pipeline's TAIL.  Once few paths survive, two launches per bounce cost more than
+//                    they do; the survivors' slots are adopted through the alive masks and run to completion here.
+//                    The tail is latency, not throughput — its length is the longest Russian-roulette survivor's
+//                    bounce count times the time of one bounce of a nearly empty wave — so sparse waves trade lanes
+//                    for serial depth: one ray per 16-lane DPP row on a sixteen-wide collapse of the same BVH
+//                    (traverse_row16: gangs of up to four rows per ray), four lanes per ray on the four-wide tree
+//                    (traverse_quad) above that, and idle lanes take over the shadow rays of busy ones.
+// Path-length returns are binned into an LDS-privatised histogram flushed with one global atomic per non-empty bin
+// per workgroup.  No MFMA: the path is pointer chasing and scalar shading.
 //
 // Reference semantics (file:line) are cited at each function; the oracle
 // (oracle/bf_oracle.cpp) restates the same functions independently on the CPU.
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
     s.rmint = 0.f;
     s.rmaxt = 0.f;
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-    uint32_t c_closest = 0, c_shadow = 0, c_nodes = 0, c_tris = 0, c_bounces = 0;
+    uint32_t c_closest = 0, c_shadow = 0, c_nodes = 0, c_wnodes = 0, c_tris = 0, c_bounces = 0;
     // wave-local pool of path indices (uniform across the wave)
     uint64_t pool_next = 0, pool_end = 0;
 
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
                 Hit qbest;
                 bool qfound;
                 traverse_row16<STATS>(sc, rlog, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
-                                      job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_nodes, c_tris, jshift
+                                      job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_wnodes, c_tris, jshift
 #ifdef BF_TAIL_PROF
                                       , pf_row
 #endif
@@ -419,9 +424,10 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
     // statistics: wave-reduce then one atomic per counter per wave
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_nodes = c_nodes, v_tris = c_tris,
-                       v_invalid = acc.invalid, v_bounces = c_bounces;
+                       v_invalid = acc.invalid, v_bounces = c_bounces, v_wnodes = c_wnodes;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v_wnodes += __shfl_down(v_wnodes, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
         v_nodes += __shfl_down(v_nodes, off);
@@ -434,9 +440,15 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
         atomicAdd(&counters[CTR_SHADOW], v_shadow);
         if (RESUME) atomicAdd(&counters[CTR_TAIL_RAYS], v_closest + v_shadow);
         if (STATS) {
-            atomicAdd(&counters[CTR_NODES], v_nodes);
+            atomicAdd(&counters[CTR_NODES], v_nodes + v_wnodes);
             atomicAdd(&counters[CTR_TRIS], v_tris);
+            if (RESUME) {
+                atomicAdd(&counters[CTR_TAIL_NODES], v_nodes);
+                atomicAdd(&counters[CTR_TAIL_WNODES], v_wnodes);
+                atomicAdd(&counters[CTR_TAIL_TRIS], v_tris);
+            }
         }
+        if (RESUME) atomicAdd(&counters[CTR_TAIL_BOUNCES], v_bounces);
         atomicAdd(&counters[CTR_INVALID], v_invalid);
         atomicAdd(&counters[CTR_BOUNCES], v_bounces);
     }

@@ -1,26 +1,26 @@
-// Wavefront path tracer for gfx950: the radar hot path split into two
-// persistent kernels per bounce, with the path state streamed through HBM.
+// Wavefront path tracer for gfx950: the radar hot path as two persistent kernels per bounce iteration over a
+// pool of path SLOTS whose state stays in place in HBM (bf_wavefront.h).  There are no queues and no device-wide
+// counters on the data path: which slots need work is three 64-bit masks per 64-slot batch (alive / trace /
+// shadow), every wave owns a contiguous segment of batches, and a MaskCursor (bf_path_logic.h) packs the set bits
+// of its segment into full waves on the fly.
 //
-//   wf_shade : one lane per live path slot.  Reads the slot's state + closest
-//              hit (coalesced, queue order), runs the integrator's vertex logic
-//              (emitter hit, Russian roulette, next-event estimation, BSDF
-//              sampling — path.cpp:121-209 and the pathlength / pathtime
-//              variants), bins finished paths into the LDS-privatised range
-//              histogram, REGENERATES finished slots with fresh paths from the
-//              global path counter, and writes survivors compacted
-//              (__ballot/__popcll prefix + one atomic per wave) into the next
-//              queue together with their next ray; shadow rays go to a second
-//              compacted queue carrying the NEE contribution they gate.
-//   wf_trace : persistent waves pull batches of 64 rays (shadow rays first,
-//              then closest-hit rays) from the queues and traverse the BVH with
-//              per-lane LDS stacks; closest hits are written in queue order,
-//              unoccluded shadow rays add their contribution to the path.
+//   wf_shade : one lane per live slot.  Coalesced state load -> the integrator's vertex logic (emitter hit,
+//              Russian roulette, next-event estimation, BSDF sampling: path.cpp:121-209 and the pathlength /
+//              pathtime / pathtimefrequency variants, bf_path_logic.h: shade_vertex) -> state stored back in
+//              place.  Finished paths are binned (film_put: LDS-privatised histogram) and the slot starts its next
+//              path (static assignment: slot i renders paths i, i + n_slots, ...).  New rays are tested here
+//              against the analytic rectangles and the four child boxes of the BVH root (presolve_ray); a lane whose
+//              rays are all answered that way shades its next vertex in the same visit (up to kShadeChain).
+//   wf_trace : persistent waves with dynamic ray replacement walk the four-wide BVH for the rays that do enter
+//              the mesh: while-while traversal, 16-entry LDS stack per lane (+ HBM spill), the tree's top 85 nodes
+//              in LDS.  Closest hits go to hit[slot]; an unoccluded shadow ray releases its NEE contribution into
+//              the slot's result.
 //
-// The fat shading code (fp64 transcendentals, > 256 registers) and the lean
-// traversal code (58 VGPRs) no longer share one register allocation, so the
-// latency-bound traversal runs at 5 waves/SIMD instead of 1, and every lane
-// of a trace wave holds a ray.  Results are bit-identical per path to the
-// megakernel (bf_kernels.hip) and to the oracle: same draws, same arithmetic.
+// The tail of a render (few, long paths) is finished by bf_render_kernel<.., RESUME = true> (bf_kernels.hip).
+// All arithmetic is fp32 (the transcendentals are the engine's own fp32 specification, bf_device_math.h; the few
+// double operations are where the reference itself multiplies by a double literal, e.g. 1e-9 in phase_update and
+// freq_of).  Results are bit-identical per path to the one-kernel variant and to the oracle: same draws, same
+// operations in the same order.
 #include "bf_path_logic.h"
 
 namespace bfd {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0;
+    uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0, c_loads = 0, c_shq = 0;
 
     // contiguous segment of batches per wave
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 need_gen = true;
             } else {
                 load_state(wf, slot, receive, s);
+                ++c_loads;
                 if (s.flags & kFlagTermPending) {
                     // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
                     film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
@@ -254,14 +255,18 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         publish_masks(m_trace, aligned, batch0, slot, has, tracing);
         publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
         c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
+        c_shq += shadowing ? 1u : 0u;
     }
 
     film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
     uint32_t v_live = c_live;
     unsigned long long v_traced = c_traced;
+    uint32_t v_loads = c_loads, v_shq = c_shq;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v_loads += __shfl_down(v_loads, off);
+        v_shq += __shfl_down(v_shq, off);
         v_traced += __shfl_down(v_traced, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
@@ -276,6 +281,10 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
         if (v_live) atomicAdd(&wf.n_live[it], v_live);      // one non-returning atomic per wave per launch
         if (v_traced) atomicAdd(&wf.counters[CTR_TRACED], v_traced);
+        if (v_loads) atomicAdd(&wf.counters[CTR_SHADE_LOADS], (unsigned long long) v_loads);
+        if (v_live) atomicAdd(&wf.counters[CTR_SHADE_STORES], (unsigned long long) v_live);
+        if (v_shq) atomicAdd(&wf.counters[CTR_SHADE_SHADOW], (unsigned long long) v_shq);
+        if (v_closest + v_shadow) atomicAdd(&wf.counters[CTR_SHADE_RAYS], v_closest + v_shadow);
     }
 }
 
@@ -297,6 +306,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 // spill to a per-thread column in HBM.  16 KiB of LDS per workgroup instead of
 // 32 lifts the kernel from 5 to 8 waves/SIMD.
 constexpr int kLdsStack = 16;
+constexpr uint32_t kTraceGuard = 1u << 24;      // wf_trace: inner-loop iterations between two refills (see the guard below)
 
 template <bool STATS, int W, bool SHIFT>
 __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t it) {
@@ -394,10 +404,17 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
             }
         }
         if (__ballot(has) == 0ull) break;
+        guard = 0;
 
         // ---- traversal until the wave thins out -----------------------------------
         while (true) {
-            if (++guard > (1u << 26)) {      // safety net: a persistent wave must always drain
+            if (++guard > kTraceGuard) {
+                // Safety net: a persistent wave must always drain.  The count restarts at every refill, so it bounds the
+                // steps ONE set of rays may take (a ray visits each node and leaf at most once: far below the bound).  It
+                // is never expected to trip; if it does, the rays are dropped LOUDLY: CTR_GUARD makes bf_render_device
+                // fail with BF_ERR_DEVICE (bf_stats.n_guard) instead of returning a plausible histogram.
+                const unsigned long long lost = __ballot(has);
+                if (lane == 0) atomicAdd(&wf.counters[CTR_GUARD], (unsigned long long) __popcll(lost));
                 has = false;
                 break;
             }

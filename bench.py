@@ -1,38 +1,50 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s + HBM-roofline fraction of the radar path-tracing hot path.
+"""bench.py — Mrays/s + roofline fractions of the radar path-tracing hot path, per BASELINE.json config.
 
-Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W`;
-for N > 1 the driver launches one rank per GPU through torch.distributed.run
-(RCCL).  A step is one pass of the hot path over one batch of synthetic input:
-BASELINE.json configs[1] — the Bus.obj-class monostatic radar scene (200 k
-triangle synthetic bus + ground, 256 range bins, 64 spp per pulse) — rendered
-for a batch of pulses (2^24 paths per GPU per step) and followed, for N > 1, by
-the RCCL all-reduce of the per-GPU range histograms.  Weak scaling: per-GPU
-work is fixed; GPU g renders global path indices [g*P, (g+1)*P) via
-bf_launch.path_offset, so the union is one sample set.
+Contract (task brief): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per
+GPU through torch.distributed.run (RCCL).  A step is one pass of the hot path over one batch of synthetic input:
 
-Consecutive steps are independent renders (successive coherent processing
-intervals of a pulse sweep), so they are issued round-robin on `--streams`
-HIP streams (default 3, one bf_scene handle each): the latency-bound deep-path
-tail of one step overlaps the head of the next.  The timed region carries no
-instrumentation; ray counts and per-kernel HIP-event durations come from an
-instrumented serial pass over the SAME steps (same seeds => same rays), which
-also yields `ms_per_step_serial`.
+  --config c2 (default, the config BASELINE.json's metric is quoted on): the Bus.obj-class monostatic radar scene
+            (200 k-triangle synthetic bus + ground, gen-2 range(pathlength), 256 range bins, 64 spp per pulse) rendered
+            for a batch of pulses: 2^24 paths per GPU per step;
+  --config c3: Car-body.ply-class shell (1 M triangles, vertex normals) + ground, 1024 bins, 2^20 paths per step;
+  --config c4shard: bus + car + motorbike (1.49 M triangles), 4096 bins, ONE of the 8 shards of C4 per GPU per step
+            (2^19 paths); --config c4 --scaling strong: the configured 2^22 paths split over the ranks;
+  --config c5: the 64-pulse coherent sweep (C2 geometry through gen-3 receive, I/Q ADC of 1024 fast-time bins, target
+            moving 5 mm per pulse): one step = one sweep = 64 x 2^20 paths, rendered as batched launches
+            (bf_render_batch_device).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: wf_trace)
-and `cpu_baseline` (the CPU oracle, a port of the reference's scalar path,
-timed on this box's host cores on a bounded sample of the same workload).
+followed, for N > 1, by the RCCL all-reduce of the per-GPU histograms.  Weak scaling: per-GPU work fixed, GPU g renders
+global path indices [g*P, (g+1)*P) via bf_launch.path_offset (the union is one sample set); --scaling strong: the total
+is fixed and split with beifong_amd.dist.shard_range.
+
+Consecutive steps are independent renders (successive coherent processing intervals), issued round-robin on
+`--streams` HIP streams — one handle per stream, all clones of ONE scene (bf_scene_clone: one BVH on the device) — so
+the latency-bound tail of one step overlaps the head of the next.  The timed region carries no instrumentation; ray
+counts, per-kernel algorithmic bytes (BF_FLAG_STATS counters) and per-kernel HIP-event durations come from two untimed
+serial passes over the SAME steps (same seeds => same rays).
+
+Rank 0 prints ONE JSON line.  `roofline`: headline = the whole path as SURVEY.md §8(d) defines it (traversal bytes of
+ALL rays of a step / time of a step), `kernels` = one entry per kernel (wf_trace, wf_shade, tail) ranked by its share of
+the GPU time, each with its own algorithmic bytes per launch / average launch duration, against the HBM peak and against
+the Infinity-Cache gather rate (the scenes are cache-resident: DESIGN.md §3).  `cpu_baseline`: the CPU oracle (a port of
+the reference's scalar path with its own SAH BVH; neither embree nor TBB exist offline), -O3 -march=native, one warm-up
++ best of 3, all host cores and one core, on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+CACHE_GATHER_GBS = 8600.0    # MI355X_MICROARCH.md "Indexed rows": 38 MB table gathered from the Infinity Cache, chip-wide
+L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup, served by the XCDs' L2s (16.8-18.8 TB/s)
 
 
 def parse():
@@ -40,12 +52,92 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths", type=int, default=1 << 24, help="paths per GPU per step")
-    ap.add_argument("--tris", type=int, default=200_000)
-    ap.add_argument("--cpu-paths", type=int, default=1 << 26, help="bounded sample for the CPU baseline")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4shard", "c4", "c5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (per pulse for c5); 0 = the config's")
+    ap.add_argument("--tris", type=int, default=0, help="c2 / c5: triangles of the synthetic bus; 0 = 200 000")
+    ap.add_argument("--pulses", type=int, default=64, help="c5: pulses per sweep")
+    ap.add_argument("--cpu-paths", type=int, default=0, help="bounded sample for the CPU baseline; 0 = the config's")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams (scene handles) the steps rotate over")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams (scene handles) the steps rotate over; 0 = the config's")
     return ap.parse_args()
+
+
+class Workload:
+    """One BASELINE.json config as a scene, a launch and a way to issue step i."""
+
+    def __init__(self, args, rank, world, capi, scenes):
+        import numpy as np
+        cfg = args.config
+        self.cfg = cfg
+        self.sweep = cfg == "c5"
+        tris = args.tris or 200_000
+        if cfg == "c2":
+            paths = args.paths or (1 << 24)
+            self.sd, self.lp = scenes.bus_radar(n_tris=tris, n_paths=paths, bins=256, dr=0.1, seed=1)
+            self.label = ("C2 bus_radar: synthetic %d-triangle bus (Bus.obj stand-in) + 20x20 m ground, monostatic 20x50 mm TX "
+                          "aperture + perspective RX, gen-2 range(pathlength) integrator, 256 range bins dr=0.1 m, 64 spp x %d "
+                          "pulses = %d paths per GPU per step")
+            self.streams = args.streams or 3
+            self.cpu_paths = args.cpu_paths or (1 << 24)
+        elif cfg == "c3":
+            paths = args.paths or (1 << 20)
+            self.sd, self.lp = scenes.car_radar(n_tris=1_000_000, n_paths=paths, bins=1024, dr=0.03, seed=2)
+            self.label = ("C3 car_radar: synthetic %d-triangle car-body shell with vertex normals (Car-body.ply stand-in) + "
+                          "ground, gen-2 range(pathlength), 1024 range bins dr=0.03 m, 2^20 primary rays: %d x 64 = %d paths per GPU per step")
+            self.streams = args.streams or 3
+            self.cpu_paths = args.cpu_paths or (1 << 22)
+        elif cfg in ("c4shard", "c4"):
+            total = 4096 << 10
+            paths = args.paths or (total // 8 if cfg == "c4shard" else total)
+            self.sd, self.lp = scenes.multi_mesh_radar(n_paths=paths, bins=4096, dr=0.01, seed=3)
+            self.label = ("C4 multi_mesh_radar: bus + car + motorbike (%d triangles) on the ground, gen-2 range(pathlength), 4096 "
+                          "range bins; %d x 64 = %d paths per step (the configured 4096 spp x 2^10 = 2^22 paths are 8 such shards)")
+            self.streams = args.streams or 3
+            self.cpu_paths = args.cpu_paths or (1 << 22)
+        else:
+            paths = args.paths or (1 << 20)
+            lam0 = 8.6e6        # nm; +-0.1 % band (tools/c5_sweep.py)
+            self.sd, self.lp = scenes.bus_receive(n_tris=tris, n_paths=paths, t_bins=1024, dr=0.03, seed=4,
+                                                  lambda_band_nm=(lam0 * 0.999, lam0 * 1.001))
+            self.lp.mode = capi.BF_MODE_RECEIVE_IQ
+            self.n_pulses = args.pulses
+            v = np.array([-5.0, 0.0, 0.0])
+            self.offsets = np.ascontiguousarray((np.arange(self.n_pulses)[:, None] * 1e-3 * v[None, :]).astype(np.float32))
+            self.label = ("C5 pulse sweep: C2 geometry (%d triangles) through gen-3 receive (wigner transmitter, omnidirectional "
+                          "receiver, BF_MODE_RECEIVE_IQ), 1024 fast-time bins, target at -5 m/s, PRI 1 ms; one step = one sweep of "
+                          + str(self.n_pulses) + " pulses x %d x 64 = %d paths per pulse per GPU, batched launches")
+            self.streams = args.streams or 2
+            self.cpu_paths = args.cpu_paths or (1 << 22)
+        self.total_paths = int(self.lp.n_paths)
+        if args.scaling == "strong":
+            from beifong_amd.dist import shard_range
+            self.path_offset, self.paths = shard_range(self.total_paths, rank, world)
+        else:
+            self.path_offset, self.paths = rank * self.total_paths, self.total_paths
+        self.receive = self.lp.mode in (capi.BF_MODE_RECEIVE_RAW, capi.BF_MODE_RECEIVE_IQ)
+        self.capi = capi
+
+    def launch(self, i, flags=0):
+        c, lp = self.capi, self.lp
+        if self.receive:
+            l = c.make_launch(lp.mode, self.paths, seed=lp.seed + 1000003 * i, path_offset=self.path_offset, bins=lp.bins,
+                              bins_y=lp.bins_y, flags=flags)
+        else:
+            l = c.make_launch(lp.mode, self.paths, seed=lp.seed + 1000003 * i, path_offset=self.path_offset, bins=lp.bins,
+                              bin_width=lp.bin_width, color_mode=lp.color_mode, flags=flags)
+        return l
+
+
+STAT_KEYS = ("n_paths", "n_rays_closest", "n_rays_shadow", "n_nodes_visited", "n_tris_tested", "n_bounces", "n_rays_tail", "n_rays_traced",
+             "n_nodes_lds", "n_nodes_tail", "n_wnodes_tail", "n_tris_tail", "n_bounces_tail", "n_shade_loads", "n_shade_stores",
+             "n_shade_shadow", "n_shade_rays", "n_launches_trace", "n_bounce_iters", "kernel_ms", "trace_ms", "shade_ms", "tail_ms")
+
+
+def add_stats(acc, st):
+    for k in STAT_KEYS:
+        acc[k] = acc.get(k, 0) + getattr(st, k)
+    acc["n_tail_launches"] = acc.get("n_tail_launches", 0) + (1 if st.tail_ms > 0 else 0)
 
 
 def main():
@@ -57,7 +149,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
 
     import numpy as np
-    import torch                      # first: its libamdhip64.so.7 is the one HIP runtime of the process
+    import torch                      # first: its libamdhip64.so is the one HIP runtime of the process
     import torch.distributed as dist
 
     from beifong_amd import capi, scenes
@@ -79,78 +171,76 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    sd, lp = scenes.bus_radar(n_tris=args.tris, n_paths=args.paths, bins=256, dr=0.1, seed=1)
-    n_streams = max(1, args.streams)
-    handles = [capi.Scene(sd, lib) for _ in range(n_streams)]      # one render in flight per handle
-    scene = handles[0]
-    info = scene.info()
-    n_chan = scene.channels(lp)
-    hists = [torch.zeros(n_chan, dtype=torch.float32, device=dev) for _ in range(n_streams)]
+    w = Workload(args, rank, world, capi, scenes)
+    n_streams = max(1, w.streams)
+    first = capi.Scene(w.sd, lib)                                  # ONE BVH build / upload ...
+    handles = [first] + [first.clone() for _ in range(n_streams - 1)]   # ... shared by the stream handles
+    info = first.info()
+    n_chan = first.channels(w.lp)
+    n_hist = n_chan * (w.n_pulses if w.sweep else 1)
+    hists = [torch.zeros(n_hist, dtype=torch.float32, device=dev) for _ in range(n_streams)]
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
 
-    def step(i, want_stats=False, flags=0):
-        j = i % n_streams
-        l = capi.make_launch(lp.mode, args.paths, seed=lp.seed + 1000003 * i, path_offset=rank * args.paths,
-                             bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode, flags=flags)
-        with torch.cuda.stream(streams[j]):
-            hists[j].zero_()
-            st = handles[j].render_device(l, hists[j].data_ptr(), stream=streams[j].cuda_stream, want_stats=want_stats)
-            if world > 1:
-                dist.all_reduce(hists[j])     # RCCL sum of the per-GPU range histograms over xGMI
-        return st
+    def step(i, acc=None, flags=0):
+        """Issue step i; with `acc` (a dict) the call is synchronous and the step's bf_stats are added to it."""
+        want = acc is not None
+        l = w.launch(i, flags)
+        if not w.sweep:
+            j = i % n_streams
+            with torch.cuda.stream(streams[j]):
+                hists[j].zero_()
+                st = handles[j].render_device(l, hists[j].data_ptr(), stream=streams[j].cuda_stream, want_stats=want)
+                if world > 1:
+                    dist.all_reduce(hists[j])     # RCCL sum of the per-GPU range histograms over xGMI
+            if want:
+                add_stats(acc, st)
+            return
+        # c5: one sweep = n_streams batches of pulses (one launch sequence each), cube accumulated in hists[0]
+        cube = hists[0]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(streams[0]):
+            cube.zero_()
+        for s in streams[1:]:
+            s.wait_stream(streams[0])
+        bounds = [w.n_pulses * j // n_streams for j in range(n_streams + 1)]
+        for j in range(n_streams):
+            k0, k1 = bounds[j], bounds[j + 1]
+            if k1 == k0:
+                continue
+            with torch.cuda.stream(streams[j]):
+                st = handles[j].render_batch_device(l, k1 - k0, cube.data_ptr() + 4 * n_chan * k0, offsets=w.offsets[k0:k1],
+                                                    stream=streams[j].cuda_stream, want_stats=want)
+            if want:
+                add_stats(acc, st)
+        if world > 1:
+            for s in streams[1:]:
+                streams[0].wait_stream(s)
+            with torch.cuda.stream(streams[0]):
+                dist.all_reduce(cube)             # one all-reduce of the whole slow-time x fast-time cube
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # algorithmic bytes per ray: V_n * S_n + V_t * 48 + 48 (S_n = 128-byte four-wide nodes), with
-    # V_n / V_t counted by the instrumented kernels on exactly this workload.
-    # wf_trace only sees the rays that enter the mesh BVH (wf_shade resolves the
-    # others against the rectangles + the BVH root boxes), so its roofline uses
-    # ITS rays and ITS nodes/triangles (the tail kernel's share is taken out
-    # pro rata by rays).
-    st = step(0, want_stats=True, flags=capi.BF_FLAG_STATS)
-    rays0 = st.n_rays_closest + st.n_rays_shadow
-    v_n = st.n_nodes_visited / rays0
-    v_t = st.n_tris_tested / rays0
-    b_ray = v_n * info.node_bytes + v_t * info.tri_bytes + 48.0
-    bvh_rays0 = st.n_rays_traced + st.n_rays_tail            # rays that walked the BVH at all
-    share = st.n_rays_traced / max(bvh_rays0, 1)
-    v_n_tr = st.n_nodes_visited * share / max(st.n_rays_traced, 1)
-    v_t_tr = st.n_tris_tested * share / max(st.n_rays_traced, 1)
-    b_ray_tr = v_n_tr * info.node_bytes + v_t_tr * info.tri_bytes + 48.0
-    # node visits wf_trace serves from its LDS copy of the tree's top levels (they are algorithmic bytes of the
-    # traversal all the same; the figure without them is reported next to the headline one)
-    v_n_lds = st.n_nodes_lds / max(st.n_rays_traced, 1)
-    b_ray_tr_mem = (v_n_tr - v_n_lds) * info.node_bytes + v_t_tr * info.tri_bytes + 48.0
-    # every scene handle allocates its wavefront pool and learns its launch plan on first use:
-    # touch each once (untimed, before the W warm-up steps) so neither pass below pays for that
-    for j in range(n_streams):
+    # every scene handle allocates its path pool and learns its launch plan on first use: touch each once (untimed,
+    # before the W warm-up steps) so neither pass below pays for that
+    for j in range(n_streams if not w.sweep else 1):
         step(j)
     sync()
     for i in range(args.warmup):
         step(i)
-
-    # instrumented serial pass over the steps of the timed region: ray counts (exact — the
-    # same seeds are rendered again below) and HIP-event durations of every kernel launch
     sync()
-    rays = 0
-    paths = 0
-    kernel_ms = 0.0
-    trace_ms = shade_ms = tail_ms = 0.0
-    trace_launches = 0
-    rays_trace = 0
+
+    # (A) counters of the timed region's steps: BF_FLAG_STATS counts node visits and triangle tests per kernel (the
+    #     instrumented kernel variants; untimed).  (B) per-kernel HIP-event durations of the same steps, serial,
+    #     product kernels.  Same seeds as the timed region below => same rays.
+    cnt, tim = {}, {}
     for i in range(args.steps):
-        st = step(i, want_stats=True)
-        rays += st.n_rays_closest + st.n_rays_shadow
-        paths += st.n_paths
-        kernel_ms += st.kernel_ms
-        trace_ms += st.trace_ms
-        shade_ms += st.shade_ms
-        tail_ms += st.tail_ms
-        trace_launches += st.n_launches_trace
-        rays_trace += st.n_rays_traced
+        step(i, acc=cnt, flags=capi.BF_FLAG_STATS)
+    for i in range(args.steps):
+        step(i, acc=tim)
 
     # timed region: EXACTLY `steps` steps, no instrumentation, barrier + synchronize on both sides
     sync()
@@ -160,7 +250,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([dt, float(rays), float(paths), kernel_ms], dtype=torch.float64, device=dev)
+    rays = cnt["n_rays_closest"] + cnt["n_rays_shadow"]
+    paths = cnt["n_paths"]
+    tot = torch.tensor([dt, float(rays), float(paths)], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -171,116 +263,189 @@ def main():
     else:
         rays_all, paths_all = float(rays), float(paths)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-    # committed summary of the separate rocprofv3 --pmc passes over this workload supplies it
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as f:
-            pt = json.load(f)
-        if pt.get("kernel") == "wf_trace" and args.paths == (1 << 24) and args.tris == 200_000:
-            traffic = float(pt["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        traffic = None
-
-    out = None
     if rank == 0:
+        K = args.steps
+        S_n, S_w, S_t, S_q = float(info.node_bytes), 512.0, float(info.tri_bytes), 48.0
+        row = 100.0 + (16.0 if w.receive else 0.0) + (4.0 if w.sweep else 0.0)      # path-state row: ray0 ray1 sa sb sd [se] + hit + hit_prim [+ render]
+        n4_tail, n16_tail = cnt["n_nodes_tail"], cnt["n_wnodes_tail"]
+        n4_trace = cnt["n_nodes_visited"] - n4_tail - n16_tail
+        t_trace = cnt["n_tris_tested"] - cnt["n_tris_tail"]
+        # algorithmic bytes: traversal = V_n S_n + V_t S_t + S_q per ray with the node size of
+        # the tree that was walked; shading = state rows read / written + triangle & normals of the shaded hit (96 B) +
+        # the root node (128 B) each new ray is tested against in wf_shade
+        b_trace = n4_trace * S_n + t_trace * S_t + cnt["n_rays_traced"] * S_q
+        b_tail = (n4_tail * S_n + n16_tail * S_w + cnt["n_tris_tail"] * S_t + cnt["n_rays_tail"] * S_q + cnt["n_bounces_tail"] * 96.0)
+        b_shade = (cnt["n_shade_loads"] * row + cnt["n_shade_stores"] * row + cnt["n_shade_shadow"] * 36.0 +
+                   (cnt["n_bounces"] - cnt["n_bounces_tail"]) * 96.0 + cnt["n_shade_rays"] * S_n)
+        b_traversal_all = (n4_trace + n4_tail) * S_n + n16_tail * S_w + cnt["n_tris_tested"] * S_t + rays * S_q
+        ms = {"wf_trace": tim["trace_ms"], "wf_shade": tim["shade_ms"], "tail": tim["tail_ms"]}
+        launches = {"wf_trace": max(tim["n_launches_trace"], 1), "wf_shade": max(tim["n_bounce_iters"], 1),
+                    "tail": max(tim["n_tail_launches"], 1)}
+        bytes_ = {"wf_trace": b_trace, "wf_shade": b_shade, "tail": b_tail}
+        names = {"wf_trace": "bfd::wf_trace<false, 5, %s>" % ("true" if w.sweep else "false"),
+                 "wf_shade": "bfd::wf_shade<*, 3>", "tail": "bfd::bf_render_kernel<false, true, *> (tail)"}
+        traffic = pmc_traffic(w, args)
+        total_ms = sum(ms.values()) or 1.0
+        kernels = []
+        for k in sorted(ms, key=lambda k: -ms[k]):
+            per_launch = bytes_[k] / launches[k]
+            avg_s = ms[k] / launches[k] / 1e3
+            ach = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+            tr = traffic.get(k) if traffic else None
+            kernels.append({
+                "kernel": names[k], "share_of_gpu_time": round(ms[k] / total_ms, 4), "ms_per_step": round(ms[k] / K, 4),
+                "launches_per_step": round(launches[k] / K, 2), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "algorithmic_bytes_per_launch": round(per_launch), "achieved": round(ach, 2), "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "frac_of_cache_gather_ceiling": round(ach / CACHE_GATHER_GBS, 5),
+                "traffic": tr, "traffic_over_algorithmic": (round(tr / per_launch, 3) if tr else None),
+            })
+        step_s = dt / K
+        whole = b_traversal_all / K / step_s / 1e9
+        whole_serial = b_traversal_all / (tim["kernel_ms"] / 1e3) / 1e9
         mrays = rays_all / dt / 1e6
-        # dominant kernel = wf_trace (BVH traversal): HIP events bracket every one
-        # of its launches on the launch stream; a step issues one launch per bounce
-        avg_launch_s = trace_ms / max(trace_launches, 1) / 1e3
-        rays_per_launch = rays_trace / max(trace_launches, 1)
-        achieved = b_ray_tr * rays_per_launch / avg_launch_s / 1e9
         out = {
-            "metric": "Mrays/s (closest + any-hit BVH queries), Bus.obj-class radar scene",
+            "metric": "Mrays/s (closest + any-hit BVH queries), %s" % {"c2": "Bus.obj-class radar scene", "c3": "Car-body.ply-class scene",
+                       "c4shard": "bus+car+motorbike scene, one of 8 shards per GPU", "c4": "bus+car+motorbike scene", "c5": "64-pulse coherent sweep"}[w.cfg],
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "ms_per_step_serial": round(kernel_ms / args.steps, 4),
+            "ms_per_step": round(step_s * 1e3, 4),
+            "ms_per_step_serial": round(tim["kernel_ms"] / K, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C2 bus_radar: synthetic %d-triangle bus (Bus.obj stand-in) + 20x20 m ground, monostatic "
-                            "20x50 mm TX aperture + perspective RX, gen-2 range(pathlength) integrator, 256 range "
-                            "bins dr=0.1 m, 64 spp x %d pulses = %d paths per GPU per step"
-                            % (info.n_triangles, args.paths // 64, args.paths),
-                "paths_per_gpu_per_step": args.paths,
-                "range_bins": 256,
+                "workload": w.label % (info.n_triangles, w.paths // 64, w.paths),
+                "name": w.cfg,
+                "paths_per_gpu_per_step": w.paths * (w.n_pulses if w.sweep else 1),
+                "range_bins": int(w.lp.bins),
                 "triangles": int(info.n_triangles),
                 "bvh_nodes": int(info.n_bvh_nodes),
-                "parallelism": "sample-sharded x%d, RCCL all-reduce of the range histogram" % world,
+                "parallelism": "sample-sharded x%d (%s), RCCL all-reduce of the histogram" % (world, args.scaling),
                 "streams": n_streams,
                 "mpaths_per_s": round(paths_all / dt / 1e6, 2),
                 "rays_per_path": round(rays_all / paths_all, 3),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "wf_trace",
-                "achieved": round(achieved, 2),
+                "scope": "whole path: traversal bytes of ALL rays of a step (V_n S_n + V_t S_t + S_q, SURVEY 8d) / ms_per_step",
+                "kernel": kernels[0]["kernel"],
+                "achieved": round(whole, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "traffic_note": "HBM bytes per wf_trace launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, "
-                                "profiles/r01_final_pmc.txt; algorithmic bytes per launch = %.3e" % (b_ray_tr * rays_per_launch),
-                "measured": "HIP events around every launch, instrumented serial pass over the timed region's steps",
-                "bytes_per_ray": round(b_ray_tr, 1),
-                "nodes_per_ray": round(v_n_tr, 2),
-                "tris_per_ray": round(v_t_tr, 2),
-                "nodes_per_ray_from_lds": round(v_n_lds, 2),
-                "achieved_without_lds_served_nodes": round(achieved * b_ray_tr_mem / b_ray_tr, 2),
-                "all_rays": {"bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(v_n, 2), "tris_per_ray": round(v_t, 2),
-                             "resolved_in_wf_shade_frac": round(1.0 - bvh_rays0 / rays0, 4)},
-                "rays_per_launch": int(rays_per_launch),
-                "launches_per_step": round(trace_launches / args.steps, 2),
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-                "per_step_ms": {"wf_trace": round(trace_ms / args.steps, 3), "wf_shade": round(shade_ms / args.steps, 3),
-                                "tail": round(tail_ms / args.steps, 3), "all_kernels": round(kernel_ms / args.steps, 3)},
-                "whole_pipeline_frac": round(b_ray * rays / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac": round(whole / HBM_PEAK_GBS, 5),
+                "frac_serial": round(whole_serial / HBM_PEAK_GBS, 5),
+                "traffic": (round(sum(kk["traffic"] * kk["launches_per_step"] for kk in kernels)) if traffic and all(kk["traffic"] for kk in kernels) else None),
+                "traffic_note": "HBM bytes per step / per launch: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes, "
+                                "profiles/r02_pmc_traffic.json (tools/profile_r02.sh); null when this run's shape differs from the profiled one",
+                "bytes_per_ray": round(b_traversal_all / rays, 1),
+                "nodes_per_ray": round((n4_trace + n4_tail + n16_tail) / rays, 2),
+                "tris_per_ray": round(cnt["n_tris_tested"] / rays, 2),
+                "resolved_in_wf_shade_frac": round(1.0 - (cnt["n_rays_traced"] + cnt["n_rays_tail"]) / rays, 4),
+                "ceiling_cache": {"note": "the scene (%.0f MB of nodes + triangles + normals) stays in the 256 MB Infinity Cache and partly in "
+                                          "the 8 x 4 MB L2s, so the traversal's physical ceiling is the scattered-gather rate out of those caches "
+                                          "(MI355X_MICROARCH.md, Indexed rows), not HBM" % (info.device_bytes / 1e6),
+                                  "infinity_cache_gather_GBs": CACHE_GATHER_GBS, "l2_gather_GBs": L2_GATHER_GBS,
+                                  "frac_of_infinity_cache_gather": round(whole / CACHE_GATHER_GBS, 5)},
+                "measured": "HIP events around every launch (serial pass over the timed region's steps); counters from a BF_FLAG_STATS pass over the same steps",
+                "kernels": kernels,
+                "state_row_bytes": row,
+                "with_shading_state": {"bytes_per_step": round((b_trace + b_tail + b_shade) / K),
+                                       "achieved": round((b_trace + b_tail + b_shade) / K / step_s / 1e9, 2)},
             },
         }
+        if world == 1 and w.cfg in ("c3", "c4shard", "c4", "c2"):
+            # what an 8-GPU strong-scaled render of this config would see: per-GPU time of 1/8 of the paths cannot drop
+            # below the tail
+            out["config"]["isolated_step_ms"] = round(tim["kernel_ms"] / K, 3)
+            out["config"]["tail_ms_per_step"] = round(tim["tail_ms"] / K, 3)
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sd, lp, args)
+            out["cpu_baseline"] = cpu_baseline(w, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, lp, args):
-    """The oracle (kind "port": a CPU restatement of the reference's scalar
-    path; the reference itself cannot be built offline) on this box's host
-    cores, on a bounded sample of the same workload."""
+def pmc_traffic(w, args):
+    """HBM bytes per launch of each kernel from the committed PMC summary of the same workload shape (PMC counters cannot
+    be read from inside this process: separate rocprofv3 --pmc passes, tools/profile_r02.sh)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            pt = json.load(f)
+        e = pt.get(w.cfg)
+        if not e or e.get("paths") != w.paths or args.tris not in (0, 200_000):
+            return None
+        return {k: float(v) for k, v in e["traffic_bytes_per_launch"].items()}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def fast_oracle_path():
+    """oracle/_fast/libbf_oracle_fast_<cpu>.so: the oracle built -O3 -march=native FOR THE CPU THIS RUNS ON (the file
+    name carries a hash of the CPU's model and flags, so a library built on another box is never loaded)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        key = "".join(l for l in txt.splitlines() if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        key = "unknown"
+    tag = hashlib.sha256(key.encode()).hexdigest()[:10]
+    out = os.path.join(ROOT, "oracle", "_fast", "libbf_oracle_fast_%s.so" % tag)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(ROOT, "oracle", "bf_oracle.cpp")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "fast", "FAST_OUT=" + out], check=True)
+    return out
+
+
+def cpu_baseline(w, args):
+    """the oracle (kind "port": a CPU restatement of the reference's scalar path; the reference itself
+    cannot be built offline and neither embree nor TBB exist here) built -O3 -march=native -ffp-contract=off, with its own
+    binned-SAH BVH, on this box's host cores: one warm-up + best of 3, all cores and one core, bounded samples of the same
+    scene and launch."""
+    import ctypes as C
     from beifong_amd import capi
-    from tests.oracle_lib import OracleScene
-    # the GPU box's CPU share for one GPU is 16 cores (task brief); affinity may list the whole host
-    cores = min(16, len(os.sched_getaffinity(0)))
-    o = OracleScene(sd)
-    l = capi.make_launch(lp.mode, args.cpu_paths, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
+    from tests import oracle_lib
+    lib = oracle_lib.load_from(fast_oracle_path())
+    cores = min(16, len(os.sched_getaffinity(0)))       # the GPU box's CPU share for one GPU is 16 cores
     t0 = time.perf_counter()
-    _, _, st = o.render(l, rng_mode=0, threads=cores)
-    dt = time.perf_counter() - t0
-    rays = st.n_rays_closest + st.n_rays_shadow
-    # single core (BASELINE.md §3 asks for both): 1/16 of the sample, the reference's own 1x1-film renders are one thread
-    n1 = max(1 << 16, args.cpu_paths // 16)
-    l1 = capi.make_launch(lp.mode, n1, seed=lp.seed, bins=lp.bins, bin_width=lp.bin_width, color_mode=lp.color_mode)
-    t1 = time.perf_counter()
-    _, _, st1 = o.render(l1, rng_mode=0, threads=1)
-    dt1 = time.perf_counter() - t1
+    o = oracle_lib.OracleScene(w.sd, accel=2, lib=lib)
+    t_build = time.perf_counter() - t0
+
+    def run(n_paths, threads):
+        l = w.launch(0)
+        l.n_paths = n_paths
+        l.path_offset = 0
+        best, rays = None, 0
+        for k in range(4):                                  # first = warm-up
+            t = time.perf_counter()
+            _, _, st = o.render(l, rng_mode=0, threads=threads)
+            d = time.perf_counter() - t
+            rays = st.n_rays_closest + st.n_rays_shadow
+            if k and (best is None or d < best):
+                best = d
+        return rays, best
+
+    n_all = w.cpu_paths
+    n_one = max(1 << 14, n_all // 16)
+    rays_all, t_all = run(n_all, cores)
+    rays_one, t_one = run(n_one, 1)
     return {
-        "value": round(rays / dt / 1e6, 3),
+        "value": round(rays_all / t_all / 1e6, 3),
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d paths of the same C2 scene (same seed, per-path PCG32 streams), oracle/bf_oracle.cpp with its "
-                  "own median-split BVH, %d std::threads, %.1f s wall" % (args.cpu_paths, cores, dt),
-        "value_1core": round((st1.n_rays_closest + st1.n_rays_shadow) / dt1 / 1e6, 3),
-        "sample_1core": "%d paths, 1 thread, %.1f s wall" % (n1, dt1),
+        "what": "SAH BVH2 port of the reference's scalar path (oracle/bf_oracle.cpp, accel = binned SAH, 16 bins, leaves <= 4); no embree, no TBB "
+                "(neither exists offline); reported baseline, not the optimisation target",
+        "build": "g++ -O3 -march=native -std=c++17 -ffp-contract=off -fno-fast-math (oracle/Makefile: fast), built on this host",
+        "protocol": "1 warm-up + best of 3, wall clock around bfo_render",
+        "sample": "%d paths of the same scene and launch (seed of step 0, per-path PCG32 streams), %d std::threads, best %.2f s; BVH build %.2f s"
+                  % (n_all, cores, t_all, t_build),
+        "value_1core": round(rays_one / t_one / 1e6, 3),
+        "sample_1core": "%d paths, 1 thread, best %.2f s" % (n_one, t_one),
     }
 
 

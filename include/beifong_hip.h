@@ -256,6 +256,18 @@ typedef struct bf_stats {
                                   by wf_shade: rectangles + BVH root-box test)       */
     uint64_t n_nodes_lds;      /* of n_nodes_visited: served from wf_trace's LDS copy of
                                   the tree's top levels (only with BF_FLAG_STATS)     */
+    /* per-kernel breakdown (what bench.py prices each kernel's roofline entry with) */
+    uint64_t n_nodes_tail;     /* four-wide node visits of the tail kernel (BF_FLAG_STATS)   */
+    uint64_t n_wnodes_tail;    /* sixteen-wide (512-byte) node visits of the tail kernel's row
+                                  traversal (BF_FLAG_STATS); included in n_nodes_visited      */
+    uint64_t n_tris_tail;      /* triangle tests of the tail kernel (BF_FLAG_STATS)           */
+    uint64_t n_bounces_tail;   /* vertices shaded by the tail kernel                          */
+    uint64_t n_shade_loads;    /* path-state rows wf_shade read                               */
+    uint64_t n_shade_stores;   /* path-state rows wf_shade wrote back                         */
+    uint64_t n_shade_shadow;   /* shadow requests wf_shade queued                             */
+    uint64_t n_shade_rays;     /* rays generated by wf_shade (rectangle + root-box test each) */
+    uint64_t n_guard;          /* rays dropped by wf_trace's iteration guard: always 0, else the
+                                  render call fails with BF_ERR_DEVICE                        */
 } bf_stats;
 
 typedef struct bf_scene_info {

@@ -528,6 +528,7 @@ struct OScene {
     std::vector<BVHNode> nodes;
     std::vector<uint32_t> tri_order;
     bool brute_force = false;
+    int accel = 0;            // 0: median-split BVH (tests), 1: brute force, 2: binned-SAH BVH (CPU baseline timing)
 };
 
 // ---------------------------------------------------------------------------
@@ -653,9 +654,141 @@ template <bool Any> static bool traverse(const OScene &sc, const Ray &ray, Hit &
     return best.valid();
 }
 
+// Binned surface-area-heuristic BVH (accel = 2): the oracle's stand-in for the reference's native accelerator, an SAH
+// kd-tree (include/mitsuba/render/kdtree.h:2079-2170; Scene::accel_init_cpu, src/librender/scene_native.inl:3-10),
+// used for the CPU BASELINE TIMING of bench.py — closest hits do not depend on the accelerator (tie rule above), so
+// the tests keep the simpler median split below.  Own implementation (16 bins per axis, leaves of <= 4 triangles,
+// explicit stack), independent of the product's builder (beifong_amd/csrc/bf_bvh.cpp).
+static void build_bvh_sah(OScene &sc) {
+    const size_t n = sc.tris.size();
+    sc.tri_order.resize(n);
+    for (size_t i = 0; i < n; ++i) sc.tri_order[i] = (uint32_t) i;
+    sc.nodes.clear();
+    if (!n) return;
+    std::vector<V3> cent(n), lo(n), hi(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Tri &t = sc.tris[i];
+        lo[i] = {std::min({t.p0.x, t.p1.x, t.p2.x}), std::min({t.p0.y, t.p1.y, t.p2.y}), std::min({t.p0.z, t.p1.z, t.p2.z})};
+        hi[i] = {std::max({t.p0.x, t.p1.x, t.p2.x}), std::max({t.p0.y, t.p1.y, t.p2.y}), std::max({t.p0.z, t.p1.z, t.p2.z})};
+        cent[i] = (lo[i] + hi[i]) * 0.5f;
+    }
+    auto comp = [](const V3 &v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); };
+    auto half_area = [](const V3 &a, const V3 &b) {
+        const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+        return (dx < 0.f || dy < 0.f || dz < 0.f) ? 0.f : dx * dy + dy * dz + dz * dx;
+    };
+    struct Job {
+        uint32_t node, first, count, depth;
+    };
+    constexpr int NB = 16;
+    std::vector<Job> todo;
+    sc.nodes.push_back({});
+    todo.push_back({0, 0, (uint32_t) n, 0});
+    while (!todo.empty()) {
+        const Job j = todo.back();
+        todo.pop_back();
+        V3 blo = {kInf, kInf, kInf}, bhi = {-kInf, -kInf, -kInf}, clo = blo, chi = bhi;
+        for (uint32_t i = 0; i < j.count; ++i) {
+            const uint32_t ti = sc.tri_order[j.first + i];
+            blo = {std::min(blo.x, lo[ti].x), std::min(blo.y, lo[ti].y), std::min(blo.z, lo[ti].z)};
+            bhi = {std::max(bhi.x, hi[ti].x), std::max(bhi.y, hi[ti].y), std::max(bhi.z, hi[ti].z)};
+            clo = {std::min(clo.x, cent[ti].x), std::min(clo.y, cent[ti].y), std::min(clo.z, cent[ti].z)};
+            chi = {std::max(chi.x, cent[ti].x), std::max(chi.y, cent[ti].y), std::max(chi.z, cent[ti].z)};
+        }
+        const V3 ext = bhi - blo;
+        const float pad = 1e-5f * std::max({ext.x, ext.y, ext.z, hmax_abs(blo), hmax_abs(bhi)}) + 1e-30f;
+        BVHNode nd;
+        nd.lo[0] = blo.x - pad; nd.lo[1] = blo.y - pad; nd.lo[2] = blo.z - pad;
+        nd.hi[0] = bhi.x + pad; nd.hi[1] = bhi.y + pad; nd.hi[2] = bhi.z + pad;
+        nd.left = nd.right = -1;
+        nd.axis = 0;
+        nd.first = j.first;
+        nd.count = j.count;
+        if (j.count > 4) {
+            int best_ax = -1, best_bin = -1;
+            float best_cost = kInf;
+            for (int ax = 0; ax < 3 && j.depth < 100; ++ax) {
+                const float c0 = comp(clo, ax), c1 = comp(chi, ax);
+                if (!(c1 > c0)) continue;
+                V3 bl[NB], bh[NB];
+                uint32_t bc[NB];
+                for (int b = 0; b < NB; ++b) {
+                    bl[b] = {kInf, kInf, kInf};
+                    bh[b] = {-kInf, -kInf, -kInf};
+                    bc[b] = 0;
+                }
+                const float scale = (float) NB / (c1 - c0);
+                for (uint32_t i = 0; i < j.count; ++i) {
+                    const uint32_t ti = sc.tri_order[j.first + i];
+                    const int b = std::min(NB - 1, std::max(0, (int) ((comp(cent[ti], ax) - c0) * scale)));
+                    bl[b] = {std::min(bl[b].x, lo[ti].x), std::min(bl[b].y, lo[ti].y), std::min(bl[b].z, lo[ti].z)};
+                    bh[b] = {std::max(bh[b].x, hi[ti].x), std::max(bh[b].y, hi[ti].y), std::max(bh[b].z, hi[ti].z)};
+                    ++bc[b];
+                }
+                float ra[NB];
+                uint32_t rc[NB];
+                V3 al = {kInf, kInf, kInf}, ah = {-kInf, -kInf, -kInf};
+                uint32_t cnt = 0;
+                for (int b = NB - 1; b > 0; --b) {
+                    al = {std::min(al.x, bl[b].x), std::min(al.y, bl[b].y), std::min(al.z, bl[b].z)};
+                    ah = {std::max(ah.x, bh[b].x), std::max(ah.y, bh[b].y), std::max(ah.z, bh[b].z)};
+                    cnt += bc[b];
+                    ra[b] = half_area(al, ah);
+                    rc[b] = cnt;
+                }
+                al = {kInf, kInf, kInf};
+                ah = {-kInf, -kInf, -kInf};
+                cnt = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    al = {std::min(al.x, bl[b].x), std::min(al.y, bl[b].y), std::min(al.z, bl[b].z)};
+                    ah = {std::max(ah.x, bh[b].x), std::max(ah.y, bh[b].y), std::max(ah.z, bh[b].z)};
+                    cnt += bc[b];
+                    if (!cnt || !rc[b + 1]) continue;
+                    const float cost = half_area(al, ah) * (float) cnt + ra[b + 1] * (float) rc[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_ax = ax;
+                        best_bin = b;
+                    }
+                }
+            }
+            uint32_t mid = j.count / 2;
+            if (best_ax >= 0) {
+                const float c0 = comp(clo, best_ax), scale = (float) NB / (comp(chi, best_ax) - c0);
+                auto it = std::partition(sc.tri_order.begin() + j.first, sc.tri_order.begin() + j.first + j.count, [&](uint32_t ti) {
+                    return std::min(NB - 1, std::max(0, (int) ((comp(cent[ti], best_ax) - c0) * scale))) <= best_bin;
+                });
+                mid = (uint32_t) (it - (sc.tri_order.begin() + j.first));
+                nd.axis = best_ax;
+            }
+            if (best_ax < 0 || mid == 0 || mid == j.count) {
+                // coincident centroids (or the depth guard): median by the longest centroid axis
+                const V3 ce = chi - clo;
+                const int ax = (ce.x >= ce.y && ce.x >= ce.z) ? 0 : (ce.y >= ce.z ? 1 : 2);
+                mid = j.count / 2;
+                std::nth_element(sc.tri_order.begin() + j.first, sc.tri_order.begin() + j.first + mid,
+                                 sc.tri_order.begin() + j.first + j.count,
+                                 [&](uint32_t a, uint32_t b) { return comp(cent[a], ax) < comp(cent[b], ax); });
+                nd.axis = ax;
+            }
+            nd.left = (int32_t) sc.nodes.size();
+            nd.right = nd.left + 1;
+            sc.nodes.push_back({});
+            sc.nodes.push_back({});
+            todo.push_back({(uint32_t) nd.left, j.first, mid, j.depth + 1});
+            todo.push_back({(uint32_t) nd.right, j.first + mid, j.count - mid, j.depth + 1});
+        }
+        sc.nodes[j.node] = nd;
+    }
+}
+
 // median-split BVH over triangle centroids (oracle's own accelerator; results
 // are accelerator-independent thanks to the tie rule above)
 static void build_bvh(OScene &sc) {
+    if (sc.accel == 2) {
+        build_bvh_sah(sc);
+        return;
+    }
     size_t n = sc.tris.size();
     sc.tri_order.resize(n);
     for (size_t i = 0; i < n; ++i) sc.tri_order[i] = (uint32_t) i;
@@ -1866,7 +1999,8 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
     if (!d || !out) return BF_ERR_INVALID;
     bfo_scene *h = new bfo_scene();
     OScene &sc = h->sc;
-    sc.brute_force = brute_force != 0;
+    sc.brute_force = brute_force == 1;      // `brute_force` doubles as the accelerator choice (OScene::accel)
+    sc.accel = brute_force;
     sc.sensor = d->sensor;
     sc.array_tables.reserve(d->n_emitters + 1);      // no reallocation: the records point into these vectors
     if (d->sensor.type == BF_RECEIVER_PHASED && d->sensor.array.velems) {

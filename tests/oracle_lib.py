@@ -23,7 +23,13 @@ def load():
     src = os.path.join(ORACLE_DIR, "bf_oracle.cpp")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         build()
-    lib = C.CDLL(LIB)
+    _lib = load_from(LIB)
+    return _lib
+
+
+def load_from(path):
+    """Bind an oracle build (the checker's -O2 library, or bench.py's -O3 -march=native timing build of the same source)."""
+    lib = C.CDLL(path)
     vp = C.c_void_p
     lib.bfo_last_error.restype = C.c_char_p
     lib.bfo_scene_create.argtypes = [C.POINTER(capi.bf_scene_desc), C.c_int, C.POINTER(vp)]
@@ -56,7 +62,6 @@ def load():
     lib.bfo_elementary.restype = None
     lib.bfo_rect_area.argtypes = [vp, C.c_uint32]
     lib.bfo_rect_area.restype = C.c_float
-    _lib = lib
     return lib
 
 
@@ -65,11 +70,12 @@ def _ptr(a):
 
 
 class OracleScene:
-    def __init__(self, holder, brute_force=False):
-        self.lib = load()
+    def __init__(self, holder, brute_force=False, accel=None, lib=None):
+        """accel: 0 median-split BVH (default), 1 brute force (== brute_force=True), 2 binned-SAH BVH (the CPU baseline's)."""
+        self.lib = lib or load()
         self.holder = holder
         h = C.c_void_p()
-        st = self.lib.bfo_scene_create(C.byref(holder.desc), int(brute_force), C.byref(h))
+        st = self.lib.bfo_scene_create(C.byref(holder.desc), int(brute_force) if accel is None else int(accel), C.byref(h))
         if st != 0:
             raise RuntimeError(f"bfo_scene_create failed: {self.lib.bfo_last_error().decode()}")
         self.handle = h

@@ -110,14 +110,14 @@ def test_batch_with_mesh_offsets_equals_translated_scenes(hiplib, iq):
     _same_records(rb[k], ro)
 
 
-def _bus_receive_with_mesh(v, f):
+def _bus_receive_with_mesh(v, f, t_bins=256, dr=0.1, lambda_band_nm=None):
     """scenes.bus_receive with the bus vertices replaced (same endpoints, materials, ADC)."""
     from beifong_amd import meshgen
     orig_bus, orig_place = meshgen.bus, meshgen.place
     try:
         meshgen.bus = lambda n, seed=1: (v, f)
         meshgen.place = lambda vv, yaw_deg=0.0, translate=(0, 0, 0): vv
-        sd, _ = scenes.bus_receive(n_tris=len(f), n_paths=64, t_bins=256, dr=0.1)
+        sd, _ = scenes.bus_receive(n_tris=len(f), n_paths=64, t_bins=t_bins, dr=dr, lambda_band_nm=lambda_band_nm)
     finally:
         meshgen.bus, meshgen.place = orig_bus, orig_place
     return sd

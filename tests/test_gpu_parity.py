@@ -957,3 +957,75 @@ def test_fuzz_random_scenes_receive(hiplib, seed):
         assert (sg.n_rays_closest, sg.n_rays_shadow, sg.n_bounces, sg.n_invalid) == (so.n_rays_closest, so.n_rays_shadow, so.n_bounces, so.n_invalid)
         amax = float(np.nanmax(np.abs(ro["L"])))
         assert np.allclose(hg, ho, rtol=2e-5, atol=lp.n_paths * 2.0 ** -24 * max(amax, 1.0) * 4), seed
+
+
+@pytest.mark.timeout(300)
+def test_trace_scheduling_extremes_complete_without_guard(hiplib, monkeypatch):
+    """wf_trace's straggler rule postpones the node steps of a few lanes while others hold leaves; its progress condition
+    ("only if some lane HAS a leaf to intersect") is what the one GPU hang of round 1 lacked.  BF_TRACE_STRAGGLERS=64 /
+    BF_TRACE_REFILL=0 is the configuration that rule protects: every node step is postponable and no lane is refilled
+    before the whole wave is idle.  The render must complete, the iteration guard must not have dropped a ray
+    (bf_stats.n_guard == 0; a non-zero count makes bf_render fail with BF_ERR_DEVICE), every path as the oracle's."""
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 16, bins=256, dr=0.1)
+    out = OracleScene(sd).render(lp, records=True, threads=8)
+    for strag, refill in (("64", "0"), ("1", "63"), ("12", "44")):
+        monkeypatch.setenv("BF_TRACE_STRAGGLERS", strag)
+        monkeypatch.setenv("BF_TRACE_REFILL", refill)
+        g = capi.Scene(sd)
+        for _ in range(2):                                   # synchronous, then planned
+            _, _, st = _render_compare_one(g, lp, out, 2e-5)
+            assert st.n_guard == 0 and st.n_rays_traced > 0
+
+
+@pytest.mark.timeout(900)
+def test_c5_full_size_sweep(hiplib):
+    """BASELINE configs[4] at its configured size on one GPU: 200 k-triangle bus, 64 pulses x 2^20 paths, 1024 fast-time
+    bins, I/Q ADC, through PulseSweeper (batched launches; the loop it replaces: python_scripts/animated_trans_rad.py:307-384).
+    Pulses 0, 31 and 63 of the cube equal stand-alone renders of the translated scene; every path of those pulses equals
+    the oracle's on a scene BUILT from the shifted vertices; the Doppler line of a 0.5 m/s target lands in the predicted bin."""
+    pytest.importorskip("torch")
+    from beifong_amd import sweep
+    n_pulses, pri, lam0 = 64, 1e-3, 8.6e6
+    sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 20, t_bins=1024, dr=0.03, seed=4,
+                                lambda_band_nm=(lam0 * 0.999, lam0 * 1.001))
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    speed = 0.5
+    offsets = np.zeros((n_pulses, 3), np.float32)
+    offsets[:, 0] = (-speed * pri * np.arange(n_pulses)).astype(np.float32)
+    sw = sweep.PulseSweeper(sd, lp, n_streams=2)
+    cube = sw.render(offsets)
+    sw.close()
+    assert cube.shape == (n_pulses, 1024, 3)
+    assert np.all(cube[:, :, 2].sum(1) == lp.n_paths)                      # W channel: every path of every pulse binned
+    # the Doppler line: 2 v PRI / lambda cycles per pulse (the analysis of tools/c5_sweep.py)
+    rd = np.abs(sweep.range_doppler(cube))
+    far = rd[:, 200:]
+    prof = far[2:-1].sum(1)
+    k = int(np.argmax(prof)) + 2
+    lam = lam0 * 1e-9
+    expect = (2 * speed * pri / lam * n_pulses) % n_pulses
+    assert abs(k - expect) <= 1.0, (k, expect)
+    assert prof.max() > 20 * np.median(prof)
+    # three pulses: stand-alone renders of the translated scene, and the oracle per path
+    pick = [0, 31, 63]
+    g = capi.Scene(sd)
+    hb, rb, _ = g.render_batch(lp, len(pick), offsets=offsets[pick], records=True)
+    v, f = meshgen.bus(200_000, seed=1)
+    v = meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7)).astype(np.float32)
+    g2 = capi.Scene(sd)
+    for j, kk in enumerate(pick):
+        scale = float(np.abs(hb[j]).max())
+        assert np.allclose(hb[j].reshape(1024, 3), cube[kk], rtol=1e-4, atol=1e-5 * scale)
+        g2.translate_meshes(offsets[kk])
+        hs, rs, _ = g2.render(lp, records=True)
+        for key in ("L", "aux"):
+            assert np.array_equal(rb[j][key].view(np.uint32), rs[key].view(np.uint32))
+        assert np.array_equal(rb[j]["n_rays"], rs["n_rays"])
+        assert np.allclose(hb[j], hs, rtol=1e-4, atol=1e-5 * scale)
+        v1 = np.ascontiguousarray((v + offsets[kk][None, :]).astype(np.float32))
+        from tests.test_gpu_batch import _bus_receive_with_mesh
+        sd1 = _bus_receive_with_mesh(v1, f, t_bins=1024, dr=0.03, lambda_band_nm=(lam0 * 0.999, lam0 * 1.001))
+        _, ro, _ = OracleScene(sd1).render(lp, records=True, threads=8)
+        for key in ("L", "aux"):
+            assert np.array_equal(rb[j][key].view(np.uint32), ro[key].view(np.uint32))
+        assert np.array_equal(rb[j]["n_rays"], ro["n_rays"]) and np.array_equal(rb[j]["valid"], ro["valid"])
