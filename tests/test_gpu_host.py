@@ -201,13 +201,15 @@ def test_file_loaded_mesh_renders_on_hip(mitsuba, hiplib, tmp_path, kind):
     sensor = scene.sensors()[0]
     desc = scene.flat_desc(sensor)
     sh = desc.desc.shapes[2]
-    assert sh.n_faces == len(f) and sh.n_vertices == len(v) and bool(sh.normals)
+    # (the generator leaves a few vertices unreferenced; the obj loader only materialises the ones faces use)
+    assert sh.n_faces == len(f) and bool(sh.normals) and (sh.n_vertices == len(v) if kind == "ply" else 0 < sh.n_vertices <= len(v))
     pos = np.ctypeslib.as_array(sh.positions, shape=(sh.n_vertices, 3))
     idx = np.ctypeslib.as_array(sh.indices, shape=(sh.n_faces, 3))
     assert np.array_equal(pos[idx], v[f])        # same triangles (the obj loader numbers vertices by first use: obj.cpp:243-262)
     if kind == "ply":
         assert np.array_equal(pos, v) and np.array_equal(idx, f)
-        assert np.array_equal(np.ctypeslib.as_array(sh.normals, shape=(len(v), 3)), n)
+        # the loader passes normals through to_world and re-normalises them (ply.cpp:222-232): an ulp may move
+        assert np.allclose(np.ctypeslib.as_array(sh.normals, shape=(len(v), 3)), n, rtol=0, atol=2e-7)
     # through the plugin surface: Integrator::render -> C ABI -> HIP
     scene.integrator().render(scene, sensor)
     bmp = np.array(sensor.film().bitmap(raw=True)).reshape(-1)
