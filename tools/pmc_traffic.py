@@ -1,0 +1,48 @@
+"""Per-kernel HBM traffic of the bench configs from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+tools/profile_r02.sh -> the JSON bench.py reads as `roofline.kernels[].traffic` (profiles/r02_pmc_traffic.json).
+Units and corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports half the
+bytes of wide (16 B per lane) loads -> x 2; WRITE_SIZE is exact."""
+import collections
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+root = sys.argv[1]
+CLASS = (("wf_trace", "wf_trace"), ("wf_shade", "wf_shade"), ("bf_render_kernel", "tail"))
+out = {}
+for cfg in ("c2", "c3", "c4shard", "c5"):
+    per = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {}})
+    found = False
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for db in glob.glob(os.path.join(root, "pmc_%s_%s" % (cfg, ctr), "**", "*.db"), recursive=True):
+            found = True
+            cur = sqlite3.connect(db).cursor()
+            for name, did, cname, val in cur.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+                if "wf_trace<true" in name or "bf_render_kernel<true" in name:
+                    continue                      # the BF_FLAG_STATS variants of bench.py's counter pass: not the product kernels
+                for key, cls in CLASS:
+                    if key in name and cname == ctr:
+                        per[cls][ctr] += val
+                        per[cls]["n"].setdefault(ctr, set()).add(did)
+    if not found:
+        continue
+    try:
+        with open(os.path.join(root, "pmc_%s_FETCH_SIZE.json" % cfg)) as f:
+            line = json.loads(f.read().strip().splitlines()[-1])
+        paths = line["config"]["paths_per_gpu_per_step"] // (64 if cfg == "c5" else 1)
+    except Exception:
+        paths = None
+    e = {"paths": paths, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --config %s --steps 2 --warmup 0 --no-cpu --streams 1" % cfg,
+         "fetch_correction": 2.0, "traffic_bytes_per_launch": {}, "dispatches": {}, "fetch_kib_sum": {}, "write_kib_sum": {}}
+    for cls, d in per.items():
+        nf, nw = len(d["n"].get("FETCH_SIZE", ())), len(d["n"].get("WRITE_SIZE", ()))
+        if not nf or not nw:
+            continue
+        e["traffic_bytes_per_launch"][cls] = round(2.0 * d["FETCH_SIZE"] * 1024 / nf + d["WRITE_SIZE"] * 1024 / nw)
+        e["dispatches"][cls] = nf
+        e["fetch_kib_sum"][cls] = d["FETCH_SIZE"]
+        e["write_kib_sum"][cls] = d["WRITE_SIZE"]
+    out[cfg] = e
+print(json.dumps(out, indent=1))
