@@ -23,7 +23,7 @@ BF_VELEM_FLOATS = 32
 BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
-BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL = 1, 2, 4
+BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL, BF_FLAG_DOPPLER = 1, 2, 4, 8
 
 M16 = C.c_float * 16
 
@@ -39,7 +39,8 @@ class bf_shape(C.Structure):
     _fields_ = [("type", C.c_uint32), ("material", C.c_uint32), ("emitter", C.c_int32),
                 ("is_sensor", C.c_uint32), ("to_world", M16), ("to_object", M16),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
-                ("texcoords", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32)]
+                ("texcoords", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32)), ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32),
+                ("velocity", M16)]
 
 
 class bf_phased_array(C.Structure):

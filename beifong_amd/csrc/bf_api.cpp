@@ -144,6 +144,7 @@ struct bf_scene {
         uint32_t iters = 0, tail_live = 0;
     };
     mutable WfPlan wf_plan;
+    mutable float *wf_dop_buf = nullptr;         // per-slot wavelength shift (WF::dop when BF_FLAG_DOPPLER is set)
     mutable uint32_t *wf_render_buf = nullptr;   // per-slot render index of batched launches (WF::render when a batch runs)
     // Pinned staging for small host tables that travel with a launch (batch seeds / mesh offsets, endpoint records):
     // a ring of slots, each with its own device mirror and an event recorded behind the copy, so the caller's arrays
@@ -344,6 +345,11 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         ds.material = s.material;
         ds.emitter = s.emitter;
         ds.rect = -1;
+        {
+            bool any = false;
+            for (int k = 0; k < 16; ++k) any = any || s.velocity[k] != 0.f;
+            for (int k = 0; k < 12; ++k) ds.velocity[k] = any ? s.velocity[k] : ((k % 5 == 0) ? 1.f : 0.f);    // all zeros = identity
+        }
         if (s.type == BF_SHAPE_RECTANGLE) {
             bfd::DRect rc;
             m34(s.to_world, rc.to_world);
@@ -949,6 +955,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.sh2, n * 4));
     HIP_TRY(alloc((void **) &wf.sh3, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_render_buf, n * 4));
+    HIP_TRY(alloc((void **) &scene->wf_dop_buf, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     wf.counters = scene->counters;
@@ -989,6 +996,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         wf.iq = lp.iq;
         wf.render = lp.batch != 0u ? scene->wf_render_buf : nullptr;
         wf.offsets = lp.batch_offsets;
+        wf.dop = lp.doppler ? scene->wf_dop_buf : nullptr;
         wf.box_slack = lp.box_slack;
         const char *e4 = getenv("BF_TAIL_ROWJOBS");
         wf.row_jobs = e4 ? (uint32_t) atoi(e4) : bfd::kTailRowJobs;
@@ -1223,6 +1231,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);
     lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
+    lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;
     lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);

@@ -40,6 +40,7 @@ struct DShape {
     uint32_t type, material;
     int32_t emitter;
     int32_t rect;         // index into rects or -1
+    float velocity[12];   // Shape "velocity" transform (shape.cpp:42), 3x4 row-major: BF_FLAG_DOPPLER only
 };
 
 struct DEmitter {
@@ -119,6 +120,7 @@ struct DLaunch {
     uint64_t batch_paths;
     const uint64_t *batch_seeds;    // device [batch], or nullptr: `seed` for every render (common random numbers)
     const float4 *batch_offsets;    // device [batch] (x, y, z, -), or nullptr: meshes as built
+    uint32_t doppler;               // BF_FLAG_DOPPLER (receive modes): Shape::doppler shifts the path's wavelength
     float box_slack;                // offsets only: node boxes widened by this much on the ray's side (bf_device_core.h: RayBox)
 };
 

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_
     PathState s;
     s.flags = 0;
     s.render = 0u;                     // lanes without a path still index the batch tables (path_shift)
+    s.dlambda = 0.f;
     s.rmint = 0.f;
     s.rmaxt = 0.f;
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};

@@ -42,6 +42,7 @@ struct PathState {
     float t_rx;          // sampled receive time (integrator.cpp:1556-1561)
     float lambda0;       // ray.wavelengths[0] in nm
     float phase;         // ray.phase of the working ray: last traced segment only (ray.h:89-93, interaction.h:61-64)
+    float dlambda;       // BF_FLAG_DOPPLER: what the Doppler hook has added to the caller's ray.wavelengths[0] (nm)
 };
 
 BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
@@ -64,6 +65,7 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     s.path_i = ((uint64_t) d.w << 32) | d.z;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
     s.render = wf.render ? wf.render[i] : 0u;
+    s.dlambda = wf.dop ? wf.dop[i] : 0.f;
     if (receive) {
         float4 e = wf.se[i];
         s.time = e.x;
@@ -81,6 +83,13 @@ BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState 
                           (uint32_t) (s.path_i >> 32));
     if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, s.phase);
     if (wf.render) wf.render[j] = s.render;
+    if (wf.dop) wf.dop[j] = s.dlambda;
+}
+// Shape::doppler — src/librender/shape.cpp:375-389 (call sites commented out at the reference's HEAD:
+// pathtimefrequency.cpp:141-144, 180-183): 2 dot(si.wi, m_velocity * Point3f(si.to_local(si.p))) / MTS_C * wavelength
+BF_DEV float shape_doppler(const DScene &sc, const SI &si, float lambda_nm) {
+    V3 q = xf_point(sc.shapes[si.shape].velocity, to_local(si.sh, si.p));
+    return 2.f * dot(si.wi, q) / sc.c * lambda_nm;
 }
 // the mesh shift of the path's render (batched launches with moving meshes; off otherwise)
 BF_DEV Shift path_shift(const DLaunch &lp, uint32_t render) { return make_shift(lp.batch_offsets, render, lp.box_slack); }
@@ -391,6 +400,7 @@ BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, 
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
     float ax = .5f, ay = .5f;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
+    s.dlambda = 0.f;
     bool film_ok = true, film_left = false, film_up = false;
     if (receive) {
         // receive_sample — integrator.cpp:1544-1572
@@ -503,6 +513,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         if (si_valid) s.flags |= kFlagValid;
         if (is_range) s.aux += si_valid ? si.t : 0.f;
         if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
+        if (receive && si_valid && lp.doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);   // :141-144
         if (receive && si_valid) {                                 // ray.update_state(-si.t); si.time = ray.time
             s.time += -si.t / sc.c;
             if (lp.phase_bins) s.phase = phase_update(s.phase, -si.t, sc.lambda_min, sc.lambda_max);
@@ -529,6 +540,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     // head of iteration `depth` — path.cpp:121-145
     if (emitter >= 0) {
         const DEmitter &e = sc.emitters[emitter];
+        if (receive && lp.doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
         float ev;
         if (receive)
             ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
@@ -663,7 +675,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
         float tf0 = s.t_rx - se.adc_sampling_start;
-        float tf1 = freq_of(sc.c, s.lambda0);
+        float tf1 = freq_of(sc.c, lp.doppler ? s.lambda0 + s.dlambda : s.lambda0);
         tf0 *= (float) se.t_bins / se.t_bandwidth;
         tf1 *= (float) se.f_bins / se.f_bandwidth;
         float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode

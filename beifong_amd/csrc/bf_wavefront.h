@@ -42,6 +42,7 @@ struct WF {
     float4 *sh1;        // d.xyz, maxt
     float *sh2;         // contribution released when unoccluded
     float *sh3;         // BF_MODE_RECEIVE_IQ: its imaginary part
+    float *dop;         // BF_FLAG_DOPPLER: wavelength shift accumulated by the slot's path (nm); nullptr when the hook is off
     uint32_t *render;   // batched launches: render index of the slot's current path (selects the mesh offset)
     const float4 *offsets;   // batched launches with moving meshes: DLaunch::batch_offsets (wf_trace has no DLaunch)
     float box_slack;

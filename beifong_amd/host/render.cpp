@@ -234,6 +234,7 @@ Receiver::Receiver(const Properties &props) : Endpoint(props) {
 
 Shape::Shape(const Properties &props) {
     m_to_world = props.transform("to_world", Transform4f());
+    m_velocity = props.transform("velocity", Transform4f());
     // shape.cpp:38-98
     for (auto &kv : props.objects(false)) {
         Object *o = kv.second.get();
@@ -407,6 +408,7 @@ void Scene::flatten(const Endpoint *endpoint) {
         }
         bs.material = it->second;
         bs.emitter = -1;
+        copy16(bs.velocity, s->velocity().matrix);
         if (s->is_rectangle()) {
             bs.type = BF_SHAPE_RECTANGLE;
             copy16(bs.to_world, s->to_world().matrix);

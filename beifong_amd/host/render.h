@@ -181,6 +181,8 @@ public:
     Sensor *sensor() const { return m_sensor.get(); }
     Receiver *receiver() const { return m_receiver.get(); }
     const Transform4f &to_world() const { return m_to_world; }
+    /// "velocity": the transform Shape::doppler applies (src/librender/shape.cpp:42,375-389), default identity
+    const Transform4f &velocity() const { return m_velocity; }
     virtual uint32_t primitive_count() const = 0;
     virtual float surface_area() const = 0;
     virtual bool is_rectangle() const { return false; }
@@ -193,6 +195,7 @@ public:
 
 protected:
     Transform4f m_to_world;
+    Transform4f m_velocity;
     ref<BSDF> m_bsdf;
     ref<Emitter> m_emitter;
     ref<Transmitter> m_transmitter;

@@ -168,14 +168,15 @@ class SceneDesc:
         return len(self.materials) - 1
 
     # ---- shapes ----
-    def add_rectangle(self, to_world, material, emitter=-1, is_sensor=False):
+    def add_rectangle(self, to_world, material, emitter=-1, is_sensor=False, velocity=None):
         s = capi.bf_shape()
         s.type, s.material, s.emitter, s.is_sensor = capi.BF_SHAPE_RECTANGLE, material, emitter, int(is_sensor)
         s.to_world, s.to_object = _m16(to_world.matrix), _m16(to_world.inv)
+        s.velocity = _m16(np.eye(4) if velocity is None else velocity.matrix)      # Shape "velocity" transform (shape.cpp:42)
         self.shapes.append(s)
         return len(self.shapes) - 1
 
-    def add_mesh(self, positions, indices, material, normals=None, emitter=-1, texcoords=None):
+    def add_mesh(self, positions, indices, material, normals=None, emitter=-1, texcoords=None, velocity=None):
         pos = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nrm = None if normals is None else np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
@@ -184,6 +185,7 @@ class SceneDesc:
         s = capi.bf_shape()
         s.type, s.material, s.emitter, s.is_sensor = capi.BF_SHAPE_MESH, material, emitter, 0
         s.to_world, s.to_object = _m16(np.eye(4)), _m16(np.eye(4))
+        s.velocity = _m16(np.eye(4) if velocity is None else velocity.matrix)
         s.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
         s.normals = nrm.ctypes.data_as(C.POINTER(C.c_float)) if nrm is not None else None
         s.texcoords = tex.ctypes.data_as(C.POINTER(C.c_float)) if tex is not None else None

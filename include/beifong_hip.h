@@ -89,6 +89,9 @@ typedef struct bf_shape {
     const uint32_t *indices; /* [3 * n_faces]                                */
     uint32_t n_vertices;
     uint32_t n_faces;
+    /* Shape "velocity" transform (src/librender/shape.cpp:42, default identity) read by
+       Shape::doppler (shape.cpp:375-389); only used with BF_FLAG_DOPPLER.  All zeros = identity. */
+    float velocity[16];
 } bf_shape;
 
 /* ---------------- emitters / transmitters -------------------------------- */
@@ -225,8 +228,14 @@ typedef struct bf_launch {
 enum {
     BF_FLAG_STATS = 1u,       /* count BVH nodes visited / triangles tested   */
     BF_FLAG_GLOBAL_ATOMICS = 2u, /* skip LDS privatisation (debug / ablation) */
-    BF_FLAG_MEGAKERNEL = 4u    /* single persistent megakernel instead of the
+    BF_FLAG_MEGAKERNEL = 4u,   /* single persistent megakernel instead of the
                                   wavefront pipeline (ablation; same results) */
+    BF_FLAG_DOPPLER = 8u       /* receive modes: the Doppler hook the reference carries commented out
+                                  ("Took doppler out to test", pathtimefrequency.cpp:124-126,141-144,180-183):
+                                  the path's wavelength is shifted by Shape::doppler(si) =
+                                  2 dot(si.wi, velocity * to_local(si.p)) / c * lambda (shape.cpp:388) at its first
+                                  intersection and at every direct transmitter hit, and the shifted wavelength selects
+                                  the ADC's frequency row.  Off by default, as at the reference's HEAD. */
 };
 
 /* per-path record for exact parity tests (optional output) */

@@ -480,6 +480,7 @@ struct Shape {
     uint32_t prim_offset, prim_count;
     int32_t rect;             // index into rects
     uint32_t tri_offset;      // index into tris
+    float velocity[16];       // m_velocity (shape.cpp:42), row-major
 };
 struct Emitter {
     bf_emitter d;
@@ -1346,6 +1347,7 @@ inline float mis_weight(float pdf_a, float pdf_b) {   // path.cpp:222-226
 
 struct PathResult {
     float L = 0, aux = 0;
+    float dlambda = 0;    // BF_FLAG_DOPPLER: what the Doppler hook adds to the caller's ray.wavelengths[0] (nm)
     float phase = 0;      // gen-3: what PathTimeFrequencyIntegrator adds to the caller's ray.phase (:453)
     float L_im = 0;       // BF_MODE_RECEIVE_IQ: imaginary part of the phasor sum (L is the real part)
     bool valid = false;
@@ -1654,6 +1656,17 @@ inline void path_phasor(float length, float lambda_nm, float &re, float &im) {
     im = sn;
 }
 
+// Shape::doppler — src/librender/shape.cpp:375-389:
+//   2 * dot(si.wi, m_velocity * Point3f(si.to_local(si.p))) / MTS_C * si.wavelengths
+// (Endpoint::doppler, endpoint.cpp:27-43, forwards to its shape's with another factor 2; the integrator's — commented
+// out — call sites use the shape's: pathtimefrequency.cpp:141-144,180-183)
+static float shape_doppler(const OScene &sc, const SI &si, float lambda_nm) {
+    M4 vel;
+    std::memcpy(vel.m, sc.shapes[si.shape].velocity, sizeof(vel.m));
+    V3 q = xf_point(vel, si.sh.to_local(si.p));
+    return 2.f * dot(si.wi, q) / sc.physics.c * lambda_nm;
+}
+
 // PathTimeFrequencyIntegrator::sample — src/integrators/pathtimefrequency.cpp:103-460
 static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, const RxCtx &cx) {
     PathResult r;
@@ -1670,6 +1683,8 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
     // (omnidirectional.cpp / wignerreceiver.cpp: Float phase = 0), spawn_ray() does not carry it
     // (interaction.h:61-64), so it only ever holds the LAST traced segment's phase
     float cur_phase = 0.f;
+    const bool doppler = (lp.flags & BF_FLAG_DOPPLER) != 0;
+    if (doppler && si.valid()) r.dlambda += shape_doppler(sc, si, cx.lambda0);      // :141-144 (commented out at HEAD)
     if (si.valid()) {                    // :149-153 ray.update_state(-si.t)
         ray.time += -si.t / c;
         si.time = ray.time;
@@ -1677,6 +1692,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
     }
     for (int depth = 1;; ++depth) {
         if (tx >= 0 && active) {
+            if (doppler) r.dlambda += shape_doppler(sc, si, cx.lambda0);            // :180-183 "Apply doppler from tx hit"
             float contrib = emission_weight * throughput * transmitter_eval(sc, sc.emitters[tx], si, cx);
             if (iq) {
                 float re, im;
@@ -1800,6 +1816,18 @@ static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, 
     return 1.f * s.gain * geom_gain * extents;
 }
 
+// ImageBlock::put, box-filter branch (filter radius <= 0.5 + RayEpsilon) — src/librender/imageblock.cpp:113,166-172 for a
+// block at offset 0 without border: pos = pos_ - 0.5; lo = ceil(pos - 0.5); the sample is added to pixel lo iff
+// 0 <= lo < size (the validity of the values is checked by the caller, :85-111).  SignalBlock::put is the same code
+// (signalblock.cpp:115,162-169).
+static bool imageblock_put_box(double *data, uint32_t w, uint32_t h, uint32_t nchan, float posx, float posy, const float *value) {
+    int lox = (int) std::ceil((posx - .5f) - .5f), loy = (int) std::ceil((posy - .5f) - .5f);
+    if (!(lox >= 0 && lox < (int) w && loy >= 0 && loy < (int) h)) return false;
+    double *dst = data + (size_t) nchan * ((size_t) loy * w + (size_t) lox);
+    for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) value[k];
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // film: SamplingIntegrator::render_sample (integrator.cpp:259-310) +
 // RangeIntegrator / TimeIntegrator AOV fill (range.cpp:141-161,
@@ -1906,13 +1934,7 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     for (uint32_t k = 0; k < nchan; ++k) ok = ok && std::isfinite(aovs[k]);
     // (film level: pos = position_sample - (0 - 0 + .5), imageblock.cpp:113,166-172; the reference applies
     // the same rule per spiral block, whose size follows the thread count)
-    int lox = (int) std::ceil((posx - .5f) - .5f), loy = (int) std::ceil((posy - .5f) - .5f);
-    ok = ok && lox >= 0 && lox < (int) film_w && loy >= 0 && loy < (int) film_h;
-    out.put = ok;
-    if (ok) {
-        double *dst = hist + (size_t) nchan * ((size_t) loy * film_w + (size_t) lox);
-        for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) aovs[k];
-    }
+    out.put = ok && imageblock_put_box(hist, film_w, film_h, nchan, posx, posy, aovs.data());
     return out;
 }
 
@@ -1937,7 +1959,7 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     float w = receiver_sample_ray(sc, time, wl, fx, fy, ax, ay, ray, cx);
     out.pr = ptf_sample(sc, lp, smp, ray, cx);
     float tf0 = time - s.adc_sampling_start;                // :1625-1626
-    float tf1 = freq_of(sc, cx.lambda0);
+    float tf1 = freq_of(sc, (lp.flags & BF_FLAG_DOPPLER) ? cx.lambda0 + out.pr.dlambda : cx.lambda0);
     tf0 *= (float) s.t_bins / s.t_bandwidth;                // :1639
     tf1 *= (float) s.f_bins / s.f_bandwidth;
     float L = std::fabs(w) * out.pr.L;                      // :1643
@@ -2019,6 +2041,11 @@ bf_status bfo_scene_create(const bf_scene_desc *d, int brute_force, bfo_scene **
         sh.prim_offset = prim;
         sh.rect = -1;
         sh.tri_offset = 0;
+        {
+            bool any = false;
+            for (int k = 0; k < 16; ++k) any = any || s.velocity[k] != 0.f;
+            for (int k = 0; k < 16; ++k) sh.velocity[k] = any ? s.velocity[k] : ((k % 5 == 0) ? 1.f : 0.f);   // all zeros = identity
+        }
         if (s.material >= d->n_materials) {
             g_err = "shape material index out of range";
             delete h;
@@ -2345,6 +2372,24 @@ float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x
     return w;
 }
 float bfo_erfinv(float x) { return erfinv_giles(x); }
+/* ImageBlock::put (box filter) on a caller-owned double[h][w][nchan] block; returns 1 if the sample landed.
+ * spectrum != 0: the put(pos, wavelengths, spectrum, alpha) overload for a grey RGB value value[0]
+ * (imageblock.h: XYZ = srgb_to_xyz(rgb), then alpha, then weight 1): nchan must be 5. */
+int bfo_imageblock_put(double *data, uint32_t w, uint32_t h, uint32_t nchan, float posx, float posy, const float *value, int spectrum,
+                       float alpha) {
+    if (spectrum) {
+        float v[5];
+        srgb_to_xyz_grey(value[0], v);
+        v[3] = alpha;
+        v[4] = 1.f;
+        for (int k = 0; k < 5; ++k)
+            if (!std::isfinite(v[k])) return 0;
+        return nchan == 5 && imageblock_put_box(data, w, h, 5, posx, posy, v) ? 1 : 0;
+    }
+    for (uint32_t k = 0; k < nchan; ++k)
+        if (!std::isfinite(value[k])) return 0;
+    return imageblock_put_box(data, w, h, nchan, posx, posy, value) ? 1 : 0;
+}
 /* MicrofacetDistribution unit access (golden vectors of src/librender/tests/test_microfacet.py).
  * op: 0 eval(m), 1 pdf(wi, m), 2 smith_g1(v = m argument, m = wi argument), 3 sample(wi, (s0, s1)) -> out[0..2] = m,
  * out[3] = pdf.  type: BF_MF_*. */

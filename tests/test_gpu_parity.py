@@ -1035,3 +1035,43 @@ def test_c5_full_size_sweep(hiplib):
         for key in ("L", "aux"):
             assert np.array_equal(rb[j][key].view(np.uint32), ro[key].view(np.uint32))
         assert np.array_equal(rb[j]["n_rays"], ro["n_rays"]) and np.array_equal(rb[j]["valid"], ro["valid"])
+
+
+def _doppler_scene(scale):
+    """C2-recv geometry with a 64 x 32 time-frequency ADC whose rows span the received band, and a `velocity` transform
+    (scale * identity, so Shape::doppler = 2 scale dot(wi, to_local(p)) / c * lambda) on the bus."""
+    sd, lp = scenes.bus_receive(n_tris=5000, n_paths=30000, t_bins=64)
+    sd.sensor.f_bins = 32
+    c, lmin = sd.physics.c, sd.physics.lambda_min_nm
+    sd.sensor.f_bandwidth = c / (lmin * 1e-9)
+    vel = np.eye(4, dtype=np.float32) * np.float32(scale)
+    vel[3, 3] = 1.0
+    for s in sd.shapes:
+        if s.type == capi.BF_SHAPE_MESH:
+            s.velocity = (capi.M16)(*vel.reshape(-1).tolist())
+    sd.finalize()
+    lp.bins_y = 32
+    return sd, lp
+
+
+def test_doppler_hook_off_by_default_and_bit_exact_when_on(hiplib):
+    """SURVEY 8(f1): Shape::doppler (shape.cpp:375-389), which the reference carries with its call sites commented out
+    (pathtimefrequency.cpp:124-126, 141-144, 180-183).  BF_FLAG_DOPPLER enables the hook in oracle and kernels: the
+    shifted wavelength selects the ADC's frequency row.  Off (the default, the reference's HEAD) nothing changes; on,
+    every path's record and row equals the oracle's; the shape's velocity transform scales the shift."""
+    sd, lp = _doppler_scene(3.0)
+    h_off, _, _ = _render_compare(sd, lp)
+    lp_on = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_DOPPLER)
+    h_on, ho, _ = _render_compare(sd, lp_on)
+    rows_off = h_off.reshape(32, 64, 3)[:, :, 2].sum(1)
+    rows_on = h_on.reshape(32, 64, 3)[:, :, 2].sum(1)
+    assert rows_off.sum() > 0 and not np.array_equal(rows_off, rows_on)        # the hook moves samples between frequency rows
+    # identity velocity on every shape: another shift, still the oracle's
+    sd1, _ = _doppler_scene(1.0)
+    h1, _, _ = _render_compare(sd1, lp_on)
+    assert not np.array_equal(h1, h_on)
+    # the planned (asynchronous) second render of a shape keeps the per-slot shift
+    g = capi.Scene(sd)
+    out = OracleScene(sd).render(lp_on, records=True, threads=8)
+    for _ in range(3):
+        _render_compare_one(g, lp_on, out, 2e-5)

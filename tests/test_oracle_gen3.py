@@ -131,3 +131,31 @@ def test_iq_mode_is_a_phasor_sum_of_the_raw_contributions():
     raw, iq = raw.reshape(256, 3), iq.reshape(256, 3)
     assert np.allclose(iq[:, 0], raw[:, 0], rtol=1e-5, atol=1e-9 * raw[:, 0].max())
     assert np.abs(iq[:, 1]).max() <= 1e-5 * raw[:, 0].max()
+
+
+def test_doppler_hook_value_and_default():
+    """Shape::doppler (src/librender/shape.cpp:388): 2 dot(si.wi, velocity * to_local(si.p)) / MTS_C * wavelength.  With the
+    identity velocity dot(wi, to_local(p)) = -d . p (orthonormal frame), so a path whose first hit is p (ray direction d)
+    gets d_lambda = -2 (d . p) / c * lambda at that hit: checked through the frequency row the sample lands in for a
+    one-bounce-deep render (max_depth = 1: nothing but the first intersection contributes a shift)."""
+    from beifong_amd import capi, scenes
+    from tests.oracle_lib import OracleScene
+    sd, lp = scenes.bus_receive(n_tris=2000, n_paths=4000, t_bins=8)
+    sd.sensor.f_bins = 64
+    c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
+    sd.sensor.f_bandwidth = c / (lmin * 1e-9)
+    sd.finalize()
+    lp.bins_y = 64
+    lp.max_depth = 1
+    o = OracleScene(sd)
+    h0, _, _ = o.render(lp, threads=4)
+    lp.flags = capi.BF_FLAG_DOPPLER
+    h1, _, _ = o.render(lp, threads=4)
+    w0 = h0.reshape(64, 8, 3)[:, :, 2].sum(1)
+    w1 = h1.reshape(64, 8, 3)[:, :, 2].sum(1)
+    assert w0.sum() > 0 and not np.array_equal(w0, w1)
+    # the rays leave the radar at (0, 0, 0.3) along +x and hit points with d . p > 0: every shift is negative, i.e. towards
+    # SHORTER wavelengths = higher frequency rows (or out of the ADC at its top)
+    centre0 = (np.arange(64) * w0).sum() / w0.sum()
+    centre1 = (np.arange(64) * w1).sum() / max(w1.sum(), 1)
+    assert w1.sum() <= w0.sum() and (w1.sum() == 0 or centre1 > centre0)

@@ -492,3 +492,114 @@ def test_point_light_sample_direction_known_answers():
     assert r["pdf"] == 1.0 and r["delta"] and r["pdf_direction"] == 0.0
     assert np.allclose(r["d"], d / dist, atol=1e-6) and np.isclose(r["dist"], dist, rtol=1e-6)
     assert np.isclose(r["spec"], 3.0 / dist ** 2, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# ImageBlock::put — src/librender/tests/test_imageblock.py:23-100
+# ---------------------------------------------------------------------------
+def _put(oracle, data, pos, value, spectrum=False, alpha=1.0):
+    h, w, c = data.shape
+    v = np.ascontiguousarray(value, np.float32)
+    oracle.bfo_imageblock_put.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float]
+    return oracle.bfo_imageblock_put(data.ctypes.data, w, h, c, float(pos[0]), float(pos[1]), v.ctypes.data, int(spectrum), alpha)
+
+
+def test_imageblock_put_box_filter(oracle):
+    # test_imageblock.py:50-73 (test02_put_image_block): a sample at the centre of every pixel of a 10 x 5 block
+    # reproduces the reference array; accumulating the block five times gives 5 x (put(block) is a plain sum, :49-77)
+    w, h, c = 10, 5, 4
+    ref = (3.14 * np.arange(h * w * c)).reshape(h, w, c)
+    im2 = np.zeros((h, w, c))
+    for x in range(h):
+        for y in range(w):
+            assert _put(oracle, im2, [y + 0.5, x + 0.5], ref[x, y, :]) == 1
+    assert np.allclose(im2, ref.astype(np.float32), atol=1e-9)
+    im = np.zeros((h, w, c))
+    for i in range(5):
+        im += im2
+        assert np.allclose(im, (i + 1) * ref.astype(np.float32).astype(np.float64), atol=1e-9)
+
+
+def test_imageblock_put_spectrum_alpha_weight(oracle):
+    # test_imageblock.py:75-100 (test03_put_values_basic), box filter of radius 0.4 (the branch for radius <= 0.5): one
+    # sample at the centre of each pixel -> XYZ = srgb_to_xyz(spectrum), alpha 1, weight 1 in that pixel only
+    rng = np.random.default_rng(7)
+    w, h = 10, 8
+    im = np.zeros((h, w, 5))
+    ref = np.zeros((h, w, 5))
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])   # spectrum.h:281-287
+    for i in range(h):
+        for j in range(w):
+            g = np.float32(rng.uniform())
+            ref[i, j, :3] = M @ np.array([g, g, g], np.float64)
+            ref[i, j, 3] = 1
+            ref[i, j, 4] = 1
+            assert _put(oracle, im, [j + 0.5, i + 0.5], [g], spectrum=True, alpha=1.0) == 1
+    assert np.allclose(im, ref, atol=1e-6)
+
+
+def test_imageblock_put_edges_and_invalid_samples(oracle):
+    # imageblock.cpp:113,166-172: lo = ceil(pos - 1): a position exactly ON a pixel boundary belongs to the pixel below
+    # it, position 0 falls outside the block; :85-111: a non-finite channel drops the whole sample
+    im = np.zeros((2, 3, 1))
+    assert _put(oracle, im, [1.0, 0.5], [1.0]) == 1 and im[0, 0, 0] == 1          # x = 1.0 -> pixel 0
+    assert _put(oracle, im, [1.0000001, 0.5], [1.0]) == 1 and im[0, 1, 0] == 1    # just above -> pixel 1
+    assert _put(oracle, im, [0.0, 0.5], [1.0]) == 0                               # ceil(-1) = -1: outside
+    assert _put(oracle, im, [3.0, 2.0], [1.0]) == 1 and im[1, 2, 0] == 1          # the far corner is inside
+    assert _put(oracle, im, [3.0000002, 1.0], [1.0]) == 0
+    assert _put(oracle, im, [1.5, 0.5], [np.nan]) == 0 and _put(oracle, im, [1.5, 0.5], [np.inf]) == 0
+    assert im.sum() == 3
+
+
+# ---------------------------------------------------------------------------
+# twosided — src/bsdfs/tests/test_twosided.py:19-42 (flags) and :62-100 (sample / eval / pdf over the sphere)
+# ---------------------------------------------------------------------------
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_twosided_components_are_smooth_on_both_sides(oracle):
+    # test01_create: component 0 = FrontSide, component 1 = BackSide of the nested BSDF (diffuse: DiffuseReflection,
+    # roughconductor: GlossyReflection) — both Smooth, so next-event estimation runs on either side: the pdf of a
+    # two-sided BSDF is that of the nested one for wi.z > 0 and its mirror image for wi.z < 0
+    for kind, kw in (("diffuse", dict(reflectance=0.5)), ("conductor", dict(alpha=0.3))):
+        m = _mat(kind=kind, twosided=True, **kw)
+        one = _mat(kind=kind, twosided=False, **kw)
+        wi, wo = np.array([0.3, -0.2, 0.8], np.float32), np.array([-0.1, 0.4, 0.6], np.float32)
+        wi = (wi / np.linalg.norm(wi)).astype(np.float32)
+        wo = (wo / np.linalg.norm(wo)).astype(np.float32)
+        flip = np.array([1, 1, -1], np.float32)
+        front = oracle.bfo_bsdf_pdf(C.byref(m), _ptr(wi), _ptr(wo))
+        assert front > 0 and front == oracle.bfo_bsdf_pdf(C.byref(one), _ptr(wi), _ptr(wo))
+        back = oracle.bfo_bsdf_pdf(C.byref(m), _ptr(wi * flip), _ptr(wo * flip))
+        assert back == front
+        assert oracle.bfo_bsdf_pdf(C.byref(one), _ptr(wi * flip), _ptr(wo * flip)) == 0.0
+
+
+def test_twosided_sample_eval_pdf_over_the_sphere(oracle):
+    # test03_sample_eval_pdf with the same diffuse BSDF on both sides (the engine's two-sided material nests ONE BSDF):
+    # for wi over the sphere (5 x 5 uniform-sphere grid) and 5 x 5 samples: weight * wo.z / pi (sign flipped below the
+    # surface) == eval within 1e-2, sampled pdf == pdf, no NaNs
+    m = _mat(reflectance=0.5, twosided=True)
+    n = 5
+    checked = 0
+    for u in range(n):
+        for v in range(n):
+            s0, s1 = u / (n - 1.0), v / (n - 1.0)
+            z = 1.0 - 2.0 * s1                                   # warp::square_to_uniform_sphere (warp.h:251-263)
+            r = math.sqrt(max(0.0, 1.0 - z * z))
+            wi = np.array([r * math.cos(2 * math.pi * s0), r * math.sin(2 * math.pi * s0), z], np.float32)
+            up = wi[2] > 0
+            for x in range(n):
+                for y in range(n):
+                    wo = np.zeros(3, np.float32)
+                    pdf = C.c_float()
+                    w = oracle.bfo_bsdf_sample(C.byref(m), _ptr(wi), 0.5, x / (n - 1.0), y / (n - 1.0), _ptr(wo), C.byref(pdf))
+                    if w > 0:
+                        s_value = w * wo[2] / math.pi * (1 if up else -1)
+                        e_value = oracle.bfo_bsdf_eval(C.byref(m), _ptr(wi), _ptr(wo))
+                        p_pdf = oracle.bfo_bsdf_pdf(C.byref(m), _ptr(wi), _ptr(wo))
+                        assert abs(s_value - e_value) < 1e-2 and not math.isnan(e_value)
+                        assert np.isclose(pdf.value, p_pdf, rtol=1e-6)
+                        checked += 1
+    assert checked >= 200          # wi.z == 0 (the equator of the grid) and grazing samples fail, as in the reference
