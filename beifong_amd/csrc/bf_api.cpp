@@ -969,9 +969,16 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     return BF_OK;
 }
 
-static uint32_t wf_tail_threshold() {
+// Live slots at which the wavefront iterations hand over to the tail kernel.  A bounce iteration of a nearly empty pool
+// costs ~0.5 ms of launch and latency floor whatever it holds, the tail ~25 us per bounce: large pools (the pipelined
+// bench step, sweeps) switch at 2^17 live slots — more would keep the tail's 168-VGPR waves on the CUs the next renders'
+// kernels want (measured: 2^18 costs 12 % of the pipelined C2 rate) — small pools, whose kernels never fill the chip,
+// switch as soon as half the pool is done (C3: 1.21 -> 0.98 ms per render, C4 shard: 1.71 -> 1.30).
+static uint32_t wf_tail_threshold(uint32_t n_slots) {
     const char *e = getenv("BF_WF_TAIL");
-    return e ? (uint32_t) strtoul(e, nullptr, 10) : (1u << 17);
+    if (e) return (uint32_t) strtoul(e, nullptr, 10);
+    if (n_slots >= bfd::kTailSmallPool) return 1u << 17;
+    return std::max<uint32_t>(1u << 17, std::min<uint32_t>(1u << 19, n_slots / 2));
 }
 
 // Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
@@ -1026,7 +1033,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
     const unsigned grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), max_blocks));
     const unsigned grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) trace_waves, max_blocks));
-    const uint32_t tail_max = wf_tail_threshold();
+    const uint32_t tail_max = wf_tail_threshold(wf.n_slots);
     volatile uint32_t *hq = scene->wf_host;      // [0] = n_live[it]
     // per-kernel timing (stats renders only): events bracket every launch
     const size_t kMaxTimed = 96;

@@ -31,6 +31,9 @@ namespace bfd {
 // slot of the wavefront queue (state + the closest hit already traced for it)
 // and runs that path to completion here, instead of paying two launches per
 // bounce for a nearly empty chip.
+// Register budget of the tail (waves per SIMD): 3 (168 VGPRs, some scratch) leaves room for the next renders' kernels when
+// renders are pipelined over streams; 2 (224 VGPRs, no scratch) is ~10 % faster for the tail itself.  The launcher picks 2
+// for small pools (a 2^20-path render never fills the chip: nothing to leave room for) and 3 for large ones.
 #ifndef BF_TAIL_WAVES
 #define BF_TAIL_WAVES 3
 #endif
@@ -41,8 +44,8 @@ __device__ unsigned long long g_tail_prof[8192 * 16];
 #else
 #define BF_PROF_STAMP(var)
 #endif
-template <bool STATS, bool RESUME, bool SPILL>
-__global__ __launch_bounds__(kBlock, RESUME ? BF_TAIL_WAVES : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
+template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES>
+__global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -550,7 +553,7 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
             const char *e = getenv("BF_TAIL_SPREAD");
             return e ? (unsigned) std::max(1, atoi(e)) : 1u;
         }();
-        const unsigned resident = (sc->spill_stride / bfd::kBlock) * BF_TAIL_WAVES / bfd::kTraceBlocksPerCU;
+        const unsigned resident = (sc->spill_stride / bfd::kBlock) * 3u / bfd::kTraceBlocksPerCU;
         if (spread > 1 && grid < resident) grid = std::min(grid * spread, resident);
     }
     grid = std::min(grid, sc->spill_stride / bfd::kBlock);
@@ -564,13 +567,26 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     if (grid == 0) return hipSuccess;
     const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
     unsigned long long *counters = wf->counters;
+    static const int tw_env = [] {
+        const char *e = getenv("BF_TAIL_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    const bool two = tw_env ? tw_env == 2 : wf->n_slots < bfd::kTailSmallPool;
+#define BF_TAIL_LAUNCH(S, P)                                                                                                           \
+    if (two)                                                                                                                           \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 2>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
+                           records, counters, *wf, it);                                                                               \
+    else                                                                                                                               \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
+                           records, counters, *wf, it)
     if (stats) {
-        if (spill) BF_RENDER_LAUNCH(true, true, true, *wf, it);
-        else BF_RENDER_LAUNCH(true, true, false, *wf, it);
+        if (spill) { BF_TAIL_LAUNCH(true, true); }
+        else { BF_TAIL_LAUNCH(true, false); }
     } else {
-        if (spill) BF_RENDER_LAUNCH(false, true, true, *wf, it);
-        else BF_RENDER_LAUNCH(false, true, false, *wf, it);
+        if (spill) { BF_TAIL_LAUNCH(false, true); }
+        else { BF_TAIL_LAUNCH(false, false); }
     }
+#undef BF_TAIL_LAUNCH
     return hipGetLastError();
 }
 

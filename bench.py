@@ -107,7 +107,7 @@ class Workload:
             self.label = ("C5 pulse sweep: C2 geometry (%d triangles) through gen-3 receive (wigner transmitter, omnidirectional "
                           "receiver, BF_MODE_RECEIVE_IQ), 1024 fast-time bins, target at -5 m/s, PRI 1 ms; one step = one sweep of "
                           + str(self.n_pulses) + " pulses x %d x 64 = %d paths per pulse per GPU, batched launches")
-            self.streams = args.streams or 2
+            self.streams = args.streams or 3
             self.cpu_paths = args.cpu_paths or (1 << 22)
         self.total_paths = int(self.lp.n_paths)
         if args.scaling == "strong":
