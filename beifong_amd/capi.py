@@ -112,7 +112,7 @@ class bf_scene_info(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("n_rects", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("n_bvh_nodes", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32)]
+                ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32), ("trace_node_bytes", C.c_uint32)]
 
 
 class bf_batch(C.Structure):

@@ -22,7 +22,7 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
                                         hipStream_t stream);
 extern "C" float bfk_host_cos(float x);
 extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
-                                           float4 *nodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
+                                           float4 *nodes, float4 *qnodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
                                            uint32_t n_wchildren, const float *d, hipStream_t stream);
 extern "C" hipError_t bfk_launch_elementary(int op, uint64_t n, const float *x, float *y);
 extern "C" hipError_t bfk_launch_trace(const bfd::DScene *sc, uint64_t n, const float *rays, int any_hit, float *out_t,
@@ -606,6 +606,17 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     }
     std::vector<float4> node_data(8 * bvh4.nodes.size());
     if (!bvh4.nodes.empty()) std::memcpy(node_data.data(), bvh4.nodes.data(), bvh4.nodes.size() * sizeof(bf::Node4));
+    // 64-byte quantised copy of the four-wide nodes for wf_trace (bf_bvh.h: Node4Q).  OPT-IN (BF_QUANT_BVH=1): four loads
+    // per node step instead of seven, but +39 VALU operations and 1.3 % more node visits — measured 3 % SLOWER on C2
+    // (wf_trace 4.33 -> 4.45 ms per step; the kernel waits on dependent fetches and on its half-busy VALU, not on the
+    // number of vector-memory instructions: DESIGN.md 3.1), so the fp32 nodes stay the default.
+    std::vector<float4> qnode_data;
+    if (!bvh4.nodes.empty() && getenv("BF_QUANT_BVH") && atoi(getenv("BF_QUANT_BVH")) != 0) {
+        std::vector<bf::Node4Q> q;
+        bf::quantise_bvh4(bvh4, q);
+        qnode_data.resize(4 * q.size());
+        std::memcpy(qnode_data.data(), q.data(), q.size() * sizeof(bf::Node4Q));
+    }
     std::vector<float4> wnode_data;
     if (use_wide) {
         // one spare node of padding: a row's speculative third load of a child record may touch the next 16 bytes
@@ -648,6 +659,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         return st;                                                        \
     }
     UPG(node_data, nodes);
+    UPG(qnode_data, qnodes);
     UPG(wnode_data, wnodes);
     UPG(tri_data, tris);
     UPG(nrm_data, normals);
@@ -687,6 +699,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     inf.n_triangles = sc->d.n_tris;
     inf.n_bvh_nodes = sc->d.n_nodes;
     inf.node_bytes = (uint32_t) sizeof(bf::Node4);
+    inf.trace_node_bytes = sc->d.qnodes ? (uint32_t) sizeof(bf::Node4Q) : (uint32_t) sizeof(bf::Node4);
     inf.tri_bytes = 48;
     inf.bvh_depth = bvh4.max_depth;
     inf.bvh_stack_need = bvh4.stack_need;
@@ -784,9 +797,10 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         // copy on write: the arrays are shared with clones (bf_scene_clone) — this handle gets its own translated
         // copies; the source of the translation is the geometry as created if this handle has it (it translated in
         // place before it was cloned), else the shared arrays themselves
-        float4 *t = nullptr, *n = nullptr, *w = nullptr;
+        float4 *t = nullptr, *n = nullptr, *w = nullptr, *q = nullptr;
         bf_status cst;
-        if ((cst = own_copy(tri_bytes, &t)) != BF_OK || (cst = own_copy(node_bytes, &n)) != BF_OK || (cst = own_copy(wnode_bytes, &w)) != BF_OK)
+        if ((cst = own_copy(tri_bytes, &t)) != BF_OK || (cst = own_copy(node_bytes, &n)) != BF_OK || (cst = own_copy(wnode_bytes, &w)) != BF_OK ||
+            (cst = own_copy(scene->d.qnodes ? node_bytes / 2 : 0, &q)) != BF_OK)
             return cst;
         if (!scene->tris0) {
             scene->tris0 = const_cast<float4 *>(scene->d.tris);
@@ -796,6 +810,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         scene->d.tris = t;
         scene->d.nodes = n;
         scene->d.wnodes = w;
+        if (scene->d.qnodes) scene->d.qnodes = q;       // re-quantised from the translated fp32 nodes by the kernel below
         scene->geom_private = true;
     } else if (!scene->tris0) {
         // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
@@ -808,7 +823,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         if (wnode_bytes) HIP_TRY(hipMemcpyAsync(scene->wnodes0, scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
     }
     HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
-                                 const_cast<float4 *>(scene->d.nodes), scene->d.n_nodes, scene->wnodes0,
+                                 const_cast<float4 *>(scene->d.nodes), const_cast<float4 *>(scene->d.qnodes), scene->d.n_nodes, scene->wnodes0,
                                  const_cast<float4 *>(scene->d.wnodes), wnode_bytes ? scene->d.n_wnodes * 16u : 0u, offset, stream));
     return BF_OK;
 }
@@ -862,6 +877,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
         if ((st = dup(src->d.tris, tri_bytes, (const void **) &sc->d.tris)) != BF_OK) return fail_out(st);
         if ((st = dup(src->d.nodes, node_bytes, (const void **) &sc->d.nodes)) != BF_OK) return fail_out(st);
         if ((st = dup(src->d.wnodes, wnode_bytes, (const void **) &sc->d.wnodes)) != BF_OK) return fail_out(st);
+        if (src->d.qnodes && (st = dup(src->d.qnodes, node_bytes / 2, (const void **) &sc->d.qnodes)) != BF_OK) return fail_out(st);
         sc->geom_private = true;
     }
     if ((st = dup(src->d.rects, sizeof(bfd::DRect) * src->d.n_rects, (const void **) &sc->d.rects)) != BF_OK) return fail_out(st);
@@ -1025,7 +1041,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
     static const int trace_waves = [] {
         const char *e = getenv("BF_TRACE_WAVES");
         int w = e ? atoi(e) : 5;
-        return w < 5 ? 4 : 5;
+        return w < 5 ? 4 : (w > 5 ? 6 : 5);
     }();
     // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
     // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)

@@ -476,4 +476,59 @@ void collapse_bvh16(const BVH &in, BVH16 &out) {
     out.stack_need = c.emit(in.root_child, 0, 1);
 }
 
+// Quantisation of one four-wide node (bf_bvh.h: Node4Q).  Plain fp32 operations in a fixed order — the device repeats
+// them when it re-fits the tree after a mesh translation (bf_kernels.hip: bf_translate_kernel).
+void quantise_node4(const Node4 &in, Node4Q &out) {
+    const float inf = std::numeric_limits<float>::infinity();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    const float *clo[3] = {in.lox, in.loy, in.loz}, *chi[3] = {in.hix, in.hiy, in.hiz};
+    for (int k = 0; k < 4; ++k) {
+        if (in.child[k] == kEmptyChild) continue;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], clo[a][k]);
+            hi[a] = std::max(hi[a], chi[a][k]);
+        }
+    }
+    uint32_t exps = 0;
+    float scale[3];
+    for (int a = 0; a < 3; ++a) {
+        out.lo[a] = lo[a];
+        // smallest power of two s with 255 s >= extent (one binade of head room for the rounding of lo + q s)
+        const float ext = hi[a] - lo[a];
+        int e = 0;
+        (void) std::frexp(ext * (1.f / 255.f), &e);          // ext / 255 = m 2^e, m in [0.5, 1)  =>  2^e > ext / 255
+        e = std::max(-100, std::min(100, e));
+        if (!(lo[a] + 255.f * std::ldexp(1.f, e) >= hi[a])) ++e;      // the top plane must be reachable as the kernels round it
+        scale[a] = std::ldexp(1.f, e);
+        exps |= (uint32_t) (e + 127) << (8 * a);
+    }
+    out.exps = exps;
+    for (int a = 0; a < 3; ++a) out.qlo[a] = out.qhi[a] = 0;
+    for (int k = 0; k < 4; ++k) {
+        out.child[k] = in.child[k];
+        for (int a = 0; a < 3; ++a) {
+            uint32_t ql = 255u, qh = 0u;
+            if (in.child[k] != kEmptyChild) {
+                const float inv = 1.f / scale[a];                         // exact: a power of two
+                float fl = std::floor((clo[a][k] - lo[a]) * inv), fh = std::ceil((chi[a][k] - lo[a]) * inv);
+                fl = std::min(255.f, std::max(0.f, fl));
+                fh = std::min(255.f, std::max(0.f, fh));
+                // containment as the kernels evaluate the planes: fl32(lo + q s)
+                while (fl > 0.f && lo[a] + fl * scale[a] > clo[a][k]) fl -= 1.f;
+                while (fh < 255.f && lo[a] + fh * scale[a] < chi[a][k]) fh += 1.f;
+                ql = (uint32_t) fl;
+                qh = (uint32_t) fh;
+            }
+            out.qlo[a] |= ql << (8 * k);
+            out.qhi[a] |= qh << (8 * k);
+        }
+    }
+    out.pad[0] = out.pad[1] = 0;
+}
+
+void quantise_bvh4(const BVH4 &in, std::vector<Node4Q> &out) {
+    out.resize(in.nodes.size());
+    for (size_t i = 0; i < in.nodes.size(); ++i) quantise_node4(in.nodes[i], out[i]);
+}
+
 }  // namespace bf

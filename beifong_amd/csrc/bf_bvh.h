@@ -80,6 +80,27 @@ struct BVH4 {
 // levels of children - 1) is reported so that the kernels' stacks can be sized.
 void collapse_bvh4(const BVH &in, BVH4 &out);
 
+// 64-byte quantised form of a Node4 for the throughput traversal kernel (wf_trace): the node's own bounds as an fp32
+// origin `lo` plus one power-of-two scale per axis, the four child boxes as 8-bit offsets from it (lower planes rounded
+// down, upper planes rounded up, so every quantised box CONTAINS the fp32 box it replaces — box tests only select
+// triangles, hits stay bit-exact).  Four 16-byte loads per node step instead of seven, 14 instead of 28 live
+// registers.  Read by the kernels as four float4:
+//   q0 = (lo.x, lo.y, lo.z, bits(ex | ey << 8 | ez << 16))      scale of axis a = 2^(e_a - 127) (a float's exponent field)
+//   q1 = child[4] as int bits (same references as Node4: the two arrays are index-compatible)
+//   q2 = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   one byte per child, child k in bits 8k .. 8k+7
+//   q3 = (qhi.y[4], qhi.z[4], 0, 0)
+// plane of child k: lo_a + q * 2^(e_a - 127).  Unused slots: qlo = 255, qhi = 0 (inverted) and child = kEmptyChild.
+struct alignas(16) Node4Q {
+    float lo[3];
+    uint32_t exps;
+    int32_t child[4];
+    uint32_t qlo[3], qhi[3];
+    uint32_t pad[2];
+};
+static_assert(sizeof(Node4Q) == 64, "quantised node must be 64 bytes");
+void quantise_node4(const Node4 &in, Node4Q &out);      // also used (same arithmetic, on the device) by the mesh translation
+void quantise_bvh4(const BVH4 &in, std::vector<Node4Q> &out);
+
 // Sixteen-wide collapse of the SAME binary tree (same leaf order, same padded boxes) for the tail kernel's row
 // traversal: one ray per 16-lane DPP row, lane j tests child j of a node or triangle j of a leaf, so the serial
 // depth of a lone ray is ~log16 instead of ~log4 of the triangle count.  512 bytes per node:

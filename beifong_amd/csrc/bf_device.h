@@ -75,7 +75,8 @@ struct DSensor {
 };
 
 struct DScene {
-    const float4 *nodes;      // 4 float4 per node
+    const float4 *qnodes;     // the same nodes quantised to 64 bytes (bf_bvh.h: Node4Q, 4 float4 each): wf_trace's; nullptr = use `nodes`
+    const float4 *nodes;      // 8 float4 per node
     const float4 *tris;       // 3 float4 per triangle
     const float4 *normals;    // 3 float4 per triangle or nullptr
     const float4 *uvs;        // 1 float4 per triangle or nullptr

@@ -238,6 +238,70 @@ BF_DEV int node4_step_top(const float4 *__restrict__ nodes, const float4 *top, i
     return node4_decide(lx, ly, lz, hx, hy, hz, ch, id, oid, ohi, mint, tmax, st);
 }
 
+// ---------------------------------------------------------------------------
+// Quantised four-wide node step (bf_bvh.h: Node4Q, 64 bytes): four 16-byte loads instead of seven.  The child planes
+// are lo_a + q 2^(e_a - 127); folded into the slab test, t = q (s / d) + (lo / d - o / d): one byte-to-float conversion
+// and one fma per plane.  Every quantised box contains the fp32 box of the same child (the host rounds lower planes
+// down and upper planes up against exactly this arithmetic), and box tests only select triangles.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTopStrideQ = 5;          // float4 per node of the LDS copy of the top levels (80-byte stride)
+BF_DEV float qbyte(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu); }      // v_cvt_f32_ubyteK
+template <class Stack>
+BF_DEV int node4q_decide(const float4 q0, const float4 q1, const float4 q2, const float4 q3, V3 id, V3 oid, V3 ohi, float mint,
+                         float tmax, Stack &st) {
+    const uint32_t ex = __float_as_uint(q0.w);
+    const float ax = __uint_as_float((ex & 0xffu) << 23) * id.x, ay = __uint_as_float(((ex >> 8) & 0xffu) << 23) * id.y,
+                az = __uint_as_float(((ex >> 16) & 0xffu) << 23) * id.z;
+    const float blx = fmadd(q0.x, id.x, oid.x), bly = fmadd(q0.y, id.y, oid.y), blz = fmadd(q0.z, id.z, oid.z);
+    const float bhx = fmadd(q0.x, id.x, ohi.x), bhy = fmadd(q0.y, id.y, ohi.y), bhz = fmadd(q0.z, id.z, ohi.z);
+    const uint32_t lx = __float_as_uint(q2.x), ly = __float_as_uint(q2.y), lz = __float_as_uint(q2.z), hx = __float_as_uint(q2.w),
+                   hy = __float_as_uint(q3.x), hz = __float_as_uint(q3.y);
+    float tn[4];
+    bool hit[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t0x = fmadd(qbyte(lx, k), ax, blx), t1x = fmadd(qbyte(hx, k), ax, bhx);
+        const float t0y = fmadd(qbyte(ly, k), ay, bly), t1y = fmadd(qbyte(hy, k), ay, bhy);
+        const float t0z = fmadd(qbyte(lz, k), az, blz), t1z = fmadd(qbyte(hz, k), az, bhz);
+        tn[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                __builtin_fmaxf(__builtin_fminf(t0z, t1z), mint));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                         __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
+        hit[k] = tn[k] <= tf * 1.0000004f;
+    }
+    const float4 ch = q1;
+    const bool h0 = hit[0] && __float_as_int(ch.x) != kNoNode, h1 = hit[1] && __float_as_int(ch.y) != kNoNode;
+    const bool h2 = hit[2] && __float_as_int(ch.z) != kNoNode, h3 = hit[3] && __float_as_int(ch.w) != kNoNode;
+    const uint32_t k0 = child_key(h0, tn[0], 0u), k1 = child_key(h1, tn[1], 1u), k2 = child_key(h2, tn[2], 2u), k3 = child_key(h3, tn[3], 3u);
+    const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
+    const uint32_t lo = min(a, c), x = max(a, c), y = min(b, d), hi = max(b, d);
+    const uint32_t m1 = min(x, y), m2 = max(x, y);
+    if (hi < kMissKey) st.push(pick_child(ch, hi));
+    if (m2 < kMissKey) st.push(pick_child(ch, m2));
+    if (m1 < kMissKey) st.push(pick_child(ch, m1));
+    if (lo < kMissKey) return pick_child(ch, lo);
+    return st.pop_or_none();
+}
+BF_DEV void load_top_qnodes(const float4 *__restrict__ qnodes, uint32_t n_top, float4 *top, uint32_t tid, uint32_t n_threads) {
+    for (uint32_t i = tid; i < n_top * 4u; i += n_threads) {
+        const uint32_t node = i >> 2, j = i & 3u;
+        top[node * kTopStrideQ + j] = qnodes[4u * node + j];
+    }
+}
+template <class Stack>
+BF_DEV int node4q_step_top(const float4 *__restrict__ qnodes, const float4 *top, int n_top, int node, V3 id, V3 oid, V3 ohi, float mint,
+                           float tmax, Stack &st) {
+    float4 q0, q1, q2, q3;
+    if (node < n_top) {
+        const lds_f4_ptr np = (lds_f4_ptr) top + kTopStrideQ * (uint32_t) node;
+        q0 = to_float4(np[0]), q1 = to_float4(np[1]), q2 = to_float4(np[2]), q3 = to_float4(np[3]);
+    } else {
+        const float4 *np = qnodes + 4u * (uint32_t) node;
+        q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    }
+    return node4q_decide(q0, q1, q2, q3, id, oid, ohi, mint, tmax, st);
+}
+
 // all triangles of one leaf; returns true when an any-hit query is decided
 template <bool STATS>
 BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, float mint, float maxt, Hit &best, uint32_t &n_tris,

@@ -593,7 +593,7 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
 namespace bfd {
 // bf_scene_translate_meshes: triangles and node boxes of the pristine copies shifted by `d`.
 __global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__restrict__ tris, uint32_t n_tri_rows,
-                                    const float4 *__restrict__ nodes0, float4 *__restrict__ nodes, uint32_t n_nodes,
+                                    const float4 *__restrict__ nodes0, float4 *__restrict__ nodes, float4 *__restrict__ qnodes, uint32_t n_nodes,
                                     const float4 *__restrict__ wnodes0, float4 *__restrict__ wnodes, uint32_t n_wchildren,
                                     float dx, float dy, float dz) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -621,6 +621,49 @@ __global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__
         o[0] = lx; o[1] = ly; o[2] = lz; o[3] = hx; o[4] = hy; o[5] = hz;
         o[6] = s[6];
         o[7] = s[7];
+        if (qnodes) {
+            // re-quantise the shifted node for wf_trace: bf::quantise_node4 (bf_bvh.cpp) operation for operation
+            const float cl[3][4] = {{lx.x, lx.y, lx.z, lx.w}, {ly.x, ly.y, ly.z, ly.w}, {lz.x, lz.y, lz.z, lz.w}};
+            const float chh[3][4] = {{hx.x, hx.y, hx.z, hx.w}, {hy.x, hy.y, hy.z, hy.w}, {hz.x, hz.y, hz.z, hz.w}};
+            const int child[4] = {__float_as_int(s[6].x), __float_as_int(s[6].y), __float_as_int(s[6].z), __float_as_int(s[6].w)};
+            float nlo[3], scale[3];
+            uint32_t exps = 0, qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                float lo = BF_INF, hi = -BF_INF;
+                for (int k = 0; k < 4; ++k)
+                    if (child[k] != kNoNode) {
+                        lo = __builtin_fminf(lo, cl[a][k]);
+                        hi = __builtin_fmaxf(hi, chh[a][k]);
+                    }
+                nlo[a] = lo;
+                int e = 0;
+                (void) __builtin_frexpf((hi - lo) * (1.f / 255.f), &e);
+                e = max(-100, min(100, e));
+                if (!(lo + 255.f * __builtin_ldexpf(1.f, e) >= hi)) ++e;
+                scale[a] = __builtin_ldexpf(1.f, e);
+                exps |= (uint32_t) (e + 127) << (8 * a);
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t ql = 255u, qh = 0u;
+                    if (child[k] != kNoNode) {
+                        const float inv = 1.f / scale[a];
+                        float fl = __builtin_floorf((cl[a][k] - lo) * inv), fh = __builtin_ceilf((chh[a][k] - lo) * inv);
+                        fl = __builtin_fminf(255.f, __builtin_fmaxf(0.f, fl));
+                        fh = __builtin_fminf(255.f, __builtin_fmaxf(0.f, fh));
+                        while (fl > 0.f && lo + fl * scale[a] > cl[a][k]) fl -= 1.f;
+                        while (fh < 255.f && lo + fh * scale[a] < chh[a][k]) fh += 1.f;
+                        ql = (uint32_t) fl;
+                        qh = (uint32_t) fh;
+                    }
+                    qlo[a] |= ql << (8 * k);
+                    qhi[a] |= qh << (8 * k);
+                }
+            }
+            float4 *q = qnodes + 4u * i;
+            q[0] = make_float4(nlo[0], nlo[1], nlo[2], __uint_as_float(exps));
+            q[1] = s[6];
+            q[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
+            q[3] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), 0.f, 0.f);
+        }
     }
     if (i < n_wchildren) {                      // one child record of a sixteen-wide node (bf_bvh.h: Node16), same re-padding
         const float4 a = wnodes0[2u * i], b = wnodes0[2u * i + 1u];
@@ -637,13 +680,13 @@ __global__ void bf_translate_kernel(const float4 *__restrict__ tris0, float4 *__
 }  // namespace bfd
 
 extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, uint32_t n_tri_rows, const float4 *nodes0,
-                                           float4 *nodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
+                                           float4 *nodes, float4 *qnodes, uint32_t n_nodes, const float4 *wnodes0, float4 *wnodes,
                                            uint32_t n_wchildren, const float *d, hipStream_t stream) {
     uint32_t n = n_tri_rows > n_nodes ? n_tri_rows : n_nodes;
     n = n > n_wchildren ? n : n_wchildren;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(bfd::bf_translate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tris0, tris, n_tri_rows, nodes0, nodes,
-                       n_nodes, wnodes0, wnodes, n_wchildren, d[0], d[1], d[2]);
+                       qnodes, n_nodes, wnodes0, wnodes, n_wchildren, d[0], d[1], d[2]);
     return hipGetLastError();
 }
 

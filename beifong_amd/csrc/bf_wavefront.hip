@@ -308,16 +308,19 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 constexpr int kLdsStack = 16;
 constexpr uint32_t kTraceGuard = 1u << 24;      // wf_trace: inner-loop iterations between two refills (see the guard below)
 
-template <bool STATS, int W, bool SHIFT>
+template <bool STATS, int W, bool SHIFT, bool QUANT>
 __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t it) {
     __shared__ int s_stack[kLdsStack * kBlock];
-    __shared__ float4 s_top[kTopNodes * kTopStride];
+    __shared__ float4 s_top[kTopNodes * (QUANT ? kTopStrideQ : kTopStride)];
     int *stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int nxt = (it & 1) ^ 1;
     uint32_t c_nodes = 0, c_tris = 0, c_top = 0;
     const int n_top = (int) min(sc.n_nodes, kTopNodes);
-    load_top_nodes(sc.nodes, (uint32_t) n_top, s_top, threadIdx.x, kBlock);
+    if (QUANT)
+        load_top_qnodes(sc.qnodes, (uint32_t) n_top, s_top, threadIdx.x, kBlock);
+    else
+        load_top_nodes(sc.nodes, (uint32_t) n_top, s_top, threadIdx.x, kBlock);
     __syncthreads();
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     LaneStack<kLdsStack, true> st = make_stack<kLdsStack, true>(sc, stack);
@@ -431,8 +434,12 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                         ++c_nodes;
                         c_top += node < n_top ? 1u : 0u;
                     }
-                    node = node4_step_top(sc.nodes, s_top, n_top, node, id, oid, SHIFT ? ohi : oid, mint,
-                                          any ? maxt : __builtin_fminf(maxt, best.t), st);
+                    if (QUANT)
+                        node = node4q_step_top(sc.qnodes, s_top, n_top, node, id, oid, SHIFT ? ohi : oid, mint,
+                                               any ? maxt : __builtin_fminf(maxt, best.t), st);
+                    else
+                        node = node4_step_top(sc.nodes, s_top, n_top, node, id, oid, SHIFT ? ohi : oid, mint,
+                                              any ? maxt : __builtin_fminf(maxt, best.t), st);
                 }
             }
             // (b) intersect the postponed leaves together
@@ -511,23 +518,40 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 
 extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uint32_t it, int stats, unsigned grid,
                                    hipStream_t stream, int waves) {
-    const bool shift = wf->offsets != nullptr;
-#define BF_TRACE_LAUNCH(W)                                                                                              \
-    if (shift) {                                                                                                        \
-        if (stats)                                                                                                      \
-            hipLaunchKernelGGL((bfd::wf_trace<true, W, true>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);  \
-        else                                                                                                            \
-            hipLaunchKernelGGL((bfd::wf_trace<false, W, true>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it); \
-    } else if (stats)                                                                                                   \
-        hipLaunchKernelGGL((bfd::wf_trace<true, W, false>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it);     \
-    else                                                                                                                \
-        hipLaunchKernelGGL((bfd::wf_trace<false, W, false>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
+    const bool shift = wf->offsets != nullptr, quant = sc->qnodes != nullptr;
+#define BF_TRACE_LAUNCH2(S, W, SH, Q) \
+    hipLaunchKernelGGL((bfd::wf_trace<S, W, SH, Q>), dim3(grid), dim3(bfd::kBlock), 0, stream, *sc, *wf, it)
+#define BF_TRACE_LAUNCH1(S, W)                      \
+    if (shift) {                                    \
+        if (quant) BF_TRACE_LAUNCH2(S, W, true, true);  \
+        else BF_TRACE_LAUNCH2(S, W, true, false);   \
+    } else {                                        \
+        if (quant) BF_TRACE_LAUNCH2(S, W, false, true); \
+        else BF_TRACE_LAUNCH2(S, W, false, false);  \
+    }
+#define BF_TRACE_LAUNCH(W)   \
+    if (stats) {             \
+        BF_TRACE_LAUNCH1(true, W)  \
+    } else {                 \
+        BF_TRACE_LAUNCH1(false, W) \
+    }
     // 28.6 KiB of LDS per workgroup (stacks + the tree's top levels): five workgroups per CU is the most that fit
-    if (waves >= 5) {
+    // (the quantised nodes' copy is 6.8 KiB: six workgroups per CU fit, if the register allocation follows)
+    if (waves >= 6 && quant) {
+        if (stats) {
+            if (shift) BF_TRACE_LAUNCH2(true, 6, true, true);
+            else BF_TRACE_LAUNCH2(true, 6, false, true);
+        } else {
+            if (shift) BF_TRACE_LAUNCH2(false, 6, true, true);
+            else BF_TRACE_LAUNCH2(false, 6, false, true);
+        }
+    } else if (waves >= 5) {
         BF_TRACE_LAUNCH(5);
     } else {
         BF_TRACE_LAUNCH(4);
     }
 #undef BF_TRACE_LAUNCH
+#undef BF_TRACE_LAUNCH1
+#undef BF_TRACE_LAUNCH2
     return hipGetLastError();
 }

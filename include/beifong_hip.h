@@ -286,6 +286,8 @@ typedef struct bf_scene_info {
     float bbox_min[3], bbox_max[3];
     uint32_t bvh_depth;       /* levels of the four-wide tree                  */
     uint32_t bvh_stack_need;  /* worst-case traversal stack entries (<= 31)    */
+    uint32_t trace_node_bytes; /* bytes per node as the throughput traversal kernel (wf_trace) reads them: 64
+                                  (quantised child boxes) — node_bytes (128, fp32 boxes) is what the other kernels read */
 } bf_scene_info;
 
 /* ---------------- entry points --------------------------------------------- */

@@ -210,3 +210,49 @@ extern "C" int bvh16_check(uint32_t n, const float *verts /* n*9 */, uint32_t ou
     return 0;
 }
 
+
+// Quantised four-wide nodes (bf::quantise_bvh4, wf_trace's 64-byte nodes): every quantised child box, evaluated as the
+// kernels do (fl32(lo + q * 2^(e - 127))), contains the fp32 child box; same child references; unused slots inverted.
+extern "C" int bvh4q_check(uint32_t n, const float *verts /* n*9 */, uint32_t out[8]) {
+    std::vector<bf::BuildTri> tris(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(tris[i].p0, verts + 9 * i, 12);
+        std::memcpy(tris[i].p1, verts + 9 * i + 3, 12);
+        std::memcpy(tris[i].p2, verts + 9 * i + 6, 12);
+    }
+    bf::BVH bvh2;
+    bf::build_bvh(tris, bvh2, 0.f);
+    bf::BVH4 bvh4;
+    bf::collapse_bvh4(bvh2, bvh4);
+    std::vector<bf::Node4Q> q;
+    bf::quantise_bvh4(bvh4, q);
+    if (q.size() != bvh4.nodes.size()) return 21;
+    double worst = 0.0;       // largest growth of a box side relative to the node's extent
+    for (size_t i = 0; i < q.size(); ++i) {
+        const bf::Node4 &a = bvh4.nodes[i];
+        const bf::Node4Q &b = q[i];
+        const float *clo[3] = {a.lox, a.loy, a.loz}, *chi[3] = {a.hix, a.hiy, a.hiz};
+        for (int k = 0; k < 4; ++k) {
+            if (b.child[k] != a.child[k]) return 22;
+            for (int ax = 0; ax < 3; ++ax) {
+                const uint32_t e = (b.exps >> (8 * ax)) & 0xffu;
+                uint32_t bits = e << 23;
+                float s;
+                std::memcpy(&s, &bits, 4);
+                const float ql = (float) ((b.qlo[ax] >> (8 * k)) & 0xffu), qh = (float) ((b.qhi[ax] >> (8 * k)) & 0xffu);
+                if (a.child[k] == bf::kEmptyChild) {
+                    if (!(ql == 255.f && qh == 0.f)) return 23;
+                    continue;
+                }
+                const float plo = b.lo[ax] + ql * s, phi = b.lo[ax] + qh * s;
+                if (!(plo <= clo[ax][k]) || !(phi >= chi[ax][k])) return 24;
+                const double grow = std::max((double) clo[ax][k] - plo, (double) phi - chi[ax][k]);
+                if (grow > 1.0001 * (double) s) return 25;             // never more than one quantum
+                worst = std::max(worst, grow / std::max(1e-30, 255.0 * (double) s));
+            }
+        }
+    }
+    out[0] = (uint32_t) q.size();
+    out[1] = (uint32_t) (worst * 1e6);
+    return 0;
+}

@@ -22,6 +22,7 @@ def checker(tmp_path_factory):
     lib = C.CDLL(str(out))
     lib.bvh_check.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     lib.bvh16_check.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32 * 8)]
+    lib.bvh4q_check.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     return lib
 
 
@@ -85,3 +86,16 @@ def test_sixteen_wide_collapse_for_the_tail_kernel(checker):
         v, f = meshgen.triangle_soup(n, seed=n)
         s = _check16(checker, v, f)
         assert s["nodes16"] == (0 if n <= 16 else s["internal"])
+
+
+def test_quantised_nodes_contain_the_fp32_boxes(checker):
+    """bf::quantise_bvh4 (wf_trace's 64-byte nodes): every 8-bit child box, evaluated in fp32 as the kernels evaluate it,
+    contains the fp32 box it replaces and grows it by at most one quantum (1 / 255 of the node's extent, or twice that
+    when the extent sits just below a power of two); child references unchanged; unused slots inverted."""
+    for v, f in (meshgen.bus(20000, seed=1), meshgen.car_body(30000, seed=2)[:2], meshgen.motorbike(10000, seed=5),
+                 meshgen.triangle_soup(5000, seed=3), meshgen.triangle_soup(3, seed=9)):
+        tri = np.ascontiguousarray(np.asarray(v, np.float32)[np.asarray(f)].reshape(-1, 9))
+        out = (C.c_uint32 * 8)()
+        rc = checker.bvh4q_check(tri.shape[0], tri.ctypes.data, C.byref(out))
+        assert rc == 0, f"quantised-node invariant {rc} violated"
+        assert out[1] <= 1e6 / 255 * 2.01

@@ -1075,3 +1075,32 @@ def test_doppler_hook_off_by_default_and_bit_exact_when_on(hiplib):
     out = OracleScene(sd).render(lp_on, records=True, threads=8)
     for _ in range(3):
         _render_compare_one(g, lp_on, out, 2e-5)
+
+
+def test_quantised_nodes_opt_in_is_bit_exact(hiplib, monkeypatch):
+    """BF_QUANT_BVH=1: wf_trace walks 64-byte nodes with 8-bit child boxes (bf_bvh.h: Node4Q; measured slower, hence
+    opt-in).  Quantised boxes contain the fp32 boxes and box tests only select triangles: every path must still equal the
+    oracle's, also after bf_scene_translate_meshes re-quantises the tree on the device, and in a batch with mesh offsets."""
+    monkeypatch.setenv("BF_QUANT_BVH", "1")
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 16, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    assert g.info().trace_node_bytes == 64 and g.info().node_bytes == 128
+    out = OracleScene(sd).render(lp, records=True, threads=8)
+    _, _, st = _render_compare_one(g, lp, out, 2e-5)
+    assert st.n_rays_traced > 0
+    monkeypatch.delenv("BF_QUANT_BVH")
+    ref = capi.Scene(sd)
+    assert ref.info().trace_node_bytes == 128
+    off = [-0.37, 0.21, 0.02]
+    g.translate_meshes(off)
+    ref.translate_meshes(off)
+    _, rq, _ = g.render(lp, records=True)
+    _, rr, _ = ref.render(lp, records=True)
+    for k in ("L", "aux"):
+        assert np.array_equal(rq[k].view(np.uint32), rr[k].view(np.uint32))
+    assert np.array_equal(rq["n_rays"], rr["n_rays"])
+    g.translate_meshes([0, 0, 0])
+    hb, rb, _ = g.render_batch(lp, 2, offsets=[[0, 0, 0], off], records=True)
+    for k in ("L", "aux"):
+        assert np.array_equal(rb[1][k].view(np.uint32), rr[k].view(np.uint32))
+        assert np.array_equal(rb[0][k].view(np.uint32), out[1][k].view(np.uint32))
