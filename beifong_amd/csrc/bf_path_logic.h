@@ -381,11 +381,16 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
     return 1.f * s.gain * geom_gain * extents;
 }
 
+// Mode specialisation: RX = 0 compiles the render modes only (path / range / time), RX = 1 the receive modes only,
+// RX = 2 decides at run time (the one-kernel variant and the tail).  The receive branches carry the Wigner / phased-array
+// / signal-model code; a shading kernel that cannot reach them allocates fewer registers.
+template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return RX == 2 ? lp.mode == BF_MODE_RECEIVE_RAW : RX == 1; }
+
 // ---------------------------------------------------------------------------
 // path generation
 // ---------------------------------------------------------------------------
-BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, PathState &s) {
-    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, PathState &s) {
+    const bool receive = mode_receive<RX>(lp);
     s.path_i = path_i;
     s.render = 0u;
     uint64_t seed = lp.seed;
@@ -488,11 +493,15 @@ struct ShadeProf {
 #define BF_SHADEPROF_ARG
 #define BF_SHADEPROF_STAMP(v)
 #endif
+template <int RX = 2>
 BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
                          uint32_t &c_bounces BF_SHADEPROF_ARG) {
     BF_SHADEPROF_STAMP(spf_t0);
-    const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
-    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+    const bool receive = mode_receive<RX>(lp);
+    const bool is_range = !receive && lp.mode == BF_MODE_RANGE, is_time = !receive && lp.mode == BF_MODE_TIME;
+    const bool iq = receive && lp.iq != 0u;
+    const bool phase_bins = receive && lp.phase_bins != 0u;
+    const bool doppler = receive && lp.doppler != 0u;
     const uint32_t n_emit = sc.n_emitters;
     sh.want = false;
     SI si;
@@ -513,17 +522,17 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         if (si_valid) s.flags |= kFlagValid;
         if (is_range) s.aux += si_valid ? si.t : 0.f;
         if (is_time) s.aux = si_valid ? si.t / lp.time_c : 0.f;
-        if (receive && si_valid && lp.doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);   // :141-144
+        if (si_valid && doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);   // :141-144
         if (receive && si_valid) {                                 // ray.update_state(-si.t); si.time = ray.time
             s.time += -si.t / sc.c;
-            if (lp.phase_bins) s.phase = phase_update(s.phase, -si.t, sc.lambda_min, sc.lambda_max);
+            if (phase_bins) s.phase = phase_update(s.phase, -si.t, sc.lambda_min, sc.lambda_max);
         }
         depth = 1;
     } else {
         // tail of the previous iteration — path.cpp:184-209, pathtimefrequency.cpp:363-399
         if (receive) {                                             // :368-371, also for a miss (Q3)
             s.time += -hit.t / sc.c;
-            if (lp.phase_bins) s.phase = phase_update(0.f, -hit.t, sc.lambda_min, sc.lambda_max);   // spawn_ray: phase restarts at 0
+            if (phase_bins) s.phase = phase_update(0.f, -hit.t, sc.lambda_min, sc.lambda_max);   // spawn_ray: phase restarts at 0
         }
         if (emitter >= 0) {
             const DEmitter &e = sc.emitters[emitter];
@@ -540,14 +549,14 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     // head of iteration `depth` — path.cpp:121-145
     if (emitter >= 0) {
         const DEmitter &e = sc.emitters[emitter];
-        if (receive && lp.doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
+        if (doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
         float ev;
         if (receive)
             ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
         else
             ev = (e.type == BF_EMITTER_AREA) ? ((si.wi.z > 0.f) ? e.radiance : 0.f) : 0.f;
         float contrib = s.emission_weight * s.throughput * ev;
-        if (lp.iq) {
+        if (iq) {
             // optical length receiver -> ... -> this transmitter point: c * (t_rx - retarded time)
             float re, im;
             path_phasor((s.t_rx - s.time) * sc.c, s.lambda0, re, im);
@@ -603,7 +612,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bsdf_pdf);
             sh.c = mis * s.throughput * bsdf_val * emitter_val;
             sh.c_im = 0.f;
-            if (lp.iq) {
+            if (iq) {
                 float re, im;
                 path_phasor((s.t_rx - s.time) * sc.c + ds.dist, s.lambda0, re, im);
                 sh.c_im = sh.c * im;
@@ -666,12 +675,13 @@ struct FilmAcc {
     uint32_t invalid;
 };
 
+template <int RX = 2>
 BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
                      FilmAcc &acc, bf_path_record *records) {
     const bool valid = (s.flags & kFlagValid) != 0;
     float rec_L, rec_aux;
     const uint32_t hb = lp.batch != 0u ? s.render * lp.n_chan : 0u;      // this render's block of the histogram
-    if (lp.mode == BF_MODE_RECEIVE_RAW) {
+    if (mode_receive<RX>(lp)) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
         float tf0 = s.t_rx - se.adc_sampling_start;
@@ -806,9 +816,9 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
 
 // wave-reduce the base channels into the histogram (render modes only) and
 // flush the LDS-privatised histogram: one global atomic per non-empty bin
-BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_hist, bool lds_hist, int tid) {
+template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, float *s_hist, float *g_hist, bool lds_hist, int tid) {
     const int lane = tid & 63;
-    if (lp.mode != BF_MODE_RECEIVE_RAW) {
+    if (!mode_receive<RX>(lp)) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             acc.X += __shfl_down(acc.X, off);

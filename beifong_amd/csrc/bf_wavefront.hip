@@ -78,7 +78,7 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
 
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
 //   FIRST = true : bounce 0, every slot < n_slots starts its first path.
-template <bool FIRST, int W>
+template <bool FIRST, int W, int RX>
 __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                       bf_path_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         __syncthreads();
     }
     const int cur = it & 1, nxt = cur ^ 1;
-    const bool receive = lp.mode == BF_MODE_RECEIVE_RAW;
+    const bool receive = mode_receive<RX>(lp);
     const uint32_t n_batches = wf.n_slots >> 6;
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
 
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 ++c_loads;
                 if (s.flags & kFlagTermPending) {
                     // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
-                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+                    film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else {
                     float4 hq = wf.hit[slot];
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             // ---- vertex logic ---------------------------------------------------------------
             if (!settled && have_hit) {
                 have_hit = false;
-                cont = shade_vertex(sc, lp, s, hit, sh, c_bounces);
+                cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces);
                 if (!cont) {
-                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+                    film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else if (!(s.flags & kFlagTermPending)) {
                     ++c_closest;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 cont = false;
                 uint64_t path_i = (FIRST && round == 0) ? (uint64_t) slot : s.path_i + wf.n_slots;
                 if (path_i < lp.n_paths) {
-                    generate_path(sc, lp, path_i, s);
+                    generate_path<RX>(sc, lp, path_i, s);
                     sh.want = false;
                     ++c_closest;
                     cont = true;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                         // the integrator still adds mis * throughput * bsdf * 0: a NaN / inf BSDF value survives that
                         // product.  c * 0 is that term (+-0 for every finite c).
                         s.result += found ? sh.c * 0.f : sh.c;
-                        if (lp.iq) s.phase += found ? sh.c_im * 0.f : sh.c_im;
+                        if (receive && lp.iq) s.phase += found ? sh.c_im * 0.f : sh.c_im;
                         shadowing = false;
                     }
                     sh.want = shadowing;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             if (chain) {
                 if (s.flags & kFlagTermPending) {
                     // the path ended at its last BSDF sample and its NEE ray is answered: bin it now
-                    film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+                    film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                     cont = false;
                 } else {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 wf.sh0[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
                 wf.sh1[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
                 wf.sh2[slot] = sh.c;
-                if (lp.iq) wf.sh3[slot] = sh.c_im;
+                if (receive && lp.iq) wf.sh3[slot] = sh.c_im;
             }
         }
         cont = has && cont;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         c_shq += shadowing ? 1u : 0u;
     }
 
-    film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
+    film_flush<RX>(lp, acc, s_hist, g_hist, lds_hist, tid);
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
     uint32_t v_live = c_live;
     unsigned long long v_traced = c_traced;
@@ -499,9 +499,14 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
                                    hipStream_t stream, int waves) {
     // `waves`: register budget of the shading kernel (waves per SIMD); 3 is the sweet spot (168 VGPRs)
-#define BF_SHADE_LAUNCH(F, W)                                                                                             \
-    hipLaunchKernelGGL((bfd::wf_shade<F, W>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
-                       records)
+    const bool rx = lp->mode == BF_MODE_RECEIVE_RAW;
+#define BF_SHADE_LAUNCH(F, W)                                                                                                    \
+    if (rx)                                                                                                                      \
+        hipLaunchKernelGGL((bfd::wf_shade<F, W, 1>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
+                           records);                                                                                             \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((bfd::wf_shade<F, W, 0>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
+                           records)
     if (first) {
         BF_SHADE_LAUNCH(true, 3);
     } else {
