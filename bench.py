@@ -126,6 +126,8 @@ class Workload:
         else:
             l = c.make_launch(lp.mode, self.paths, seed=lp.seed + 1000003 * i, path_offset=self.path_offset, bins=lp.bins,
                               bin_width=lp.bin_width, color_mode=lp.color_mode, flags=flags)
+        if os.environ.get("BENCH_MAX_DEPTH"):        # developer probe (what would a shorter tail buy); never set by the driver
+            l.max_depth = int(os.environ["BENCH_MAX_DEPTH"])
         return l
 
 

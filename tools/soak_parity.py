@@ -78,6 +78,59 @@ if len(sys.argv) > 2 and sys.argv[2] == "misc":
     print("FAILED" if fails else "all cases bit-exact")
     sys.exit(1 if fails else 0)
 
+if len(sys.argv) > 2 and sys.argv[2] == "batch":
+    # round 2: batched launches (per-render seeds, on-the-fly mesh offsets), the Doppler hook, clones — every path of
+    # every render of the batch against the oracle on a scene BUILT from the shifted vertices
+    from beifong_amd import meshgen
+    from tests.test_gpu_batch import _bus_receive_with_mesh
+
+    def check_batch(name, g, lp, seeds, offsets, oracle_scene_of):
+        global fails
+        hb, rb, sb = g.render_batch(lp, len(seeds), seeds=seeds, offsets=offsets, records=True)
+        bad_total = 0
+        for k, sd_k in enumerate(oracle_scene_of):
+            l1 = capi.bf_launch()
+            import ctypes as C
+            C.memmove(C.byref(l1), C.byref(lp), C.sizeof(capi.bf_launch))
+            l1.seed = int(seeds[k])
+            _, ro, _ = OracleScene(sd_k).render(l1, records=True, threads=16)
+            bad = sum(int((rb[k][key].view(np.uint32) != ro[key].view(np.uint32)).sum()) for key in ("L", "aux"))
+            bad += int((rb[k]["n_rays"] != ro["n_rays"]).sum()) + int((rb[k]["valid"] != ro["valid"]).sum())
+            bad_total += bad
+        ok = bad_total == 0
+        fails += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} {name:52s} renders {len(seeds)} x {lp.n_paths} paths, rays {sb.n_rays_closest + sb.n_rays_shadow}, "
+              f"tail rays {sb.n_rays_tail}, mismatching records {bad_total}", flush=True)
+
+    v0, f0 = meshgen.bus(200_000, seed=1)
+    v0 = meshgen.place(v0, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7)).astype(np.float32)
+    lam = (8.6e6 * 0.999, 8.6e6 * 1.001)
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(seed)
+        # C5-like: I/Q receive, 6 pulses with their own offsets (mm to metres) and seeds
+        sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 20, t_bins=1024, dr=0.03, seed=4, lambda_band_nm=lam)
+        lp.mode = capi.BF_MODE_RECEIVE_IQ
+        offs = np.concatenate([np.zeros((1, 3)), rng.uniform(-0.01, 0.01, (2, 3)), rng.uniform(-2.0, 2.0, (3, 3))]).astype(np.float32)
+        seeds = [int(x) for x in rng.integers(1, 1 << 40, len(offs))]
+        scenes_k = [_bus_receive_with_mesh(np.ascontiguousarray((v0 + o[None, :]).astype(np.float32)), f0, t_bins=1024, dr=0.03, lambda_band_nm=lam)
+                    for o in offs]
+        g = capi.Scene(sd)
+        check_batch(f"C5 I/Q batch with offsets, soak seed {seed}", g, lp, seeds, offs, scenes_k)
+        # the same through a clone, with the Doppler hook on
+        c = g.clone()
+        lp.mode = capi.BF_MODE_RECEIVE_RAW
+        lp.flags = capi.BF_FLAG_DOPPLER
+        check_batch(f"C2-recv + Doppler hook, clone, soak seed {seed}", c, lp, seeds[:3], offs[:3], scenes_k[:3])
+        c.close()
+        g.close()
+        # range mode, no offsets: 4 renders x 2^22 paths with their own seeds (LDS-privatised batch histogram)
+        sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 22, seed=1)
+        g = capi.Scene(sd)
+        check_batch(f"C2 range batch of seeds, soak seed {seed}", g, lp, seeds[:4], None, [sd] * 4)
+        g.close()
+    print("FAILED" if fails else "all cases bit-exact")
+    sys.exit(1 if fails else 0)
+
 for seed in range(n_seeds):
     sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=100 + seed)
     check(f"C2 range bus seed {100 + seed}", sd, lp)
