@@ -39,7 +39,7 @@ namespace bfd {
 #endif
 #ifdef BF_TAIL_PROF
 // developer build (make prof): per-wave cycle breakdown of the tail kernel, read back by bfdbg_tail_profile
-__device__ unsigned long long g_tail_prof[8192 * 16];
+__device__ unsigned long long g_tail_prof[8192 * 24];
 #define BF_PROF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define BF_PROF_STAMP(var)
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
 
 #ifdef BF_TAIL_PROF
     unsigned long long pf_iters = 0, pf_regen = 0, pf_trav = 0, pf_film = 0, pf_shade = 0, pf_quad = 0, pf_rowpass = 0;
+    unsigned long long pf_dense_iters = 0, pf_dense_trav = 0, pf_dense_shade = 0, pf_dense_rays = 0;
     RowProf pf_row = {0, 0, 0, 0};
     ShadeProf pf_sp = {0, 0, 0, 0};
     const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
@@ -176,6 +177,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         const uint32_t n_cl = (uint32_t) __popcll(closest_mask), n_sh = (uint32_t) __popcll(want_mask);
 #ifdef BF_TAIL_PROF
         if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= 16u) ++pf_quad;
+        const bool pf_is_dense = n_cl + n_sh > 16u;
+        pf_dense_rays += pf_is_dense ? n_cl + n_sh : 0u;
 #endif
         if (RESUME && n_cl + n_sh != 0u && n_cl + n_sh <= wf.row_jobs && sc.wnodes != nullptr) {
             // ---- deep tail: ONE ray per 16-lane row on the sixteen-wide tree (traverse_row16), four rays per pass ------
@@ -372,6 +375,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         {
             const unsigned long long pf_t4 = __builtin_amdgcn_s_memtime();
             ++pf_iters;
+            if (pf_is_dense) {
+                ++pf_dense_iters;
+                pf_dense_trav += pf_t2 - pf_t1;
+                pf_dense_shade += pf_t4 - pf_t3;
+            }
             pf_regen += pf_t1 - pf_t0;
             pf_trav += pf_t2 - pf_t1;
             pf_film += pf_t3 - pf_t2;
@@ -404,7 +412,11 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     if (RESUME && lane == 0) {
         const uint32_t w = blockIdx.x * (kBlock / 64) + (tid >> 6);
         if (w < 8192u) {
-            unsigned long long *q = g_tail_prof + 16u * w;
+            unsigned long long *q = g_tail_prof + 24u * w;
+            q[16] = pf_dense_iters;
+            q[17] = pf_dense_trav;
+            q[18] = pf_dense_shade;
+            q[19] = pf_dense_rays;
             q[8] = pf_rowpass;
             q[9] = pf_row.steps;
             q[10] = pf_row.rect;
@@ -694,7 +706,7 @@ extern "C" hipError_t bfk_launch_translate(const float4 *tris0, float4 *tris, ui
 extern "C" int bfdbg_tail_profile(unsigned long long *out, int n_waves) {
     if (n_waves > 8192) n_waves = 8192;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bfd::g_tail_prof), sizeof(unsigned long long) * 16 * (size_t) n_waves) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bfd::g_tail_prof), sizeof(unsigned long long) * 24 * (size_t) n_waves) != hipSuccess) return -1;
     unsigned long long zero[8] = {0};
     (void) zero;
     return n_waves;
@@ -702,7 +714,7 @@ extern "C" int bfdbg_tail_profile(unsigned long long *out, int n_waves) {
 extern "C" int bfdbg_tail_profile_clear(void) {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(bfd::g_tail_prof)) != hipSuccess) return -1;
-    return hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8192) == hipSuccess ? 0 : -1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 24 * 8192) == hipSuccess ? 0 : -1;
 }
 #endif
 
