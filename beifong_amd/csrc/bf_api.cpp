@@ -1204,7 +1204,12 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
             if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER &&
                 scene->emitter_types[i] != BF_TRANSMITTER_PHASED)
                 return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);
+        // the Wigner and phased receivers sample their own local-oscillator signal under "mix_resample"
+        // (wignerreceiver.cpp:72-110,179-189): not built, so the flag is the omnidirectional receiver's only
+        if ((launch->flags & BF_FLAG_MIX_RESAMPLE) && scene->sensor_host.type != BF_RECEIVER_OMNI)
+            return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_MIX_RESAMPLE: only the omnidirectional receiver has receive_type \"mix_resample\"");
     } else {
+        if (launch->flags & BF_FLAG_MIX_RESAMPLE) return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE is a receive-mode flag");
         if (is_rx) return fail(BF_ERR_INVALID, "render modes need a sensor (fluxmeter / perspective), not a receiver");
         for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
             if (scene->emitter_types[i] != BF_EMITTER_SPOT && scene->emitter_types[i] != BF_EMITTER_AREA &&
@@ -1255,6 +1260,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.n_chan = bf_launch_channels(launch);
     lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
     lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
+    lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;
     lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);

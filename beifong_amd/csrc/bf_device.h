@@ -121,6 +121,7 @@ struct DLaunch {
     uint64_t batch_paths;
     const uint64_t *batch_seeds;    // device [batch], or nullptr: `seed` for every render (common random numbers)
     const float4 *batch_offsets;    // device [batch] (x, y, z, -), or nullptr: meshes as built
+    uint32_t mix;                   // BF_FLAG_MIX_RESAMPLE (receive modes): the ADC's frequency axis is the beat frequency
     uint32_t doppler;               // BF_FLAG_DOPPLER (receive modes): Shape::doppler shifts the path's wavelength
     float box_slack;                // offsets only: node boxes widened by this much on the ray's side (bf_device_core.h: RayBox)
 };

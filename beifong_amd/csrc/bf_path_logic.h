@@ -686,6 +686,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         const DSensor &se = *sc.sensor;
         float tf0 = s.t_rx - se.adc_sampling_start;
         float tf1 = freq_of(sc.c, lp.doppler ? s.lambda0 + s.dlambda : s.lambda0);
+        if (lp.mix) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, s.lambda0));      // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601)
         tf0 *= (float) se.t_bins / se.t_bandwidth;
         tf1 *= (float) se.f_bins / se.f_bandwidth;
         float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode

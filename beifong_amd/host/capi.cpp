@@ -89,6 +89,10 @@ int bfh_integrator_launch(void *integrator, void *endpoint, bf_launch *out) {
     BFH_TRY({
         auto *in = dynamic_cast<SamplingIntegrator *>((Object *) integrator);
         if (!in) Throw("object is not a SamplingIntegrator");
+        if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
+            in->receive_launch(re, *out);
+            return 0;
+        }
         std::memset(out, 0, sizeof(*out));
         out->color_mode = variant() == "scalar_rgb" ? BF_COLOR_RGB : BF_COLOR_MONO;
         out->max_depth = in->max_depth();
@@ -104,12 +108,6 @@ int bfh_integrator_launch(void *integrator, void *endpoint, bf_launch *out) {
                 out->spp = (uint32_t) out->n_paths;
                 out->n_paths *= (uint64_t) se->film()->width() * se->film()->height();
             }
-        } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
-            out->n_paths = re->sampler()->sample_count();
-            out->seed = re->sampler()->base_seed();
-            out->bins = re->adc()->t_bins();
-            out->bins_y = re->adc()->f_bins();
-            out->color_mode = BF_COLOR_MONO;
         }
     })
 }

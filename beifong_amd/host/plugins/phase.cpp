@@ -27,6 +27,7 @@ public:
         lp.phase_bins = (uint32_t) m_bins;
     }
     int max_depth() const override { return m_integrator->max_depth(); }
+    bool doppler() const override { return m_integrator->doppler(); }
     int rr_depth() const override { return m_integrator->rr_depth(); }
 private:
     ref<SamplingIntegrator> m_integrator;

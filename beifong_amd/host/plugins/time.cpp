@@ -26,6 +26,7 @@ public:
         lp.time_c = 3.0e8f;           // pathtime.cpp:140
     }
     int max_depth() const override { return m_integrator->max_depth(); }
+    bool doppler() const override { return m_integrator->doppler(); }
     int rr_depth() const override { return m_integrator->rr_depth(); }
 private:
     ref<SamplingIntegrator> m_integrator;

@@ -7,6 +7,10 @@ public:
         if (props.has_property("to_world"))
             Throw("Found a 'to_world' transformation -- this is not allowed. The wigner receiver inherits this "
                   "transformation from its parent shape.");
+        // "mix_resample" gives this receiver a local-oscillator signal model of its own (wignerreceiver.cpp sample_frequency /
+        // eval_signal, "signaltype" cw | pulse | linfmcw): not built; the omnidirectional receiver takes mix_resample
+        if (m_receive_type == "mix_resample")
+            Throw("wignerreceiver: receive_type \"mix_resample\" is not supported (\"raw\" and \"raw_resample\" are)");
         if (m_adc->reconstruction_filter()->radius() > 0.5f + 1500 * 5.9604644775390625e-8f)
             Throw("wignerreceiver: only the box reconstruction filter is supported (adc rfilter radius <= 0.5)");
         m_f_centre = props.float_("freq_centre", 1.f);

@@ -493,6 +493,9 @@ SamplingIntegrator::SamplingIntegrator(const Properties &props) : Integrator(pro
     if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
     m_max_depth = (int) props.int_("max_depth", -1);
     if (m_max_depth < 0 && m_max_depth != -1) Throw("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    // not a reference property: switches on Shape::doppler at the three call sites the reference carries commented
+    // out (pathtimefrequency.cpp:124-126,141-144,180-183); false = the reference's HEAD
+    m_doppler = props.bool_("doppler", false);
 }
 
 static uint32_t color_mode_of_variant() {
@@ -537,20 +540,13 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
     return !m_stop;
 }
 
-bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
-    // integrator.cpp:315-768 (live branch :484-666): channels Y,A,W + aov_names()
-    ADC *adc = receiver->adc();
-    std::vector<std::string> channels = {"Y", "A", "W"};
-    for (auto &n : aov_names()) channels.push_back(n);
-    adc->prepare(channels);
-    // "raw" and "raw_resample" take the same branches everywhere at HEAD (integrator.cpp:1603-1623,
-    // wignerreceiver.cpp:64-71,174-178).  "mix_resample" bins |f_after - f_rx|, which is exactly 0 while
-    // the Doppler update is commented out (pathtimefrequency.cpp:440-445) and so lands outside the ADC
-    // (SignalBlock::put: ceil(0 - 1) = -1); "mixer" is an empty branch (:1624-1634).  Neither is built.
-    if (receiver->receive_type() != "raw" && receiver->receive_type() != "raw_resample")
-        Throw("receive_type \"%s\" is not supported (\"raw\" and \"raw_resample\" are)", receiver->receive_type().c_str());
-    bf_launch lp;
+void SamplingIntegrator::receive_launch(const Receiver *receiver, bf_launch &lp) const {
+    const std::string &rt = receiver->receive_type();
+    if (rt != "raw" && rt != "raw_resample" && rt != "mix_resample")
+        Throw("receive_type \"%s\" is not supported (\"raw\", \"raw_resample\" and \"mix_resample\" are)", rt.c_str());
     std::memset(&lp, 0, sizeof(lp));
+    if (rt == "mix_resample") lp.flags |= BF_FLAG_MIX_RESAMPLE;
+    if (doppler()) lp.flags |= BF_FLAG_DOPPLER;
     lp.color_mode = BF_COLOR_MONO;
     lp.n_paths = receiver->sampler()->sample_count();
     lp.seed = receiver->sampler()->base_seed();
@@ -559,8 +555,23 @@ bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
     lp.time_c = 3.0e8f;
     configure(lp);
     if (lp.mode != BF_MODE_RECEIVE_RAW) Throw("this integrator does not implement receive()");
-    lp.bins = adc->t_bins();
-    lp.bins_y = adc->f_bins();
+    lp.bins = receiver->adc()->t_bins();
+    lp.bins_y = receiver->adc()->f_bins();
+}
+
+bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
+    // integrator.cpp:315-768 (live branch :484-666): channels Y,A,W + aov_names()
+    ADC *adc = receiver->adc();
+    std::vector<std::string> channels = {"Y", "A", "W"};
+    for (auto &n : aov_names()) channels.push_back(n);
+    adc->prepare(channels);
+    // "raw" and "raw_resample" take the same branches everywhere at HEAD (integrator.cpp:1603-1623,
+    // wignerreceiver.cpp:64-71,174-178).  "mix_resample" bins the beat frequency |f_after - f_rx| (:1588-1603), which is
+    // exactly 0 while the Doppler update is commented out (pathtimefrequency.cpp:440-445) and so lands outside the ADC
+    // (SignalBlock::put: ceil(0 - 1) = -1): BF_FLAG_MIX_RESAMPLE reproduces that.  "mixer" is an empty branch that would
+    // bin an uninitialised coordinate (:1624-1634): rejected.
+    bf_launch lp;
+    receive_launch(receiver, lp);
     uint32_t n = bf_launch_channels(&lp);
     std::vector<float> hist(n);
     auto t0 = std::chrono::steady_clock::now();

@@ -257,10 +257,15 @@ public:
     /// MonteCarloIntegrator parameters; AOV wrappers (range, time, phase) forward to their sub-integrator
     virtual int max_depth() const { return m_max_depth; }
     virtual int rr_depth() const { return m_rr_depth; }
+    /// "doppler" (not a reference property, default false = the reference's HEAD): BF_FLAG_DOPPLER for receive()
+    virtual bool doppler() const { return m_doppler; }
+    /// the bf_launch receive() hands to bf_render for this receiver (receive_type -> flags, ADC -> bins)
+    void receive_launch(const Receiver *receiver, bf_launch &launch) const;
     const Class *class_() const override;
 
 protected:
     int m_max_depth = -1, m_rr_depth = 5;
+    bool m_doppler = false;
 };
 
 /// src/librender/scene.cpp:22-120

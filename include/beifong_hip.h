@@ -230,6 +230,12 @@ enum {
     BF_FLAG_GLOBAL_ATOMICS = 2u, /* skip LDS privatisation (debug / ablation) */
     BF_FLAG_MEGAKERNEL = 4u,   /* single persistent megakernel instead of the
                                   wavefront pipeline (ablation; same results) */
+    BF_FLAG_MIX_RESAMPLE = 16u, /* receive modes: receive_type "mix_resample" (integrator.cpp:1588-1603): the ADC's frequency
+                                  coordinate is the BEAT frequency |c / lambda_after - c / lambda_rx| between the wavelength the
+                                  path ends with and the one the receiver sampled, instead of c / lambda ("raw" / "raw_resample",
+                                  :1604-1623).  The two differ only by the Doppler hook, so without BF_FLAG_DOPPLER the beat is
+                                  exactly 0 and every sample falls outside the ADC (ceil(0 - 1) = -1), as at the reference's HEAD.
+                                  receive_type "mixer" (:1624-1634) is an empty branch there and has no counterpart here. */
     BF_FLAG_DOPPLER = 8u       /* receive modes: the Doppler hook the reference carries commented out
                                   ("Took doppler out to test", pathtimefrequency.cpp:124-126,141-144,180-183):
                                   the path's wavelength is shifted by Shape::doppler(si) =

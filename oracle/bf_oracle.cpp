@@ -1960,6 +1960,7 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     out.pr = ptf_sample(sc, lp, smp, ray, cx);
     float tf0 = time - s.adc_sampling_start;                // :1625-1626
     float tf1 = freq_of(sc, (lp.flags & BF_FLAG_DOPPLER) ? cx.lambda0 + out.pr.dlambda : cx.lambda0);
+    if (lp.flags & BF_FLAG_MIX_RESAMPLE) tf1 = std::fabs(tf1 - freq_of(sc, cx.lambda0));     // receive_type "mix_resample" :1590-1601
     tf0 *= (float) s.t_bins / s.t_bandwidth;                // :1639
     tf1 *= (float) s.f_bins / s.f_bandwidth;
     float L = std::fabs(w) * out.pr.L;                      // :1643
@@ -2155,6 +2156,10 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
     const bool is_receive = lp->mode == BF_MODE_RECEIVE_RAW || lp->mode == BF_MODE_RECEIVE_IQ;
     if (is_receive && (s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.type != BF_RECEIVER_WIGNER && s->sc.sensor.type != BF_RECEIVER_PHASED)) {
         g_err = "receive mode needs a receiver";
+        return BF_ERR_INVALID;
+    }
+    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && (!is_receive || s->sc.sensor.type != BF_RECEIVER_OMNI)) {
+        g_err = "BF_FLAG_MIX_RESAMPLE: receive modes with the omnidirectional receiver only";
         return BF_ERR_INVALID;
     }
     const OScene &sc = s->sc;

@@ -63,6 +63,29 @@ def test_receive_through_the_plugin_surface(mitsuba, hiplib):
         mitsuba.set_variant("scalar_rgb")
 
 
+def test_receive_mix_resample_through_the_plugin_surface(mitsuba, hiplib):
+    # receive_type "mix_resample" + the integrator's Doppler switch: XML -> flags -> HIP == oracle; without the switch the
+    # ADC stays empty (beat frequency 0), the reference's HEAD
+    from beifong_amd.mitsuba.core.xml import load_string
+    mix = RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                '<receiver type="omnidirectional"><string name="receive_type" value="mix_resample"/>')
+    dop = mix.replace('<integrator type="pathtimefrequency"/>',
+                      '<integrator type="pathtimefrequency"><boolean name="doppler" value="true"/></integrator>')
+    mitsuba.set_variant("scalar_spectral")
+    try:
+        for xml, empty in ((mix, True), (dop, False)):
+            scene = load_string(xml)
+            rx = scene.receivers()[0]
+            scene.integrator().receive(scene, rx)
+            bmp = np.array(rx.adc().bitmap(raw=True))
+            lp = scene.integrator().launch_for(rx)
+            ref, _, _ = OracleScene(scene.flat_desc(rx)).render(lp, threads=8)
+            assert np.allclose(bmp.reshape(-1), ref, rtol=2e-5, atol=1e-3)
+            assert (not bmp.any()) if empty else bmp[0, :, 2].sum() > 0
+    finally:
+        mitsuba.set_variant("scalar_rgb")
+
+
 def test_bfrender_cli(hiplib, tmp_path):
     # mitsuba -m scalar_rgb -Dspp=.. scene.xml (src/mitsuba/mitsuba.cpp:173-183)
     p = tmp_path / "scene.xml"

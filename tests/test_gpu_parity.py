@@ -1077,6 +1077,39 @@ def test_doppler_hook_off_by_default_and_bit_exact_when_on(hiplib):
         _render_compare_one(g, lp_on, out, 2e-5)
 
 
+def test_mix_resample_receive_type(hiplib):
+    """BF_FLAG_MIX_RESAMPLE (receive_type "mix_resample", integrator.cpp:1588-1603): the frequency row is that of the beat
+    |c / lambda_after - f_rx|.  With the Doppler hook every path's record and row equals the oracle's (both pipelines);
+    without it the beat is 0 and every sample is dropped, as at the reference's HEAD; the Wigner receiver and render modes
+    refuse the flag."""
+    sd, lp = _doppler_scene(3.0)
+    sd.sensor.f_bandwidth = 0.5 * sd.physics.c / (sd.physics.lambda_min_nm * 1e-9)
+    sd.finalize()
+    both = capi.BF_FLAG_DOPPLER | capi.BF_FLAG_MIX_RESAMPLE
+    lp_mix = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=both)
+    h_mix, _, _ = _render_compare(sd, lp_mix)
+    rows = h_mix.reshape(32, 64, 3)[:, :, 2].sum(1)
+    assert rows.sum() > 0.3 * lp.n_paths and np.count_nonzero(rows) > 3
+    lp_dop = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_DOPPLER)
+    h_dop, _, _ = _render_compare(sd, lp_dop)
+    assert not np.array_equal(h_dop, h_mix)
+    lp_only = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_MIX_RESAMPLE)
+    h0, _, _ = _render_compare(sd, lp_only)
+    assert not h0.any()
+    # a batch keeps the flag per render
+    g = capi.Scene(sd)
+    hb, rb, _ = g.render_batch(lp_mix, 2, seeds=[lp.seed, lp.seed + 1], records=True)
+    assert np.allclose(hb[0], h_mix, rtol=1e-4, atol=1e-3)
+    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=256, t_bins=4, receiver="wigner")
+    lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
+    with pytest.raises(capi.BeifongError):
+        capi.Scene(sdw).render(lpw)
+    sdr, lpr = scenes.bus_radar(n_tris=500, n_paths=256, bins=16, dr=0.5)
+    lpr.flags = capi.BF_FLAG_MIX_RESAMPLE
+    with pytest.raises(capi.BeifongError):
+        capi.Scene(sdr).render(lpr)
+
+
 def test_quantised_nodes_opt_in_is_bit_exact(hiplib, monkeypatch):
     """BF_QUANT_BVH=1: wf_trace walks 64-byte nodes with 8-bit child boxes (bf_bvh.h: Node4Q; measured slower, hence
     opt-in).  Quantised boxes contain the fp32 boxes and box tests only select triangles: every path must still equal the

@@ -332,6 +332,39 @@ def test_receive_scene_with_fork_plugins(mitsuba):
     assert d.shapes[0].emitter == 0 and d.sensor.type == capi.BF_RECEIVER_OMNI and d.sensor.shape == 1
 
 
+def test_receive_type_mix_resample_and_doppler_property(mitsuba):
+    """receiver.cpp:21 receive_type: "mix_resample" (integrator.cpp:1588-1603) -> BF_FLAG_MIX_RESAMPLE on the omnidirectional
+    receiver; the integrator's "doppler" switch (not a reference property; the reference carries the calls commented out)
+    -> BF_FLAG_DOPPLER; "mixer" (an empty branch in the reference) and mix_resample on the Wigner receiver are refused."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    mix = RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                '<receiver type="omnidirectional"><string name="receive_type" value="mix_resample"/>')
+    scene = load_string(mix)
+    rx = scene.receivers()[0]
+    lp, h, _ = _oracle_on_host_scene(scene, rx)
+    assert lp.flags == capi.BF_FLAG_MIX_RESAMPLE and not h.any()          # HEAD: beat 0, every sample outside the ADC
+    dop = mix.replace('<integrator type="pathtimefrequency"/>',
+                      '<integrator type="pathtimefrequency"><boolean name="doppler" value="true"/></integrator>')
+    scene = load_string(dop)
+    rx = scene.receivers()[0]
+    lp, h, _ = _oracle_on_host_scene(scene, rx)
+    assert lp.flags == capi.BF_FLAG_MIX_RESAMPLE | capi.BF_FLAG_DOPPLER
+    assert h.reshape(1, 256, 3)[0, :, 2].sum() > 0                         # identity velocity: the ground's returns beat
+    # the AOV wrapper forwards the switch of its nested integrator
+    scene = load_string(dop.replace('<integrator type="pathtimefrequency"><boolean name="doppler" value="true"/></integrator>',
+                                    '<integrator type="phase"><integer name="bins" value="4"/><integrator type="pathtimefrequency">'
+                                    '<boolean name="doppler" value="true"/></integrator></integrator>'))
+    assert scene.integrator().launch_for(scene.receivers()[0]).flags == capi.BF_FLAG_MIX_RESAMPLE | capi.BF_FLAG_DOPPLER
+    scene = load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                              '<receiver type="omnidirectional"><string name="receive_type" value="mixer"/>'))
+    with pytest.raises(HostError, match="mixer"):
+        scene.integrator().launch_for(scene.receivers()[0])
+    with pytest.raises(HostError, match="mix_resample"):
+        load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                          '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'))
+
+
 def test_phase_integrator_plugin_and_nested_depths(mitsuba):
     """phase.cpp (built at HEAD) wraps pathtimefrequency: `bins` S{k}.Y channels after Y, A, W; the
     MonteCarloIntegrator parameters are those of the NESTED integrator (integrator.cpp:1713-1728)."""

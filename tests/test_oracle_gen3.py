@@ -2,6 +2,7 @@
 holds no test or stored output for it (parity unpinned), so these pin
 the restatement through physics it must obey."""
 import numpy as np
+import pytest
 
 from beifong_amd import capi, scenes
 from tests.oracle_lib import OracleScene
@@ -159,3 +160,49 @@ def test_doppler_hook_value_and_default():
     centre0 = (np.arange(64) * w0).sum() / w0.sum()
     centre1 = (np.arange(64) * w1).sum() / max(w1.sum(), 1)
     assert w1.sum() <= w0.sum() and (w1.sum() == 0 or centre1 > centre0)
+
+
+def test_mix_resample_bins_the_beat_frequency():
+    """receive_type "mix_resample" (integrator.cpp:1588-1603): tf[1] = |c / lambda_after - f_rx|.  At the reference's HEAD
+    the wavelength never changes, the beat is 0 and SignalBlock::put drops every sample (lo = ceil(0 - 1) = -1); with the
+    Doppler hook on, the beat rows are the raw rows folded about the receive frequency: with f_rx on the edge between raw
+    rows 31 | 32 and rows of equal width, W_mix[k] = W_raw[32 + k] + W_raw[31 - k]."""
+    from beifong_amd import capi, scenes
+    from tests.oracle_lib import OracleScene
+    lam = 8.0e6                                                   # nm; a band 2e-6 wide: f_rx is one frequency to 1e-6
+    sd, lp = scenes.bus_receive(n_tris=2000, n_paths=6000, t_bins=4, lambda_band_nm=(lam * (1 - 1e-6), lam * (1 + 1e-6)))
+    f0 = sd.physics.c / (lam * 1e-9)
+    vel = np.eye(4, dtype=np.float32) * np.float32(2.0)
+    vel[3, 3] = 1.0
+    for s_ in sd.shapes:
+        if s_.type == capi.BF_SHAPE_MESH:
+            s_.velocity = (capi.M16)(*vel.reshape(-1).tolist())
+    sd.sensor.f_bins = 64
+    sd.sensor.f_bandwidth = 2.0 * f0
+    sd.finalize()
+    lp.bins_y = 64
+    lp.flags = capi.BF_FLAG_DOPPLER
+    raw, _, _ = OracleScene(sd).render(lp, threads=4)
+    w_raw = raw.reshape(64, 4, 3)[:, :, 2].sum(1)
+    assert w_raw.sum() == lp.n_paths or w_raw.sum() > 0.9 * lp.n_paths
+    assert (w_raw[:31].sum() + w_raw[33:].sum()) > 0                # the hook moves samples off the receive frequency
+    sd.sensor.f_bins = 32
+    sd.sensor.f_bandwidth = f0
+    sd.finalize()
+    lp.bins_y = 32
+    lp.flags = capi.BF_FLAG_DOPPLER | capi.BF_FLAG_MIX_RESAMPLE
+    mix, _, st = OracleScene(sd).render(lp, threads=4)
+    w_mix = mix.reshape(32, 4, 3)[:, :, 2].sum(1)
+    fold = w_raw[32:] + w_raw[31::-1]
+    # a path with NO shift (it missed the moving mesh) has beat exactly 0 and is dropped: those sit in raw row 31 (f_rx is
+    # at or just below the edge) -- fold row 0 counts them, the mix row 0 does not
+    assert np.array_equal(w_mix[1:], fold[1:]) and 0 < w_mix[0] <= fold[0]
+    # without the hook: nothing lands in the ADC
+    lp.flags = capi.BF_FLAG_MIX_RESAMPLE
+    none, _, st0 = OracleScene(sd).render(lp, threads=4)
+    assert not none.any()
+    # render modes and the Wigner receiver do not take the flag
+    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=16, t_bins=4, receiver="wigner")
+    lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
+    with pytest.raises(Exception):
+        OracleScene(sdw).render(lpw, threads=1)
