@@ -493,9 +493,29 @@ struct ShadeProf {
 #define BF_SHADEPROF_ARG
 #define BF_SHADEPROF_STAMP(v)
 #endif
+// developer build (-DBF_SHADE_PROF, tools/shade_profile.py): how many lanes of a wave enter each section of wf_shade.
+// SLP(sec, cond) sits in wave-uniform control flow right before `if (cond)`: one wave entry and popcount(cond) lanes.
+#ifdef BF_SHADE_PROF
+constexpr int kShadeProfSections = 32;
+static __device__ unsigned long long g_lane_prof[2 * kShadeProfSections];      // [sec] = wave entries, [32 + sec] = lanes
+#define BF_LANEPROF_ARG , bool lpf = false
+#define SLP(sec, cond)                                                                      \
+    do {                                                                                    \
+        if (lpf) {                                                                          \
+            const unsigned long long slp_b = __ballot(cond);                                \
+            if (slp_b && (int) (threadIdx.x & 63) == __ffsll((long long) slp_b) - 1) {      \
+                atomicAdd(&g_lane_prof[sec], 1ull);                                         \
+                atomicAdd(&g_lane_prof[kShadeProfSections + (sec)], (unsigned long long) __popcll(slp_b)); \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+#else
+#define BF_LANEPROF_ARG
+#define SLP(sec, cond)
+#endif
 template <int RX = 2>
 BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
-                         uint32_t &c_bounces BF_SHADEPROF_ARG) {
+                         uint32_t &c_bounces BF_SHADEPROF_ARG BF_LANEPROF_ARG) {
     BF_SHADEPROF_STAMP(spf_t0);
     const bool receive = mode_receive<RX>(lp);
     const bool is_range = !receive && lp.mode == BF_MODE_RANGE, is_time = !receive && lp.mode == BF_MODE_TIME;
@@ -507,6 +527,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     SI si;
     const bool si_valid = hit.t != BF_INF;
     int emitter = -1;
+    SLP(10, si_valid);
     if (si_valid) {
         make_si(sc, s.ro, s.rd, hit, si, nullptr, path_shift(lp, s.render));
         emitter = si.emitter;
@@ -534,6 +555,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
             s.time += -hit.t / sc.c;
             if (phase_bins) s.phase = phase_update(0.f, -hit.t, sc.lambda_min, sc.lambda_max);   // spawn_ray: phase restarts at 0
         }
+        SLP(11, emitter >= 0);
         if (emitter >= 0) {
             const DEmitter &e = sc.emitters[emitter];
             float emitter_pdf = receive ? transmitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
@@ -547,6 +569,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     }
     s.flags = (s.flags & ~kDepthMask) | (depth & kDepthMask);
     // head of iteration `depth` — path.cpp:121-145
+    SLP(12, emitter >= 0);
     if (emitter >= 0) {
         const DEmitter &e = sc.emitters[emitter];
         if (doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
@@ -578,6 +601,9 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     const bf_material &mat = sc.materials[si.material];
     ++c_bounces;
     BF_SHADEPROF_STAMP(spf_t2);
+    SLP(13, true);                                        // lanes that survive to NEE + BSDF sampling
+    SLP(15, mat.type == BF_BSDF_ROUGHCONDUCTOR);
+    SLP(16, mat.type != BF_BSDF_ROUGHCONDUCTOR);
     if (bsdf_smooth(mat)) {
         // Scene::sample_emitter_direction / sample_transmitter_direction — scene.cpp:180-230, 249-299
         float sx = next_1d(s.rng), sy = next_1d(s.rng);
@@ -605,6 +631,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
                 emitter_val *= rcp(emitter_pdf);
             }
         }
+        SLP(14, ds.pdf != 0.f);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
             float bsdf_val, bsdf_pdf;

@@ -78,6 +78,18 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
 
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
 //   FIRST = true : bounce 0, every slot < n_slots starts its first path.
+#ifdef BF_SHADE_PROF
+// developer build (tools/shade_profile.py): cycles of the wave between consecutive stamps, by section (the stamps sit in
+// wave-uniform control flow); SLP (bf_path_logic.h) counts wave entries and lanes per section
+#define SLT(k)                                                            \
+    do {                                                                  \
+        const unsigned long long slt_now = __builtin_amdgcn_s_memtime();  \
+        t_sec[k] += slt_now - slt_last;                                   \
+        slt_last = slt_now;                                               \
+    } while (0)
+#else
+#define SLT(k)
+#endif
 template <bool FIRST, int W, int RX>
 __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                       bf_path_record *__restrict__ records) {
@@ -96,6 +108,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
     uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0, c_loads = 0, c_shq = 0;
+#ifdef BF_SHADE_PROF
+    const bool lpf = true;
+    unsigned long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cursor, load, vertex + film, generate, presolve, chain, store
+    unsigned long long slt_last = __builtin_amdgcn_s_memtime();
+#endif
 
     // contiguous segment of batches per wave
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
@@ -139,12 +156,15 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         hit.prim = 0;
         hit.slot = 0;
 
+        SLP(0, has);
+        SLT(0);
         if (has) {
             if (FIRST) {
                 need_gen = true;
             } else {
                 load_state(wf, slot, receive, s);
                 ++c_loads;
+                SLP(1, (s.flags & kFlagTermPending) != 0);
                 if (s.flags & kFlagTermPending) {
                     // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
                     film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
@@ -159,6 +179,10 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 }
             }
         }
+#ifdef BF_SHADE_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SLT(1);
         // Chained shading: a lane whose new rays are both answered by the early resolution below
         // (rectangle hit or miss of the mesh, NEE ray clear of the mesh) needs no trace launch, so it
         // shades its next vertex — or starts its next path — right away, up to wf.shade_chain rounds per
@@ -168,9 +192,15 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         bool tracing = false, shadowing = false;
         for (uint32_t round = 0;; ++round) {
             // ---- vertex logic ---------------------------------------------------------------
+            SLP(2 + min(round, 2u), !settled && have_hit);
             if (!settled && have_hit) {
                 have_hit = false;
+#ifdef BF_SHADE_PROF
+                cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces, true);
+#else
                 cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces);
+#endif
+                SLP(5, !cont);
                 if (!cont) {
                     film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
@@ -181,6 +211,8 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             }
             // ---- regeneration: slot i renders paths i, i + n_slots, i + 2 n_slots, ... --------
             // (static assignment: no device-wide path counter to serialise on)
+            SLT(2);
+            SLP(6, !settled && need_gen);
             if (!settled && need_gen) {
                 need_gen = false;
                 cont = false;
@@ -192,11 +224,14 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                     cont = true;
                 }
             }
+            SLT(3);
             // ---- early resolution of the new rays ---------------------------------------------
             if (!settled) {
                 tracing = cont && !(s.flags & kFlagTermPending);
                 shadowing = cont && sh.want;
                 const Shift shf = path_shift(lp, s.render);
+                SLP(7, shadowing);
+                SLP(8, tracing);
                 if (shadowing) {
                     Hit tmp;
                     bool found;
@@ -215,10 +250,13 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                     tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found, shf);
                 }
             }
+            SLT(4);
             // ---- chain or settle ----------------------------------------------------------------
             const bool resolved = !settled && cont && !tracing && !shadowing;
             const bool chain = resolved && round + 1u < wf.shade_chain;
             if (!__any(chain)) break;
+            SLP(9, chain && (s.flags & kFlagTermPending));
+            SLP(17 + min(round, 2u), chain);
             if (chain) {
                 if (s.flags & kFlagTermPending) {
                     // the path ended at its last BSDF sample and its NEE ray is answered: bin it now
@@ -232,7 +270,10 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 settled = true;
             }
         }
+        SLT(5);
         // ---- write back in place ----------------------------------------------------------------
+        SLP(20, has && cont);
+        SLP(21, has && cont && shadowing);
         if (has && cont) {
             if (!(s.flags & kFlagTermPending)) {
                 // resolved rays carry their final hit; the others start wf_trace from the rectangle hit
@@ -256,9 +297,14 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
         c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
         c_shq += shadowing ? 1u : 0u;
+        SLT(6);
     }
 
     film_flush<RX>(lp, acc, s_hist, g_hist, lds_hist, tid);
+#ifdef BF_SHADE_PROF
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_lane_prof[24 + k], t_sec[k]);      // sections 24..31 of the wave-entry half: cycles
+#endif
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
     uint32_t v_live = c_live;
     unsigned long long v_traced = c_traced;
@@ -494,6 +540,20 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
 }
 
 }  // namespace bfd
+
+#ifdef BF_SHADE_PROF
+// developer build: wave entries [0..31] (24..31: cycles between stamps) and lanes [32..63] per section of wf_shade
+extern "C" int bfdbg_shade_lane_profile(unsigned long long *out, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(bfd::g_lane_prof), sizeof(unsigned long long) * 2 * bfd::kShadeProfSections) != hipSuccess) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(bfd::g_lane_prof)) != hipSuccess) return -1;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * 2 * bfd::kShadeProfSections) != hipSuccess) return -1;
+    }
+    return 2 * bfd::kShadeProfSections;
+}
+#endif
 
 extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it, int first,
                                    float *g_hist, bf_path_record *records, unsigned grid, size_t lds_bytes,
