@@ -299,7 +299,7 @@ def main():
                 "launches_per_step": round(launches[k] / K, 2), "avg_launch_ms": round(avg_s * 1e3, 4),
                 "algorithmic_bytes_per_launch": round(per_launch), "achieved": round(ach, 2), "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "frac_of_cache_gather_ceiling": round(ach / CACHE_GATHER_GBS, 5),
-                "traffic": tr, "traffic_over_algorithmic": (round(tr / per_launch, 3) if tr else None),
+                "traffic": tr, "traffic_over_algorithmic": (round(tr / per_launch, 3) if tr and per_launch else None),
             })
         step_s = dt / K
         whole = b_traversal_all / K / step_s / 1e9
