@@ -1126,9 +1126,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         // the tail kernel finishes whatever is alive, whatever the estimate: the estimate only sizes its grid
         const uint32_t est = std::max<uint32_t>(plan.tail_live + plan.tail_live / 4, 64u * bfd::kBlock);
         HIP_TRY(tic(2));
-#ifndef BF_PROBE_NO_TAIL      // timing probe only (make variant EXTRA=-DBF_PROBE_NO_TAIL): what the pipelined step costs without any tail; results are wrong
         HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, plan.iters, est, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail, stream));
-#endif
         HIP_TRY(toc());
         if (!scene->wf_fb_pending) {
             HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live, plan.iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -1,5 +1,6 @@
 #!/bin/bash
-# what does the tail cost the pipelined step?  (variant build that skips the tail launch of planned renders: timing only)
+# what does the tail cost the pipelined step?  Needs a variant library built from a tree in which the planned branch of
+# bf_api.cpp does not launch the tail (a one-line local change, see profiles/r02_no_tail_probe.txt): timing only
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() {
