@@ -21,7 +21,7 @@
 namespace bfd {
 
 constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce live counters
-constexpr uint32_t kShadeChain = 3;
+constexpr uint32_t kShadeChain = 8;        // wf_shade: vertices per visit while rays resolve early (C5: 8 beats 3 by 4 %, C2-C4 indifferent; profiles/r02_chain_sweep.txt)
 constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
 constexpr uint32_t kTraceBlocksPerCU = 8;

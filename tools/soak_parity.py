@@ -121,6 +121,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "batch":
         lp.mode = capi.BF_MODE_RECEIVE_RAW
         lp.flags = capi.BF_FLAG_DOPPLER
         check_batch(f"C2-recv + Doppler hook, clone, soak seed {seed}", c, lp, seeds[:3], offs[:3], scenes_k[:3])
+        lp.flags = capi.BF_FLAG_DOPPLER | capi.BF_FLAG_MIX_RESAMPLE       # receive_type "mix_resample": beat-frequency rows
+        check_batch(f"C2-recv mix_resample + Doppler, clone, soak seed {seed}", c, lp, seeds[3:5], offs[3:5], scenes_k[3:5])
         c.close()
         g.close()
         # range mode, no offsets: 4 renders x 2^22 paths with their own seeds (LDS-privatised batch histogram)
