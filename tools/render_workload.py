@@ -1,4 +1,4 @@
-"""Developer tool: a few isolated renders of a bench workload, to be run under rocprofv3 (kernel trace, PMC or PC sampling)."""
+"""Developer tool: a few isolated renders of a bench workload, to be run under rocprofv3 (--kernel-trace or --pmc passes)."""
 import os
 import sys
 
