@@ -944,11 +944,20 @@ def test_fuzz_random_scenes_render(hiplib, seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_random_scenes_receive(hiplib, seed):
+@pytest.mark.parametrize("hook", [False, True])
+def test_fuzz_random_scenes_receive(hiplib, seed, hook):
+    """hook: the same scenes with the Doppler hook on (every shape's default velocity) and, on the omnidirectional
+    receiver, receive_type "mix_resample" (odd seeds): records AND the ADC rows against the oracle."""
     sd, lp = _fuzz_scene(seed, receive=True)
+    extra = 0
+    if hook:
+        extra = capi.BF_FLAG_DOPPLER
+        if sd.sensor.type == capi.BF_RECEIVER_OMNI and seed % 2:
+            extra |= capi.BF_FLAG_MIX_RESAMPLE
+    lp.flags = extra
     ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
     g = capi.Scene(sd)
-    for flags in (capi.BF_FLAG_MEGAKERNEL, 0):
+    for flags in (capi.BF_FLAG_MEGAKERNEL | extra, extra):
         lp.flags = flags
         hg, rg, sg = g.render(lp, records=True)
         assert np.array_equal(rg["n_rays"], ro["n_rays"]) and np.array_equal(rg["valid"], ro["valid"]), seed
