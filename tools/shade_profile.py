@@ -14,6 +14,10 @@ n_paths = int(os.environ.get("PATHS", 1 << 24))
 scene_name = os.environ.get("SCENE", "bus")
 if scene_name == "bus":
     sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=n_paths)
+elif scene_name == "c5":        # one C5-like pulse batch: I/Q receive on the bus, the pool a quarter of the launch (slots regenerate)
+    lam = 8.6e6
+    sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=n_paths, t_bins=1024, dr=0.03, seed=4, lambda_band_nm=(lam * 0.999, lam * 1.001))
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
 elif scene_name == "car":
     sd, lp = scenes.car_radar(n_tris=1_000_000, n_paths=n_paths)
 else:
