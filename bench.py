@@ -20,7 +20,11 @@ is fixed and split with beifong_amd.dist.shard_range.
 
 Consecutive steps are independent renders (successive coherent processing intervals), issued round-robin on
 `--streams` HIP streams — one handle per stream, all clones of ONE scene (bf_scene_clone: one BVH on the device) — so
-the latency-bound tail of one step overlaps the head of the next.  The timed region carries no instrumentation; ray
+the latency-bound tail of one step overlaps the heads of the next ones.  The HIP runtime maps a process's streams onto 4
+hardware queues by default, which caps that overlap at three renders in flight (4 and 8 streams are even slower than 3:
+two streams then share a queue with the default stream's work); the bench raises GPU_MAX_HW_QUEUES to 16 before HIP starts
+and keeps 8 renders in flight (C5: 4 batches) — C2 8.9 -> 8.5 ms per step, C3 0.87 -> 0.73, C4 shard 1.16 -> 0.98
+(profiles/r02_hw_queues_streams.txt).  The timed region carries no instrumentation; ray
 counts, per-kernel algorithmic bytes (BF_FLAG_STATS counters) and per-kernel HIP-event durations come from two untimed
 serial passes over the SAME steps (same seeds => same rays).
 
@@ -32,6 +36,10 @@ the reference's scalar path with its own SAH BVH; neither embree nor TBB exist o
 + best of 3, all host cores and one core, on a bounded sample of the same workload.
 """
 import argparse
+import os
+
+# before anything loads the HIP runtime: hardware queues per process (default 4), see the note on streams above
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import hashlib
 import json
 import os
@@ -78,14 +86,14 @@ class Workload:
             self.label = ("C2 bus_radar: synthetic %d-triangle bus (Bus.obj stand-in) + 20x20 m ground, monostatic 20x50 mm TX "
                           "aperture + perspective RX, gen-2 range(pathlength) integrator, 256 range bins dr=0.1 m, 64 spp x %d "
                           "pulses = %d paths per GPU per step")
-            self.streams = args.streams or 3
+            self.streams = args.streams or 8
             self.cpu_paths = args.cpu_paths or (1 << 24)
         elif cfg == "c3":
             paths = args.paths or (1 << 20)
             self.sd, self.lp = scenes.car_radar(n_tris=1_000_000, n_paths=paths, bins=1024, dr=0.03, seed=2)
             self.label = ("C3 car_radar: synthetic %d-triangle car-body shell with vertex normals (Car-body.ply stand-in) + "
                           "ground, gen-2 range(pathlength), 1024 range bins dr=0.03 m, 2^20 primary rays: %d x 64 = %d paths per GPU per step")
-            self.streams = args.streams or 3
+            self.streams = args.streams or 8
             self.cpu_paths = args.cpu_paths or (1 << 22)
         elif cfg in ("c4shard", "c4"):
             total = 4096 << 10
@@ -93,7 +101,7 @@ class Workload:
             self.sd, self.lp = scenes.multi_mesh_radar(n_paths=paths, bins=4096, dr=0.01, seed=3)
             self.label = ("C4 multi_mesh_radar: bus + car + motorbike (%d triangles) on the ground, gen-2 range(pathlength), 4096 "
                           "range bins; %d x 64 = %d paths per step (the configured 4096 spp x 2^10 = 2^22 paths are 8 such shards)")
-            self.streams = args.streams or 3
+            self.streams = args.streams or 8
             self.cpu_paths = args.cpu_paths or (1 << 22)
         else:
             paths = args.paths or (1 << 20)
@@ -107,7 +115,7 @@ class Workload:
             self.label = ("C5 pulse sweep: C2 geometry (%d triangles) through gen-3 receive (wigner transmitter, omnidirectional "
                           "receiver, BF_MODE_RECEIVE_IQ), 1024 fast-time bins, target at -5 m/s, PRI 1 ms; one step = one sweep of "
                           + str(self.n_pulses) + " pulses x %d x 64 = %d paths per pulse per GPU, batched launches")
-            self.streams = args.streams or 3
+            self.streams = args.streams or 4
             self.cpu_paths = args.cpu_paths or (1 << 22)
         self.total_paths = int(self.lp.n_paths)
         if args.scaling == "strong":

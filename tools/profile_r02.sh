@@ -3,6 +3,7 @@
 # Output: gpurun_out/r02prof/...; tools/pmc_traffic.py turns the PMC databases into profiles/r02_pmc_traffic.json.
 set -e
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16      # as bench.py sets it for itself; under rocprofv3 the profiler starts HIP first, so it has to come from outside
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02prof
 mkdir -p $O

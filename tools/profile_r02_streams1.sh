@@ -2,6 +2,7 @@
 # with roofline.kernels[].avg_launch_ms of the same run's JSON line
 set -e
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16      # as bench.py sets it for itself; under rocprofv3 the profiler starts HIP first, so it has to come from outside
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02prof
 mkdir -p $O
