@@ -583,7 +583,10 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
         const char *e = getenv("BF_TAIL_WAVES");
         return e ? atoi(e) : 0;
     }();
-    const bool two = tw_env ? tw_env == 2 : wf->n_slots < bfd::kTailSmallPool;
+    // 3 waves per SIMD (168 VGPRs, some scratch) unless BF_TAIL_WAVES=2 asks for the 2-wave build (no scratch): alone on the
+    // GPU a small pool's tail is 2-3 % faster with 2, but with several renders in flight 3 leave room for the neighbours
+    // (C3 0.74 -> 0.69 ms per render, C4 shard 0.96 -> 0.88; profiles/r02_retune_hw_queues.txt)
+    const bool two = tw_env == 2;
 #define BF_TAIL_LAUNCH(S, P)                                                                                                           \
     if (two)                                                                                                                           \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 2>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \

@@ -25,7 +25,7 @@ constexpr uint32_t kShadeChain = 8;        // wf_shade: vertices per visit while
 constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
 constexpr uint32_t kTraceBlocksPerCU = 8;
-constexpr uint32_t kTailSmallPool = 1u << 22;   // pools below this never fill the chip: earlier tail, tail at 2 waves / SIMD (bf_api.cpp: wf_tail_threshold)
+constexpr uint32_t kTailSmallPool = 1u << 22;   // pools below this never fill the chip: earlier hand-over to the tail (bf_api.cpp: wf_tail_threshold)
 constexpr uint32_t kTailRowJobs = 12;      // tail: up to three passes of four row-traversed rays beat one quad pass of sixteen
 
 struct WF {
