@@ -6,3 +6,12 @@ ctypes bindings (capi), the flat scene description builder (scenedesc) and the
 Mitsuba-shaped front end.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, at
+# most three renders overlap and a fourth stream is slower than three (DESIGN.md 3.3).  Sweeps and pipelined renders keep
+# more in flight, so the package asks for 16 — if the variable is unset and this import comes before the process's first
+# HIP call (the runtime reads it when it starts; `import torch` alone does not start it).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
