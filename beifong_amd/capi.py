@@ -18,12 +18,13 @@ BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
 BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED, BF_EMITTER_POINT = range(6)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED, BF_SENSOR_IRRADIANCEMETER, BF_SENSOR_RADIANCEMETER = range(7)
-BF_ABI_VERSION = 2          # include/beifong_hip.h: BF_ABI_VERSION
+BF_ABI_VERSION = 3          # include/beifong_hip.h: BF_ABI_VERSION
 BF_VELEM_FLOATS = 32
 BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
 BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL, BF_FLAG_DOPPLER, BF_FLAG_MIX_RESAMPLE = 1, 2, 4, 8, 16
+BF_FLAG_ROLLING, BF_FLAG_TIMING = 32, 64
 
 M16 = C.c_float * 16
 
@@ -102,7 +103,7 @@ class bf_stats(C.Structure):
                 ("n_nodes_lds", C.c_uint64), ("n_nodes_tail", C.c_uint64), ("n_wnodes_tail", C.c_uint64),
                 ("n_tris_tail", C.c_uint64), ("n_bounces_tail", C.c_uint64), ("n_shade_loads", C.c_uint64),
                 ("n_shade_stores", C.c_uint64), ("n_shade_shadow", C.c_uint64), ("n_shade_rays", C.c_uint64),
-                ("n_guard", C.c_uint64)]
+                ("n_guard", C.c_uint64), ("n_launches_tail", C.c_uint32), ("reserved_", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -119,10 +120,14 @@ class bf_batch(C.Structure):
     _fields_ = [("n_renders", C.c_uint32), ("seeds", C.POINTER(C.c_uint64)), ("mesh_offsets", C.POINTER(C.c_float))]
 
 
+# include/beifong_hip.h: BF_ABI_MATERIAL .. BF_ABI_BATCH, in that order
+ABI_STRUCTS = [bf_material, bf_shape, bf_emitter, bf_sensor, bf_scene_desc, bf_launch, bf_path_record, bf_stats, bf_scene_info, bf_batch]
+
 # every symbol include/beifong_hip.h declares
 EXPORTED_SYMBOLS = [
-    "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
+    "bf_abi_sizeof", "bf_abi_fingerprint", "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
     "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_scene_clone", "bf_launch_channels", "bf_render_device", "bf_render",
+    "bf_scene_flush", "bf_scene_sync",
     "bf_render_batch_device", "bf_render_batch",
     "bf_trace_closest", "bf_trace_any", "bf_ray_intersect", "bf_eval_elementary",
 ]
@@ -149,6 +154,13 @@ def load_library(path=None):
     lib.bf_version.restype = C.c_int
     if lib.bf_version() != BF_ABI_VERSION:
         raise BeifongError(f"{p}: ABI version {lib.bf_version()}, this binding is for {BF_ABI_VERSION} (include/beifong_hip.h) — rebuild")
+    # struct sizes as the library was compiled against this binding's ctypes mirrors (include/beifong_hip.h: bf_abi_sizeof)
+    lib.bf_abi_sizeof.argtypes = [C.c_uint32]
+    lib.bf_abi_sizeof.restype = C.c_uint32
+    for k, t in enumerate(ABI_STRUCTS):
+        if lib.bf_abi_sizeof(k) != C.sizeof(t):
+            raise BeifongError(f"{p}: sizeof({t.__name__}) is {lib.bf_abi_sizeof(k)} in the library, {C.sizeof(t)} in this binding — "
+                               "rebuild (python -c 'import __graft_entry__ as g; g.build()')")
     lib.bf_last_error.restype = C.c_char_p
     lib.bf_device_count.restype = C.c_int
     lib.bf_set_device.argtypes = [C.c_int]
@@ -162,6 +174,8 @@ def load_library(path=None):
     lib.bf_launch_channels.restype = C.c_uint32
     lib.bf_render_device.argtypes = [vp, C.POINTER(bf_launch), vp, vp, vp, C.POINTER(bf_stats)]
     lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
+    lib.bf_scene_flush.argtypes = [vp, vp, C.POINTER(bf_stats)]
+    lib.bf_scene_sync.argtypes = [vp]
     lib.bf_render_batch_device.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, vp, C.POINTER(bf_stats)]
     lib.bf_render_batch.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
@@ -266,6 +280,18 @@ class Scene:
                                                   C.c_void_p(stream) if stream else None,
                                                   C.byref(st) if st is not None else None), "bf_render_device")
         return st
+
+    def flush(self, stream=0, want_stats=False):
+        """bf_scene_flush: finish the paths the handle's rolling renders (BF_FLAG_ROLLING) left alive; with want_stats the
+        call waits and returns the whole sequence's bf_stats."""
+        st = bf_stats() if want_stats else None
+        check(self.lib, self.lib.bf_scene_flush(self.handle, C.c_void_p(stream) if stream else None,
+                                                C.byref(st) if st is not None else None), "bf_scene_flush")
+        return st
+
+    def sync(self):
+        """bf_scene_sync: flush, wait for the handle's work and raise if any render since the last check dropped rays."""
+        check(self.lib, self.lib.bf_scene_sync(self.handle), "bf_scene_sync")
 
     @staticmethod
     def _batch(n_renders, seeds, offsets):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -36,7 +37,8 @@ extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uin
                                    hipStream_t stream, int waves);
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
-                                      hipStream_t stream);
+                                      hipStream_t stream, int tail_waves, unsigned spread, unsigned block_cap);
+extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, uint32_t idx, const bfd::DRoll *d, hipStream_t stream);
 
 namespace {
 
@@ -103,10 +105,61 @@ struct bf_geometry {
     }
 };
 
+// Developer overrides, read from the environment ONCE, when a scene is created; clones inherit them.
+struct bf_tunables {
+    uint32_t pool = 1u << 24;                // BF_WF_POOL
+    int64_t tail = -1;                       // BF_WF_TAIL (-1: by pool size)
+    uint32_t trace_refill = bfd::kTraceRefill, trace_stragglers = bfd::kTraceStragglers;
+    uint32_t shade_chain = bfd::kShadeChain, row_jobs = bfd::kTailRowJobs;
+    int shade_waves = 3, trace_waves = 5, tail_waves = 3;
+    unsigned tail_spread = 1, tail_blocks = 0;
+    bool allow_plan = true;                  // BF_WF_SYNC=1 turns launch plans off
+    uint32_t roll_iters = 0;                 // BF_ROLL_ITERS: bounce iterations per call of a rolling sequence (0: adaptive)
+    bool no_wide = false, quant = false;
+    int wide_rows_log = -1;
+};
+static bf_tunables read_tunables() {
+    bf_tunables t;
+    auto num = [](const char *name, long long dflt) -> long long {
+        const char *e = getenv(name);
+        return e ? strtoll(e, nullptr, 10) : dflt;
+    };
+    t.pool = (uint32_t) std::max<long long>(1024, std::min<long long>(num("BF_WF_POOL", 1ll << 24), 1ll << 26));
+    t.tail = num("BF_WF_TAIL", -1);
+    t.trace_refill = (uint32_t) num("BF_TRACE_REFILL", bfd::kTraceRefill);
+    t.trace_stragglers = (uint32_t) num("BF_TRACE_STRAGGLERS", bfd::kTraceStragglers);
+    t.shade_chain = (uint32_t) std::max<long long>(1, num("BF_SHADE_CHAIN", bfd::kShadeChain));
+    t.row_jobs = (uint32_t) num("BF_TAIL_ROWJOBS", bfd::kTailRowJobs);
+    t.shade_waves = (int) std::max<long long>(1, std::min<long long>(4, num("BF_SHADE_WAVES", 3)));
+    {
+        const long long w = num("BF_TRACE_WAVES", 5);
+        t.trace_waves = w < 5 ? 4 : (w > 5 ? 6 : 5);
+    }
+    t.tail_waves = num("BF_TAIL_WAVES", 3) == 2 ? 2 : 3;
+    t.tail_spread = (unsigned) std::max<long long>(1, num("BF_TAIL_SPREAD", 1));
+    t.tail_blocks = (unsigned) std::max<long long>(0, num("BF_TAIL_BLOCKS", 0));
+    t.allow_plan = num("BF_WF_SYNC", 0) == 0;
+    t.roll_iters = (uint32_t) std::max<long long>(0, std::min<long long>(32, num("BF_ROLL_ITERS", 0)));
+    t.no_wide = getenv("BF_NO_WIDE_BVH") != nullptr;
+    t.quant = num("BF_QUANT_BVH", 0) != 0;
+    t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
+    return t;
+}
+
 struct bf_scene {
     bfd::DScene d;
+    bf_tunables tun;
     std::shared_ptr<bf_geometry> geom;     // nodes / wnodes / tris / normals / uvs as created
+    // handles that render the SAME triangle / node arrays hold the same token (a clone that took its own snapshot of a
+    // translated scene does not): bf_scene_translate_meshes copies on write only while the token is shared
+    std::shared_ptr<char> geom_token;
     bool geom_private = false;             // d.tris / d.nodes / d.wnodes point at this handle's own translated copies
+    // one host thread at a time per handle (the handle owns the path pool its render's state lives in)
+    mutable std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    // stream order between successive renders of the handle: a render on another stream than the previous one waits for it
+    mutable hipStream_t last_stream = nullptr;
+    mutable hipEvent_t last_done = nullptr;
+    mutable bool has_last = false;
     std::vector<void *> owned;             // this handle's own allocations (small tables, spill columns, private geometry)
     bf_scene_info info;
     int device = 0;
@@ -131,9 +184,28 @@ struct bf_scene {
     mutable uint32_t *wf_host = nullptr;   // pinned read-back of queue counters
     mutable hipEvent_t wf_event = nullptr;
     mutable unsigned long long *wf_masks = nullptr;
-    mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only)
-    mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render
-    mutable uint32_t wf_iters = 0, wf_trace_launches = 0;
+    mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only): pair k = events 2k, 2k + 1
+    mutable std::vector<int> wf_ev_kind;         // kind of every recorded pair: 0 trace, 1 shade, 2 tail
+    mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render / rolling sequence
+    mutable uint32_t wf_iters = 0, wf_trace_launches = 0, wf_tail_launches = 0;
+    // Rolling sequence (bf_render_device with BF_FLAG_ROLLING, bf_scene_flush): see wf_roll_render
+    struct Roll {
+        bool open = false;
+        uint32_t count = 0;                      // renders issued since the sequence was opened
+        uint32_t it = 0;                         // bounce-iteration counter (mask parity runs on across calls)
+        bf_launch shape;                         // launch of the first render: later ones may differ in seed / path_offset only
+        bfd::DLaunch lp;                         // device launch of the sequence (n_paths = supply so far)
+        hipStream_t stream = nullptr;
+        bool count_nodes = false, timed = false;
+        uint32_t window = 1;                     // renders of the LDS histogram window
+        uint32_t iters = 0;                      // bounce iterations per call (adapted from the live counts)
+        uint32_t flush_iters = 0;                // planned bounce iterations of a flush before its tail (learned)
+        uint32_t flush_live = 0;                 // slots alive at the flush's tail (learned: sizes its grid)
+        uint32_t fb_call_iters = 0;              // iterations of the call whose live counts are in flight to wf_feedback
+        bool fb_is_flush = false;
+    };
+    mutable Roll roll;
+    mutable bfd::DRoll *roll_ring = nullptr;     // device [kRollRing]
     // Launch plan learned from the previous render of the same shape (wf_render): how many bounce
     // iterations precede the tail and how many slots are then alive.  With a plan the whole render is
     // enqueued without a host round trip; the live counts come back through a pinned buffer afterwards.
@@ -165,9 +237,37 @@ struct bf_scene {
     mutable uint32_t wf_fb_iters = 0;
 };
 
+// One host thread at a time per handle: the second one gets BF_ERR_INVALID instead of a race on the handle's pool.
+namespace {
+struct BusyGuard {
+    const bf_scene *s;
+    bool ok;
+    explicit BusyGuard(const bf_scene *sc) : s(sc), ok(sc && !sc->busy.test_and_set(std::memory_order_acquire)) {}
+    ~BusyGuard() {
+        if (ok) s->busy.clear(std::memory_order_release);
+    }
+};
+#define BF_ENTER(scene)                                                                                                   \
+    BusyGuard busy_guard_(scene);                                                                                         \
+    if (!busy_guard_.ok)                                                                                                  \
+        return fail(BF_ERR_INVALID, "%s: the scene handle is in use by another host thread (one call at a time per handle; " \
+                                    "bf_scene_clone gives every thread / stream its own)", __func__)
+}  // namespace
+
+static bf_status order_after_last(const bf_scene *scene, hipStream_t stream);
+static bf_status mark_last(const bf_scene *scene, hipStream_t stream);
+static bf_status close_sequence(const bf_scene *scene, hipStream_t stream);
+
 extern "C" {
 
 int bf_version(void) { return BF_ABI_VERSION; }
+uint32_t bf_abi_sizeof(uint32_t which) {
+    static const uint32_t sizes[BF_ABI_STRUCTS] = {sizeof(bf_material), sizeof(bf_shape), sizeof(bf_emitter), sizeof(bf_sensor),
+                                                   sizeof(bf_scene_desc), sizeof(bf_launch), sizeof(bf_path_record), sizeof(bf_stats),
+                                                   sizeof(bf_scene_info), sizeof(bf_batch)};
+    return which < BF_ABI_STRUCTS ? sizes[which] : 0u;
+}
+uint64_t bf_abi_fingerprint(void) { return BF_ABI_FINGERPRINT; }
 const char *bf_last_error(void) { return g_err.c_str(); }
 
 int bf_device_count(void) {
@@ -199,12 +299,16 @@ uint32_t bf_launch_channels(const bf_launch *lp) {
 
 bf_status bf_scene_destroy(bf_scene *s) {
     if (!s) return BF_OK;
+    // kernels of this handle that are still in flight read the arrays freed below (an open rolling sequence is simply
+    // abandoned: its histograms stay incomplete, as documented)
+    if (s->has_last) (void) hipEventSynchronize(s->last_done);
     for (void *p : s->owned) (void) hipFree(p);
     for (void *p : s->wf_owned) (void) hipFree(p);
     if (s->wf_host) (void) hipHostFree(s->wf_host);
     if (s->wf_event) (void) hipEventDestroy(s->wf_event);
     if (s->wf_feedback) (void) hipHostFree(s->wf_feedback);
     if (s->wf_fb_event) (void) hipEventDestroy(s->wf_fb_event);
+    if (s->last_done) (void) hipEventDestroy(s->last_done);
     for (hipEvent_t e : s->wf_timing) (void) hipEventDestroy(e);
     if (s->counters) (void) hipFree(s->counters);
     for (auto &st : s->stage) {
@@ -257,6 +361,7 @@ static bf_status stage_release_after(bf_scene::Stage *st, hipStream_t stream) {
 
 static int32_t bfd_no_node() { return INT32_MIN; }
 static_assert(bf::kTopNodes == bfd::kTopNodes, "the builder's breadth-first prefix is what wf_trace caches");
+static_assert(bfd::CTR_GUARD + 1 == bfd::CTR_COUNT, "the sticky guard word is the last counter: renders clear the ones before it");
 
 namespace {
 struct TriMeta {
@@ -541,7 +646,9 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     std::memset(&sc->d, 0, sizeof(sc->d));
     std::memset(&sc->info, 0, sizeof(sc->info));
     std::memset(&sc->wf, 0, sizeof(sc->wf));
+    sc->tun = read_tunables();
     sc->geom = std::make_shared<bf_geometry>();
+    sc->geom_token = std::make_shared<char>(0);
     {
         bf_status ast = bind_arrays(sc, flat, nullptr, true);
         if (ast != BF_OK) {
@@ -565,8 +672,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     uint32_t wide_rlog = 2;
     while (wide_rlog > 0 && (16u << wide_rlog) * std::max(1u, bvh16.max_depth) > (uint32_t) bfd::kWideStack) --wide_rlog;
     const bool use_wide = !btris.empty() && 16u * std::max(1u, bvh16.max_depth) <= (uint32_t) bfd::kWideStack &&
-                          btris.size() < (1u << 27) && !getenv("BF_NO_WIDE_BVH");
-    if (const char *e = getenv("BF_WIDE_ROWS_LOG")) wide_rlog = std::min<uint32_t>(wide_rlog, (uint32_t) atoi(e));
+                          btris.size() < (1u << 27) && !sc->tun.no_wide;
+    if (sc->tun.wide_rows_log >= 0) wide_rlog = std::min<uint32_t>(wide_rlog, (uint32_t) sc->tun.wide_rows_log);
     for (int k = 0; k < 3 && !btris.empty(); ++k)
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
     std::vector<float4> tri_data(3 * btris.size()), nrm_data;
@@ -611,7 +718,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     // (wf_trace 4.33 -> 4.45 ms per step; the kernel waits on dependent fetches and on its half-busy VALU, not on the
     // number of vector-memory instructions: DESIGN.md 3.1), so the fp32 nodes stay the default.
     std::vector<float4> qnode_data;
-    if (!bvh4.nodes.empty() && getenv("BF_QUANT_BVH") && atoi(getenv("BF_QUANT_BVH")) != 0) {
+    if (!bvh4.nodes.empty() && sc->tun.quant) {
         std::vector<bf::Node4Q> q;
         bf::quantise_bvh4(bvh4, q);
         qnode_data.resize(4 * q.size());
@@ -688,6 +795,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->d.lambda_max = desc->physics.lambda_max_nm;
 
     hipError_t e = hipMalloc((void **) &sc->counters, sizeof(unsigned long long) * bfd::CTR_COUNT);
+    if (e == hipSuccess) e = hipMemset(sc->counters, 0, sizeof(unsigned long long) * bfd::CTR_COUNT);
     if (e != hipSuccess) {
         bf_scene_destroy(sc);
         return fail(BF_ERR_DEVICE, "hipMalloc(counters): %s", hipGetErrorString(e));
@@ -733,6 +841,13 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
                                         "BVH boxes were padded for; create a new scene", (double) f.origin_scale,
                     (double) scene->origin_scale_built);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BF_ENTER(scene);
+    {
+        // the paths of an open rolling sequence belong to the endpoints as they are: finish them first
+        bf_status ost = order_after_last(scene, stream);
+        if (ost == BF_OK) ost = close_sequence(scene, stream);
+        if (ost != BF_OK) return ost;
+    }
     {
         bf_status ast = bind_arrays(scene, f, stream, false);
         if (ast != BF_OK) return ast;
@@ -772,7 +887,7 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
     scene->d.c = desc->physics.c;
     scene->d.lambda_min = desc->physics.lambda_min_nm;
     scene->d.lambda_max = desc->physics.lambda_max_nm;
-    return BF_OK;
+    return mark_last(scene, stream);
 }
 
 bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void *stream_) {
@@ -781,51 +896,69 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         return fail(BF_ERR_INVALID, "bf_scene_translate_meshes: non-finite offset");
     if (scene->d.n_tris == 0) return BF_OK;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BF_ENTER(scene);
+    {
+        bf_status ost = order_after_last(scene, stream);
+        if (ost == BF_OK) ost = close_sequence(scene, stream);
+        if (ost != BF_OK) return ost;
+    }
     const size_t tri_bytes = (size_t) scene->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
     const size_t wnode_bytes = scene->d.wnodes ? (size_t) scene->d.n_wnodes * 32 * sizeof(float4) : 0;
-    const bool shared = scene->geom.use_count() > 1 && !scene->geom_private;
-    auto own_copy = [&](size_t bytes, float4 **out) -> bf_status {
-        *out = nullptr;
-        if (!bytes) return BF_OK;
-        void *p = nullptr;
-        HIP_TRY(hipMalloc(&p, bytes));
-        scene->owned.push_back(p);
-        *out = (float4 *) p;
+    const bool shared = scene->geom_token.use_count() > 1 && !scene->geom_private;
+    // all-or-nothing allocation: the handle's pointers change only once every copy exists (a failed hipMalloc half way
+    // must not leave tris0 set and nodes0 null for the next call to trip over)
+    struct Copies {
+        float4 *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    } cp;
+    auto alloc_all = [&](const size_t (&bytes)[4]) -> bf_status {
+        for (int k = 0; k < 4; ++k) {
+            if (!bytes[k]) continue;
+            void *q = nullptr;
+            hipError_t he = hipMalloc(&q, bytes[k]);
+            if (he != hipSuccess) {
+                for (int j = 0; j < k; ++j)
+                    if (cp.p[j]) (void) hipFree(cp.p[j]);
+                return fail(BF_ERR_NOMEM, "bf_scene_translate_meshes: hipMalloc(%zu bytes): %s", bytes[k], hipGetErrorString(he));
+            }
+            cp.p[k] = (float4 *) q;
+        }
+        for (int k = 0; k < 4; ++k)
+            if (cp.p[k]) scene->owned.push_back(cp.p[k]);
         return BF_OK;
     };
     if (shared) {
         // copy on write: the arrays are shared with clones (bf_scene_clone) — this handle gets its own translated
         // copies; the source of the translation is the geometry as created if this handle has it (it translated in
         // place before it was cloned), else the shared arrays themselves
-        float4 *t = nullptr, *n = nullptr, *w = nullptr, *q = nullptr;
-        bf_status cst;
-        if ((cst = own_copy(tri_bytes, &t)) != BF_OK || (cst = own_copy(node_bytes, &n)) != BF_OK || (cst = own_copy(wnode_bytes, &w)) != BF_OK ||
-            (cst = own_copy(scene->d.qnodes ? node_bytes / 2 : 0, &q)) != BF_OK)
-            return cst;
+        const size_t bytes[4] = {tri_bytes, node_bytes, wnode_bytes, scene->d.qnodes ? node_bytes / 2 : 0};
+        bf_status cst = alloc_all(bytes);
+        if (cst != BF_OK) return cst;
         if (!scene->tris0) {
             scene->tris0 = const_cast<float4 *>(scene->d.tris);
             scene->nodes0 = const_cast<float4 *>(scene->d.nodes);
             scene->wnodes0 = const_cast<float4 *>(scene->d.wnodes);
         }
-        scene->d.tris = t;
-        scene->d.nodes = n;
-        scene->d.wnodes = w;
-        if (scene->d.qnodes) scene->d.qnodes = q;       // re-quantised from the translated fp32 nodes by the kernel below
-        scene->geom_private = true;
+        scene->d.tris = cp.p[0];
+        scene->d.nodes = cp.p[1];
+        scene->d.wnodes = cp.p[2];
+        if (scene->d.qnodes) scene->d.qnodes = cp.p[3];       // re-quantised from the translated fp32 nodes by the kernel below
+        scene->geom_private = true;       // (the token stays shared: tris0 / nodes0 may still READ the shared arrays)
     } else if (!scene->tris0) {
         // first use: keep the geometry as created, so that every later offset is applied to it (no drift)
-        bf_status cst;
-        if ((cst = own_copy(tri_bytes, &scene->tris0)) != BF_OK || (cst = own_copy(node_bytes, &scene->nodes0)) != BF_OK ||
-            (cst = own_copy(wnode_bytes, &scene->wnodes0)) != BF_OK)
-            return cst;
-        HIP_TRY(hipMemcpyAsync(scene->tris0, scene->d.tris, tri_bytes, hipMemcpyDeviceToDevice, stream));
-        if (node_bytes) HIP_TRY(hipMemcpyAsync(scene->nodes0, scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
-        if (wnode_bytes) HIP_TRY(hipMemcpyAsync(scene->wnodes0, scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
+        const size_t bytes[4] = {tri_bytes, node_bytes, wnode_bytes, 0};
+        bf_status cst = alloc_all(bytes);
+        if (cst != BF_OK) return cst;
+        HIP_TRY(hipMemcpyAsync(cp.p[0], scene->d.tris, tri_bytes, hipMemcpyDeviceToDevice, stream));
+        if (node_bytes) HIP_TRY(hipMemcpyAsync(cp.p[1], scene->d.nodes, node_bytes, hipMemcpyDeviceToDevice, stream));
+        if (wnode_bytes) HIP_TRY(hipMemcpyAsync(cp.p[2], scene->d.wnodes, wnode_bytes, hipMemcpyDeviceToDevice, stream));
+        scene->tris0 = cp.p[0];
+        scene->nodes0 = cp.p[1];
+        scene->wnodes0 = cp.p[2];
     }
     HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
                                  const_cast<float4 *>(scene->d.nodes), const_cast<float4 *>(scene->d.qnodes), scene->d.n_nodes, scene->wnodes0,
                                  const_cast<float4 *>(scene->d.wnodes), wnode_bytes ? scene->d.n_wnodes * 16u : 0u, offset, stream));
-    return BF_OK;
+    return mark_last(scene, stream);
 }
 
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
@@ -837,11 +970,18 @@ bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
 bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     if (!src || !out) return fail(BF_ERR_INVALID, "null argument");
     *out = nullptr;
+    BF_ENTER(src);
+    {
+        bf_status cst = close_sequence(src, src->roll.stream);
+        if (cst != BF_OK) return cst;
+    }
     HIP_TRY(hipDeviceSynchronize());      // pending endpoint updates / translations of `src` are part of what is cloned
     bf_scene *sc = new (std::nothrow) bf_scene();
     if (!sc) return fail(BF_ERR_NOMEM, "out of host memory");
     sc->d = src->d;                        // geometry pointers shared (as they stand now); the rest replaced below
+    sc->tun = src->tun;
     sc->geom = src->geom;
+    sc->geom_token = src->geom_token;      // replaced below if the clone takes its own snapshot
     std::memset(&sc->wf, 0, sizeof(sc->wf));
     sc->info = src->info;
     sc->device = src->device;
@@ -879,6 +1019,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
         if ((st = dup(src->d.wnodes, wnode_bytes, (const void **) &sc->d.wnodes)) != BF_OK) return fail_out(st);
         if (src->d.qnodes && (st = dup(src->d.qnodes, node_bytes / 2, (const void **) &sc->d.qnodes)) != BF_OK) return fail_out(st);
         sc->geom_private = true;
+        sc->geom_token = std::make_shared<char>(0);      // the snapshot is the clone's alone: `src` keeps translating in place
     }
     if ((st = dup(src->d.rects, sizeof(bfd::DRect) * src->d.n_rects, (const void **) &sc->d.rects)) != BF_OK) return fail_out(st);
     if ((st = dup(src->d.shapes, sizeof(bfd::DShape) * src->info.n_shapes, (const void **) &sc->d.shapes)) != BF_OK) return fail_out(st);
@@ -929,6 +1070,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     }
     {
         hipError_t e = hipMalloc((void **) &sc->counters, sizeof(unsigned long long) * bfd::CTR_COUNT);
+        if (e == hipSuccess) e = hipMemset(sc->counters, 0, sizeof(unsigned long long) * bfd::CTR_COUNT);
         if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: counters: %s", hipGetErrorString(e)));
     }
     *out = sc;
@@ -939,19 +1081,13 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
 // ---------------------------------------------------------------------------
 // wavefront driver
 // ---------------------------------------------------------------------------
-static uint32_t wf_pool_capacity() {
-    const char *e = getenv("BF_WF_POOL");
-    uint64_t v = e ? strtoull(e, nullptr, 10) : (1ull << 24);
-    v = std::max<uint64_t>(1024, std::min<uint64_t>(v, 1ull << 26));
-    return (uint32_t) v;
-}
-
 static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     bfd::WF &wf = scene->wf;
     if (wf.capacity >= capacity) return BF_OK;
     for (void *p : scene->wf_owned) (void) hipFree(p);
     scene->wf_owned.clear();
     std::memset(&wf, 0, sizeof(wf));
+    scene->roll_ring = nullptr;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) scene->wf_owned.push_back(*p);
@@ -974,6 +1110,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &scene->wf_dop_buf, n * 4));
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
+    HIP_TRY(alloc((void **) &scene->roll_ring, bfd::kRollRing * sizeof(bfd::DRoll)));
     wf.counters = scene->counters;
     wf.capacity = capacity;
     if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
@@ -990,11 +1127,140 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
 // bench step, sweeps) switch at 2^17 live slots — more would keep the tail's 168-VGPR waves on the CUs the next renders'
 // kernels want (measured: 2^18 costs 12 % of the pipelined C2 rate) — small pools, whose kernels never fill the chip,
 // switch as soon as half the pool is done (C3: 1.21 -> 0.98 ms per render, C4 shard: 1.71 -> 1.30).
-static uint32_t wf_tail_threshold(uint32_t n_slots) {
-    const char *e = getenv("BF_WF_TAIL");
-    if (e) return (uint32_t) strtoul(e, nullptr, 10);
+static uint32_t wf_tail_threshold(const bf_scene *scene, uint32_t n_slots) {
+    if (scene->tun.tail >= 0) return (uint32_t) scene->tun.tail;
     if (n_slots >= bfd::kTailSmallPool) return 1u << 17;
     return std::max<uint32_t>(1u << 17, std::min<uint32_t>(1u << 19, n_slots / 2));
+}
+
+namespace {
+// Everything the launches of one render (or of one call of a rolling sequence) share.
+struct WfCtx {
+    const bf_scene *scene;
+    const bfd::DLaunch *lp;
+    float *hist;
+    bf_path_record *rec;
+    hipStream_t stream;
+    bool count_nodes, timed;
+    size_t mask_bytes, lds_shade, lds_tail;
+    unsigned grid_shade, grid_trace;
+    uint32_t tail_max;
+};
+}  // namespace
+
+// per-kernel timing (stats renders, BF_FLAG_TIMING sequences): one event pair around every launch
+static hipError_t wf_tic(const WfCtx &c, int kind) {
+    if (!c.timed) return hipSuccess;
+    const bf_scene *sc = c.scene;
+    while (sc->wf_timing.size() < 2 * (sc->wf_ev_kind.size() + 1)) {
+        hipEvent_t e;
+        hipError_t he = hipEventCreate(&e);
+        if (he != hipSuccess) return he;
+        sc->wf_timing.push_back(e);
+    }
+    sc->wf_ev_kind.push_back(kind);
+    return hipEventRecord(sc->wf_timing[2 * (sc->wf_ev_kind.size() - 1)], c.stream);
+}
+static hipError_t wf_toc(const WfCtx &c) {
+    if (!c.timed) return hipSuccess;
+    return hipEventRecord(c.scene->wf_timing[2 * (c.scene->wf_ev_kind.size() - 1) + 1], c.stream);
+}
+// wait for the stream and add the recorded pairs up by kind (wf_ms), then forget them
+static bf_status wf_collect_timing(const bf_scene *scene, hipStream_t stream) {
+    scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
+    scene->wf_tail_launches = 0;
+    if (scene->wf_ev_kind.empty()) return BF_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t k = 0; k < scene->wf_ev_kind.size(); ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, scene->wf_timing[2 * k], scene->wf_timing[2 * k + 1]));
+        scene->wf_ms[scene->wf_ev_kind[k]] += ms;
+        if (scene->wf_ev_kind[k] == 2) ++scene->wf_tail_launches;
+    }
+    scene->wf_ev_kind.clear();
+    return BF_OK;
+}
+
+// pool size, masks, scheduling knobs and grids for `lp` on this handle
+static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_t pool_paths, float *hist_dev, bf_path_record *records_dev,
+                          hipStream_t stream, bool count_nodes, bool timed, WfCtx &c) {
+    uint64_t want = std::min<uint64_t>(scene->tun.pool, std::max<uint64_t>(pool_paths, 64));
+    uint32_t cap = (uint32_t) ((want + 63) & ~uint64_t(63));
+    bf_status st = wf_ensure(scene, cap);
+    if (st != BF_OK) return st;
+    bfd::WF &wf = scene->wf;
+    wf.n_slots = (uint32_t) ((std::min<uint64_t>(wf.capacity, pool_paths) + 63) & ~uint64_t(63));
+    wf.trace_refill = scene->tun.trace_refill;
+    wf.trace_stragglers = scene->tun.trace_stragglers;
+    wf.shade_chain = scene->tun.shade_chain;
+    wf.row_jobs = scene->tun.row_jobs;
+    wf.iq = lp.iq;
+    wf.render = lp.batch != 0u ? scene->wf_render_buf : nullptr;
+    wf.offsets = lp.batch_offsets;
+    wf.dop = lp.doppler ? scene->wf_dop_buf : nullptr;
+    wf.box_slack = lp.box_slack;
+    const size_t nb = wf.n_slots / 64;
+    for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
+        wf.m_alive[b] = scene->wf_masks + (3 * b + 0) * nb;
+        wf.m_trace[b] = scene->wf_masks + (3 * b + 1) * nb;
+        wf.m_shadow[b] = scene->wf_masks + (3 * b + 2) * nb;
+    }
+    c.scene = scene;
+    c.lp = &lp;
+    c.hist = hist_dev;
+    c.rec = records_dev;
+    c.stream = stream;
+    c.count_nodes = count_nodes;
+    c.timed = timed;
+    c.mask_bytes = 3 * nb * sizeof(unsigned long long);
+    c.lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan_all + 15) & ~size_t(15)) : 0;
+    c.lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + c.lds_shade;
+    // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
+    // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)
+    const unsigned batches_per_block = bfd::kBlock / 64;
+    const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
+    c.grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, scene->tun.shade_waves), max_blocks));
+    c.grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) scene->tun.trace_waves, max_blocks));
+    c.tail_max = wf_tail_threshold(scene, wf.n_slots);
+    return BF_OK;
+}
+// One bounce iteration `it`: clear the next parity's masks, shade (first: 0 alive masks, 1 first bounce of a pool, 2 alive
+// masks then the wake launch of a rolling call), trace.
+static bf_status wf_iteration(const WfCtx &c, uint32_t it, int first) {
+    const bf_scene *scene = c.scene;
+    const bfd::WF &wf = scene->wf;
+    const int nxt = (it & 1) ^ 1;
+    HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, c.mask_bytes, c.stream));     // alive, trace, shadow are contiguous
+    if (first != 1) {
+        HIP_TRY(wf_tic(c, 1));
+        HIP_TRY(bfk_wf_shade(&scene->d, c.lp, &wf, it, 0, c.hist, c.rec, c.grid_shade, c.lds_shade, c.stream, scene->tun.shade_waves));
+        HIP_TRY(wf_toc(c));
+    }
+    if (first != 0) {
+        HIP_TRY(wf_tic(c, 1));
+        HIP_TRY(bfk_wf_shade(&scene->d, c.lp, &wf, it, first, c.hist, c.rec, c.grid_shade, c.lds_shade, c.stream, scene->tun.shade_waves));
+        HIP_TRY(wf_toc(c));
+    }
+    return BF_OK;
+}
+static bf_status wf_trace_launch(const WfCtx &c, uint32_t it) {
+    HIP_TRY(wf_tic(c, 0));
+    HIP_TRY(bfk_wf_trace(&c.scene->d, &c.scene->wf, it, c.count_nodes ? 1 : 0, c.grid_trace, c.stream, c.scene->tun.trace_waves));
+    HIP_TRY(wf_toc(c));
+    return BF_OK;
+}
+static bf_status wf_tail_launch(const WfCtx &c, uint32_t it, uint32_t est_live) {
+    const bf_scene *scene = c.scene;
+    HIP_TRY(wf_tic(c, 2));
+    HIP_TRY(bfk_launch_tail(&scene->d, c.lp, &scene->wf, it, est_live, c.hist, c.rec, c.count_nodes ? 1 : 0, c.lds_tail, c.stream,
+                            scene->tun.tail_waves, scene->tun.tail_spread, scene->tun.tail_blocks));
+    HIP_TRY(wf_toc(c));
+    return BF_OK;
+}
+// The guard word of wf_trace (CTR_GUARD) is never cleared by a render, so it is sticky across the renders of a handle.
+static bf_status wf_guard_error(unsigned long long lost) {
+    return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays in an earlier render of this scene: that render's "
+                               "histogram is wrong (a traversal bug; please report the scene)", lost);
 }
 
 // Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
@@ -1004,101 +1270,39 @@ static uint32_t wf_tail_threshold(uint32_t n_slots) {
 // finishes them (including the paths those slots still have to start).
 static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float *hist_dev, bf_path_record *records_dev,
                            hipStream_t stream, bool count_nodes, bool stats) {
-    uint64_t want = std::min<uint64_t>(wf_pool_capacity(), std::max<uint64_t>(lp.n_paths, 64));
-    uint32_t cap = (uint32_t) ((want + 63) & ~uint64_t(63));
-    bf_status st = wf_ensure(scene, cap);
+    WfCtx c;
+    bf_status st = wf_setup(scene, lp, lp.n_paths, hist_dev, records_dev, stream, count_nodes, stats, c);
     if (st != BF_OK) return st;
     bfd::WF &wf = scene->wf;
-    wf.n_slots = (uint32_t) ((std::min<uint64_t>(wf.capacity, lp.n_paths) + 63) & ~uint64_t(63));
-    {
-        const char *e1 = getenv("BF_TRACE_REFILL"), *e2 = getenv("BF_TRACE_STRAGGLERS");
-        wf.trace_refill = e1 ? (uint32_t) atoi(e1) : bfd::kTraceRefill;
-        wf.trace_stragglers = e2 ? (uint32_t) atoi(e2) : bfd::kTraceStragglers;
-        const char *e3 = getenv("BF_SHADE_CHAIN");
-        wf.shade_chain = std::max(1, e3 ? atoi(e3) : (int) bfd::kShadeChain);
-        wf.iq = lp.iq;
-        wf.render = lp.batch != 0u ? scene->wf_render_buf : nullptr;
-        wf.offsets = lp.batch_offsets;
-        wf.dop = lp.doppler ? scene->wf_dop_buf : nullptr;
-        wf.box_slack = lp.box_slack;
-        const char *e4 = getenv("BF_TAIL_ROWJOBS");
-        wf.row_jobs = e4 ? (uint32_t) atoi(e4) : bfd::kTailRowJobs;
-    }
-    const size_t nb = wf.n_slots / 64, mask_bytes = 3 * nb * sizeof(unsigned long long);
-    for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
-        wf.m_alive[b] = scene->wf_masks + (3 * b + 0) * nb;
-        wf.m_trace[b] = scene->wf_masks + (3 * b + 1) * nb;
-        wf.m_shadow[b] = scene->wf_masks + (3 * b + 2) * nb;
-    }
     HIP_TRY(hipMemsetAsync(wf.n_live, 0, (bfd::kWfMaxIter + 2) * sizeof(uint32_t), stream));
-    size_t lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan_all + 15) & ~size_t(15)) : 0;
-    size_t lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + lds_shade;
-    static const int shade_waves = [] {
-        const char *e = getenv("BF_SHADE_WAVES");
-        int w = e ? atoi(e) : 3;
-        return w < 1 ? 1 : (w > 4 ? 4 : w);
-    }();
-    static const int trace_waves = [] {
-        const char *e = getenv("BF_TRACE_WAVES");
-        int w = e ? atoi(e) : 5;
-        return w < 5 ? 4 : (w > 5 ? 6 : 5);
-    }();
-    // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
-    // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)
-    const unsigned batches_per_block = bfd::kBlock / 64;
-    const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
-    const unsigned grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, shade_waves), max_blocks));
-    const unsigned grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) trace_waves, max_blocks));
-    const uint32_t tail_max = wf_tail_threshold(wf.n_slots);
+    const uint32_t tail_max = c.tail_max;
     volatile uint32_t *hq = scene->wf_host;      // [0] = n_live[it]
-    // per-kernel timing (stats renders only): events bracket every launch
-    const size_t kMaxTimed = 96;
-    size_t n_ev = 0;
-    std::vector<int> ev_kind;                    // 0 trace, 1 shade, 2 tail (per event pair)
-    if (stats)
-        while (scene->wf_timing.size() < 2 * kMaxTimed) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            scene->wf_timing.push_back(e);
-        }
-    auto tic = [&](int kind) -> hipError_t {
-        if (!stats || n_ev >= kMaxTimed) return hipSuccess;
-        ev_kind.push_back(kind);
-        return hipEventRecord(scene->wf_timing[2 * n_ev], stream);
-    };
-    auto toc = [&]() -> hipError_t {
-        if (!stats || n_ev >= kMaxTimed) return hipSuccess;
-        return hipEventRecord(scene->wf_timing[2 * n_ev++ + 1], stream);
-    };
+    scene->wf_ev_kind.clear();
     auto finish = [&](uint32_t iters, uint32_t traces) -> bf_status {
-        scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
         scene->wf_iters = iters;
         scene->wf_trace_launches = traces;
-        if (!stats) return BF_OK;
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (size_t k = 0; k < n_ev; ++k) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, scene->wf_timing[2 * k], scene->wf_timing[2 * k + 1]));
-            scene->wf_ms[ev_kind[k]] += ms;
+        if (!stats) {
+            scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
+            return BF_OK;
         }
-        return BF_OK;
+        return wf_collect_timing(scene, stream);
     };
     // ---- planned render: no host round trip ------------------------------------------------------
     bf_scene::WfPlan &plan = scene->wf_plan;
     const uint32_t depth_key = (uint32_t) lp.max_depth;
-    static const bool allow_plan = [] {
-        const char *e = getenv("BF_WF_SYNC");
-        return !(e && atoi(e) != 0);
-    }();
     const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
     (void) hipGetLastError();      // hipErrorNotReady from the query must not leak into the launch checks below
-    if (fb_ready) {
+    if (fb_ready && scene->roll.fb_call_iters) {      // the counts in flight belong to a rolling call: not this plan's
+        scene->wf_fb_pending = false;
+        scene->roll.fb_call_iters = 0;
+    } else if (fb_ready) {
         // live counts of the last planned render: move the switch to the tail to where it belongs
         scene->wf_fb_pending = false;
         const unsigned long long lost = reinterpret_cast<volatile unsigned long long *>(scene->wf_host)[1];
-        if (lost)
-            return fail(BF_ERR_DEVICE, "the previous planned render of this scene dropped %llu rays at wf_trace's iteration guard: "
-                                       "its histogram is wrong (a traversal bug; please report the scene)", lost);
+        if (lost) {
+            HIP_TRY(hipMemsetAsync(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long), stream));
+            return wf_guard_error(lost);
+        }
         const uint32_t *nl = scene->wf_feedback;
         uint32_t k = 0;
         while (k < scene->wf_fb_iters && nl[k] > plan.tail_max) ++k;
@@ -1110,24 +1314,15 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
             plan.tail_live = nl[scene->wf_fb_iters - 1];
         }
     }
-    if (allow_plan && plan.valid && plan.n_paths == lp.n_paths && plan.mode == lp.mode &&
+    if (scene->tun.allow_plan && plan.valid && plan.n_paths == lp.n_paths && plan.mode == lp.mode &&
         plan.max_depth == depth_key && plan.n_slots == wf.n_slots && plan.tail_max == tail_max && plan.iters > 0) {
         for (uint32_t it = 0; it < plan.iters; ++it) {
-            const int nxt = (it & 1) ^ 1;
-            HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, mask_bytes, stream));
-            HIP_TRY(tic(1));
-            HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev, grid_shade, lds_shade, stream,
-                                 shade_waves));
-            HIP_TRY(toc());
-            HIP_TRY(tic(0));
-            HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream, trace_waves));
-            HIP_TRY(toc());
+            if ((st = wf_iteration(c, it, it == 0 ? 1 : 0)) != BF_OK) return st;
+            if ((st = wf_trace_launch(c, it)) != BF_OK) return st;
         }
         // the tail kernel finishes whatever is alive, whatever the estimate: the estimate only sizes its grid
         const uint32_t est = std::max<uint32_t>(plan.tail_live + plan.tail_live / 4, 64u * bfd::kBlock);
-        HIP_TRY(tic(2));
-        HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, plan.iters, est, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail, stream));
-        HIP_TRY(toc());
+        if ((st = wf_tail_launch(c, plan.iters, est)) != BF_OK) return st;
         if (!scene->wf_fb_pending) {
             HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live, plan.iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(reinterpret_cast<unsigned long long *>(scene->wf_host) + 1, wf.counters + bfd::CTR_GUARD,
@@ -1135,6 +1330,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
             HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
             scene->wf_fb_pending = true;
             scene->wf_fb_iters = plan.iters;
+            scene->roll.fb_call_iters = 0;
         }
         return finish(plan.iters, plan.iters);
     }
@@ -1152,17 +1348,10 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
 
     // ---- synchronous render (first render of a shape, or per-kernel statistics requested) ----------
     for (uint32_t it = 0; it < bfd::kWfMaxIter; ++it) {
-        const int nxt = (it & 1) ^ 1;
-        HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, mask_bytes, stream));    // alive, trace, shadow are contiguous
-        HIP_TRY(tic(1));
-        HIP_TRY(bfk_wf_shade(&scene->d, &lp, &wf, it, it == 0 ? 1 : 0, hist_dev, records_dev, grid_shade, lds_shade, stream,
-                             shade_waves));
-        HIP_TRY(toc());
+        if ((st = wf_iteration(c, it, it == 0 ? 1 : 0)) != BF_OK) return st;
         HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_live + it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(scene->wf_event, stream));
-        HIP_TRY(tic(0));
-        HIP_TRY(bfk_wf_trace(&scene->d, &wf, it, count_nodes ? 1 : 0, grid_trace, stream, trace_waves));
-        HIP_TRY(toc());
+        if ((st = wf_trace_launch(c, it)) != BF_OK) return st;
         HIP_TRY(hipEventSynchronize(scene->wf_event));
         uint32_t n_live = hq[0];
         if (n_live == 0) {
@@ -1171,19 +1360,259 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         }
         if (n_live <= tail_max) {
             learn(it + 1, n_live);
-            HIP_TRY(tic(2));
-            HIP_TRY(bfk_launch_tail(&scene->d, &lp, &wf, it + 1, n_live, hist_dev, records_dev, count_nodes ? 1 : 0, lds_tail,
-                                    stream));
-            HIP_TRY(toc());
+            if ((st = wf_tail_launch(c, it + 1, n_live)) != BF_OK) return st;
             return finish(it + 1, it + 1);
         }
     }
     return fail(BF_ERR_UNSUPPORTED, "path depth exceeded the wavefront iteration limit (%u bounces)", bfd::kWfMaxIter);
 }
 
+// ---------------------------------------------------------------------------
+// Rolling sequences (BF_FLAG_ROLLING).  Every render ends in a latency-bound tail of a few long Russian-roulette
+// survivors (126-174 bounces among 2^20 paths) that costs a quarter of a 2^24-path step and three quarters of a 2^20-path
+// one.  Consecutive renders of one handle that only differ in seed / shard offset / output buffer — the steps of a
+// Monte-Carlo accumulation, the pulses of a coherent interval (python_scripts/animated_trans_rad.py:307-384,
+// Receive.ipynb cell 30 run such loops one render() / receive() per frame) — therefore form ONE batched launch whose
+// path supply grows by one render per call: slot i renders global paths i, i + n_slots, ... (render = g / n_paths), a
+// call enqueues a few bounce iterations over the whole pool (first the slots still alive, then a "wake" launch that
+// starts the next path of every idle slot), and the survivors of render k simply ride along with the launches of
+// renders k + 1, k + 2, ... .  One tail runs per sequence: bf_scene_flush (or anything that needs the pool: another kind
+// of render, an endpoint update, a clone).  Every path is the path a stand-alone render would trace (own PCG32 stream).
+// ---------------------------------------------------------------------------
+static bool roll_same_shape(const bf_launch &a, const bf_launch &b) {
+    return a.mode == b.mode && a.color_mode == b.color_mode && a.n_paths == b.n_paths && a.max_depth == b.max_depth &&
+           a.rr_depth == b.rr_depth && a.bins == b.bins && a.bins_y == b.bins_y && a.bin_width == b.bin_width &&
+           a.time_c == b.time_c && a.flags == b.flags && a.phase_bins == b.phase_bins;
+}
+
+static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool sync_timing);
+
+static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, const bfd::DLaunch &lp_in, float *hist_dev,
+                                bf_path_record *records_dev, hipStream_t stream) {
+    bf_scene::Roll &r = scene->roll;
+    bf_status st;
+    if (r.open && (!roll_same_shape(r.shape, *launch) || r.count >= bfd::kRollRing || r.stream != stream)) {
+        if ((st = wf_roll_flush(scene, r.stream, false)) != BF_OK) return st;
+        if (r.stream != stream) {
+            // the flush ran on the old stream: the new sequence's first launches reuse the pool behind it
+            HIP_TRY(hipEventRecord(scene->wf_event, r.stream));
+            HIP_TRY(hipStreamWaitEvent(stream, scene->wf_event, 0));
+        }
+    }
+    const bool opening = !r.open;
+    if (opening) {
+        r.shape = *launch;
+        r.lp = lp_in;
+        r.lp.batch = 1u;
+        r.lp.batch_paths = lp_in.n_paths;
+        r.count = 0;
+        r.it = 0;
+        r.stream = stream;
+        r.count_nodes = (launch->flags & BF_FLAG_STATS) != 0;
+        r.timed = (launch->flags & BF_FLAG_TIMING) != 0;
+        // LDS window: the newest renders' histogram blocks, as many as fit
+        r.window = 1;
+        if (lp_in.lds_hist) r.window = std::max<uint32_t>(1u, std::min<uint32_t>(bfd::kRollWindow, (uint32_t) bfd::kMaxLdsHist / std::max(1u, lp_in.n_chan)));
+        HIP_TRY(hipMemsetAsync(scene->counters, 0, sizeof(unsigned long long) * bfd::CTR_GUARD, stream));
+        scene->wf_ev_kind.clear();
+        scene->wf_iters = scene->wf_trace_launches = 0;
+    }
+    const uint32_t k = r.count;
+    bfd::DLaunch &lp = r.lp;
+    lp.n_paths = (uint64_t) (k + 1u) * lp.batch_paths;
+    lp.roll_newest = k;
+    lp.roll_lo = k + 1u > r.window ? k + 1u - r.window : 0u;
+    lp.n_chan_all = (lp.roll_newest - lp.roll_lo + 1u) * lp.n_chan;
+    WfCtx c;
+    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c)) != BF_OK) return st;
+    lp.roll = scene->roll_ring;           // wf_setup may have (re)allocated the pool and the ring with it
+    {
+        bfd::DRoll d;
+        d.seed = launch->seed;
+        d.path_offset = launch->path_offset;
+        d.hist = hist_dev;
+        d.records = records_dev;
+        HIP_TRY(bfk_roll_set(scene->roll_ring, k & (bfd::kRollRing - 1u), &d, stream));
+    }
+    // ---- how many bounce iterations this call enqueues ------------------------------------------------
+    // The pool has one slot per path of a render, and a call adds one path per slot to the supply, so the calls keep up
+    // if a slot finishes one path per call on average.  Too few iterations and the backlog of started-late paths grows
+    // until the flush; too many and the late ones run over a nearly empty pool.  Steered by the live counts that come
+    // back (without ever waiting for them): aim at 1/8 .. 1/2 of the pool still busy when a call's launches end.
+    const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
+    (void) hipGetLastError();
+    if (fb_ready) {
+        scene->wf_fb_pending = false;
+        const uint32_t n = r.fb_call_iters;
+        if (n && !r.fb_is_flush && !scene->tun.roll_iters) {
+            const uint32_t live_end = scene->wf_feedback[n - 1];
+            if (live_end > scene->wf.n_slots / 2 && r.iters < 16) ++r.iters;
+            else if (live_end < scene->wf.n_slots / 8 && r.iters > 1) --r.iters;
+        }
+        r.fb_call_iters = 0;
+    }
+    if (scene->tun.roll_iters) r.iters = scene->tun.roll_iters;
+    if (r.iters == 0) r.iters = 2;
+    if (r.it + 2u * 64u > bfd::kWfMaxIter) r.it &= 1u;       // the live-counter ring: keep the parity, restart the index
+    const uint32_t it0 = r.it, I = r.iters;
+    HIP_TRY(hipMemsetAsync(scene->wf.n_live + it0, 0, I * sizeof(uint32_t), stream));
+    for (uint32_t j = 0; j < I; ++j) {
+        const uint32_t it = r.it;
+        if ((st = wf_iteration(c, it, j == 0 ? (opening ? 1 : 2) : 0)) != BF_OK) return st;
+        if ((st = wf_trace_launch(c, it)) != BF_OK) return st;
+        ++r.it;
+    }
+    scene->wf_iters += I;
+    scene->wf_trace_launches += I;
+    if (!scene->wf_fb_pending) {
+        HIP_TRY(hipMemcpyAsync(scene->wf_feedback, scene->wf.n_live + it0, I * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
+        scene->wf_fb_pending = true;
+        r.fb_call_iters = I;
+        r.fb_is_flush = false;
+    }
+    r.open = true;
+    ++r.count;
+    return BF_OK;
+}
+
+// Finish every path of the open sequence: bounce iterations until few slots are alive, then ONE tail launch.  The first
+// flush of a sequence shape runs synchronously (the host reads the live count per iteration, as the first render of a
+// shape does) and learns how many iterations that takes; later ones enqueue that many without a host round trip — the
+// tail finishes whatever is alive, the estimate only sizes its grid.
+static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool sync_timing) {
+    bf_scene::Roll &r = scene->roll;
+    if (!r.open) return BF_OK;
+    bf_status st;
+    if (stream != r.stream) {
+        HIP_TRY(hipEventRecord(scene->wf_event, r.stream));
+        HIP_TRY(hipStreamWaitEvent(stream, scene->wf_event, 0));
+    }
+    bfd::DLaunch &lp = r.lp;
+    WfCtx c;
+    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c)) != BF_OK) return st;
+    bfd::WF &wf = scene->wf;
+    volatile uint32_t *hq = scene->wf_host;
+    const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
+    (void) hipGetLastError();
+    if (fb_ready) {
+        scene->wf_fb_pending = false;
+        if (r.fb_is_flush && r.fb_call_iters) {
+            // live counts of the last planned flush: first iteration after which the tail threshold was met
+            const uint32_t *nl = scene->wf_feedback, n = r.fb_call_iters;
+            uint32_t k = 0;
+            while (k < n && nl[k] > c.tail_max) ++k;
+            if (k < n) {
+                r.flush_iters = k + 1;
+                r.flush_live = nl[k];
+            } else {
+                r.flush_iters = std::min<uint32_t>(n + 2, 48u);
+                r.flush_live = nl[n - 1];
+            }
+        }
+        r.fb_call_iters = 0;
+    }
+    if (r.it + 2u * 64u > bfd::kWfMaxIter) r.it &= 1u;
+    const uint32_t it0 = r.it;
+    HIP_TRY(hipMemsetAsync(wf.n_live + it0, 0, 64 * sizeof(uint32_t), stream));
+    uint32_t done_iters = 0;
+    if (scene->tun.allow_plan && r.flush_iters > 0) {
+        for (uint32_t j = 0; j < r.flush_iters; ++j) {
+            if ((st = wf_iteration(c, r.it, 0)) != BF_OK) return st;
+            if ((st = wf_trace_launch(c, r.it)) != BF_OK) return st;
+            ++r.it;
+            ++done_iters;
+        }
+        const uint32_t est = std::max<uint32_t>(r.flush_live + r.flush_live / 4, 64u * bfd::kBlock);
+        if ((st = wf_tail_launch(c, r.it, est)) != BF_OK) return st;
+        if (!scene->wf_fb_pending && done_iters) {
+            HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live + it0, done_iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
+            scene->wf_fb_pending = true;
+            r.fb_call_iters = done_iters;
+            r.fb_is_flush = true;
+        }
+    } else {
+        uint32_t n_live = 0;
+        for (uint32_t j = 0; j < 48u; ++j) {
+            if ((st = wf_iteration(c, r.it, 0)) != BF_OK) return st;
+            HIP_TRY(hipMemcpyAsync((void *) &hq[0], wf.n_live + r.it, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(scene->wf_event, stream));
+            if ((st = wf_trace_launch(c, r.it)) != BF_OK) return st;
+            HIP_TRY(hipEventSynchronize(scene->wf_event));
+            ++r.it;
+            ++done_iters;
+            n_live = hq[0];
+            if (n_live <= c.tail_max) break;
+        }
+        r.flush_iters = done_iters;
+        r.flush_live = n_live;
+        if (n_live) {
+            if ((st = wf_tail_launch(c, r.it, n_live)) != BF_OK) return st;
+        }
+    }
+    scene->wf_iters += done_iters;
+    scene->wf_trace_launches += done_iters;
+    r.open = false;
+    if (sync_timing) return wf_collect_timing(scene, stream);
+    return BF_OK;
+}
+
+// counters -> bf_stats (+ the per-kernel times of the last timed render / sequence)
+static void fill_stats(const bf_scene *scene, const unsigned long long *c, uint64_t n_paths, bf_stats *st) {
+    std::memset(st, 0, sizeof(*st));
+    st->n_paths = n_paths;
+    st->n_rays_closest = c[bfd::CTR_CLOSEST];
+    st->n_rays_shadow = c[bfd::CTR_SHADOW];
+    st->n_nodes_visited = c[bfd::CTR_NODES];
+    st->n_nodes_lds = c[bfd::CTR_NODES_LDS];
+    st->n_tris_tested = c[bfd::CTR_TRIS];
+    st->n_invalid = c[bfd::CTR_INVALID];
+    st->n_bounces = c[bfd::CTR_BOUNCES];
+    st->n_rays_tail = c[bfd::CTR_TAIL_RAYS];
+    st->n_rays_traced = c[bfd::CTR_TRACED];
+    st->n_nodes_tail = c[bfd::CTR_TAIL_NODES];
+    st->n_wnodes_tail = c[bfd::CTR_TAIL_WNODES];
+    st->n_tris_tail = c[bfd::CTR_TAIL_TRIS];
+    st->n_bounces_tail = c[bfd::CTR_TAIL_BOUNCES];
+    st->n_shade_loads = c[bfd::CTR_SHADE_LOADS];
+    st->n_shade_stores = c[bfd::CTR_SHADE_STORES];
+    st->n_shade_shadow = c[bfd::CTR_SHADE_SHADOW];
+    st->n_shade_rays = c[bfd::CTR_SHADE_RAYS];
+    st->n_guard = c[bfd::CTR_GUARD];
+    st->trace_ms = scene->wf_ms[0];
+    st->shade_ms = scene->wf_ms[1];
+    st->tail_ms = scene->wf_ms[2];
+    st->n_launches_trace = scene->wf_trace_launches;
+    st->n_bounce_iters = scene->wf_iters;
+    st->n_launches_tail = scene->wf_tail_launches;
+}
+
+// Stream order between the successive uses of a handle's pool: work enqueued on another stream than the previous
+// call's waits for it (an event wait on the device, never on the host).
+static bf_status order_after_last(const bf_scene *scene, hipStream_t stream) {
+    if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->last_done, 0));
+    return BF_OK;
+}
+static bf_status mark_last(const bf_scene *scene, hipStream_t stream) {
+    if (!scene->last_done) HIP_TRY(hipEventCreateWithFlags(&scene->last_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(scene->last_done, stream));
+    scene->last_stream = stream;
+    scene->has_last = true;
+    return BF_OK;
+}
+// anything but another render of the open rolling sequence needs the pool (or the scene tables) to itself
+static bf_status close_sequence(const bf_scene *scene, hipStream_t stream) {
+    if (!scene->roll.open) return BF_OK;
+    bf_status st = wf_roll_flush(scene, stream, false);
+    if (st != BF_OK) return st;
+    return mark_last(scene, stream);
+}
+
 static bf_status render_common(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_dev,
                                bf_path_record *records_dev, void *stream_, bf_stats *stats_out) {
     if (!scene || !launch || !hist_dev) return fail(BF_ERR_INVALID, "null argument");
+    BF_ENTER(scene);
     const uint32_t n_renders = batch ? batch->n_renders : 1u;
     if (batch) {
         if (n_renders == 0) return fail(BF_ERR_INVALID, "bf_render_batch: n_renders is 0");
@@ -1238,6 +1667,19 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
                         (unsigned long long) (launch->path_offset + launch->n_paths), (unsigned long long) (px * launch->spp));
     }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const bool rolling = (launch->flags & BF_FLAG_ROLLING) != 0u && launch->n_paths != 0u && launch->n_paths <= scene->tun.pool;
+    if (launch->flags & BF_FLAG_ROLLING) {
+        if (batch || multi_pixel || (launch->flags & BF_FLAG_MEGAKERNEL))
+            return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_ROLLING: batched launches, multi-pixel films and the one-kernel variant do not roll");
+        if (stats_out)
+            return fail(BF_ERR_INVALID, "BF_FLAG_ROLLING: a rolling render returns before its paths have ended, so it has no statistics "
+                                        "of its own (pass stats_out = NULL; bf_scene_flush reports the sequence's)");
+    }
+    {
+        bf_status ost = order_after_last(scene, stream);
+        if (ost != BF_OK) return ost;
+        if (!rolling && (ost = close_sequence(scene, stream)) != BF_OK) return ost;
+    }
     bfd::DLaunch lp;
     std::memset(&lp, 0, sizeof(lp));
     lp.film_w = multi_pixel ? launch->film_width : 1u;
@@ -1309,7 +1751,14 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     unsigned blocks_per_cu = (unsigned) std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
     unsigned grid = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t) scene->n_cus * blocks_per_cu));
 
-    HIP_TRY(hipMemsetAsync(scene->counters, 0, sizeof(unsigned long long) * bfd::CTR_COUNT, stream));
+    if (rolling) {
+        // more paths than the pool has slots would need several paths per slot and render: not a rolling shape (above)
+        bf_status rst = wf_roll_render(scene, launch, lp, hist_dev, records_dev, stream);
+        if (rst != BF_OK) return rst;
+        return mark_last(scene, stream);
+    }
+    // every counter but the sticky guard word (the last one)
+    HIP_TRY(hipMemsetAsync(scene->counters, 0, sizeof(unsigned long long) * bfd::CTR_GUARD, stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats_out) {
         HIP_TRY(hipEventCreate(&ev0));
@@ -1331,46 +1780,26 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
         HIP_TRY(hipEventSynchronize(ev1));
         unsigned long long c[bfd::CTR_COUNT];
         HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
-        std::memset(stats_out, 0, sizeof(*stats_out));
-        stats_out->n_paths = lp.n_paths;
-        stats_out->n_rays_closest = c[bfd::CTR_CLOSEST];
-        stats_out->n_rays_shadow = c[bfd::CTR_SHADOW];
-        stats_out->n_nodes_visited = c[bfd::CTR_NODES];
-        stats_out->n_nodes_lds = c[bfd::CTR_NODES_LDS];
-        stats_out->n_tris_tested = c[bfd::CTR_TRIS];
-        stats_out->n_invalid = c[bfd::CTR_INVALID];
-        stats_out->n_bounces = c[bfd::CTR_BOUNCES];
-        stats_out->n_rays_tail = c[bfd::CTR_TAIL_RAYS];
-        stats_out->n_rays_traced = c[bfd::CTR_TRACED];
-        stats_out->n_nodes_tail = c[bfd::CTR_TAIL_NODES];
-        stats_out->n_wnodes_tail = c[bfd::CTR_TAIL_WNODES];
-        stats_out->n_tris_tail = c[bfd::CTR_TAIL_TRIS];
-        stats_out->n_bounces_tail = c[bfd::CTR_TAIL_BOUNCES];
-        stats_out->n_shade_loads = c[bfd::CTR_SHADE_LOADS];
-        stats_out->n_shade_stores = c[bfd::CTR_SHADE_STORES];
-        stats_out->n_shade_shadow = c[bfd::CTR_SHADE_SHADOW];
-        stats_out->n_shade_rays = c[bfd::CTR_SHADE_RAYS];
-        stats_out->n_guard = c[bfd::CTR_GUARD];
+        if ((launch->flags & BF_FLAG_MEGAKERNEL) || !launch->n_paths) {
+            scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
+            scene->wf_trace_launches = scene->wf_iters = scene->wf_tail_launches = 0;
+        }
+        fill_stats(scene, c, lp.n_paths, stats_out);
+        float ms = 0.f;
+        hipError_t he = hipEventElapsedTime(&ms, ev0, ev1);
+        (void) hipEventDestroy(ev0);
+        (void) hipEventDestroy(ev1);
+        if (he != hipSuccess) return fail(BF_ERR_DEVICE, "hipEventElapsedTime: %s", hipGetErrorString(he));
+        stats_out->kernel_ms = ms;
         if (c[bfd::CTR_GUARD]) {
-            (void) hipEventDestroy(ev0);
-            (void) hipEventDestroy(ev1);
+            // reported here: clear the sticky word and the copy of it that may be in flight to the next planned render
+            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
+            scene->wf_fb_pending = false;
             return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays: the histogram is wrong (a traversal bug; please "
                                        "report the scene)", c[bfd::CTR_GUARD]);
         }
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        stats_out->kernel_ms = ms;
-        if (!(launch->flags & BF_FLAG_MEGAKERNEL) && launch->n_paths) {
-            stats_out->trace_ms = scene->wf_ms[0];
-            stats_out->shade_ms = scene->wf_ms[1];
-            stats_out->tail_ms = scene->wf_ms[2];
-            stats_out->n_launches_trace = scene->wf_trace_launches;
-            stats_out->n_bounce_iters = scene->wf_iters;
-        }
-        (void) hipEventDestroy(ev0);
-        (void) hipEventDestroy(ev1);
     }
-    return BF_OK;
+    return mark_last(scene, stream);
 }
 
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch, float *hist_dev, bf_path_record *records_dev,
@@ -1382,6 +1811,71 @@ bf_status bf_render_batch_device(const bf_scene *scene, const bf_launch *launch,
                                  bf_path_record *records_dev, void *stream, bf_stats *stats_out) {
     if (!batch) return fail(BF_ERR_INVALID, "bf_render_batch_device: null batch");
     return render_common(scene, launch, batch, hist_dev, records_dev, stream, stats_out);
+}
+
+bf_status bf_scene_flush(bf_scene *scene, void *stream_, bf_stats *stats_out) {
+    if (!scene) return fail(BF_ERR_INVALID, "null argument");
+    BF_ENTER(scene);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const bool was_open = scene->roll.open;
+    const uint64_t n_paths = was_open ? scene->roll.lp.n_paths : 0;
+    bf_status st = order_after_last(scene, stream);
+    if (st != BF_OK) return st;
+    if (was_open) {
+        if ((st = wf_roll_flush(scene, stream, stats_out != nullptr)) != BF_OK) return st;
+        if ((st = mark_last(scene, stream)) != BF_OK) return st;
+    }
+    if (stats_out) {
+        std::memset(stats_out, 0, sizeof(*stats_out));
+        if (!was_open) return BF_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long c[bfd::CTR_COUNT];
+        HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
+        fill_stats(scene, c, n_paths, stats_out);
+        stats_out->kernel_ms = scene->wf_ms[0] + scene->wf_ms[1] + scene->wf_ms[2];
+        if (c[bfd::CTR_GUARD]) {
+            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
+            scene->wf_fb_pending = false;
+            return wf_guard_error(c[bfd::CTR_GUARD]);
+        }
+    }
+    return BF_OK;
+}
+
+bf_status bf_scene_sync(bf_scene *scene) {
+    if (!scene) return fail(BF_ERR_INVALID, "null argument");
+    BF_ENTER(scene);
+    bf_status st = close_sequence(scene, scene->roll.stream);
+    if (st != BF_OK) return st;
+    if (scene->has_last) HIP_TRY(hipEventSynchronize(scene->last_done));
+    scene->wf_fb_pending = false;         // whatever feedback was in flight has landed; the next render re-learns from its own
+    scene->roll.fb_call_iters = 0;
+    unsigned long long lost = 0;
+    HIP_TRY(hipMemcpy(&lost, scene->counters + bfd::CTR_GUARD, sizeof(lost), hipMemcpyDeviceToHost));
+    if (lost) {
+        HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
+        return wf_guard_error(lost);
+    }
+    return BF_OK;
+}
+
+/* test hook (not part of the ABI): pre-load the sticky guard word, as if wf_trace had dropped `n` rays */
+bf_status bfdbg_preload_guard(bf_scene *scene, unsigned long long n) {
+    if (!scene) return fail(BF_ERR_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(scene->counters + bfd::CTR_GUARD, &n, sizeof(n), hipMemcpyHostToDevice));
+    return BF_OK;
+}
+
+/* test hook: take (1) / release (0) the handle's busy flag, as a call of another host thread would hold it */
+bf_status bfdbg_hold_busy(bf_scene *scene, int on) {
+    if (!scene) return fail(BF_ERR_INVALID, "null argument");
+    if (on) {
+        if (scene->busy.test_and_set(std::memory_order_acquire)) return fail(BF_ERR_INVALID, "bfdbg_hold_busy: already held");
+    } else {
+        scene->busy.clear(std::memory_order_release);
+    }
+    return BF_OK;
 }
 
 static bf_status render_host(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_out,

@@ -101,6 +101,18 @@ struct DScene {
     const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
 };
 
+// One render of a ROLLING SEQUENCE (bf_render_device with BF_FLAG_ROLLING): what differs between the renders of a
+// sequence.  The sequence is one batched launch whose path supply grows by one render per call: global path index
+// g = render * batch_paths + local path, slot i renders g = i, i + n_slots, ... for as long as the supply lasts, so the
+// long paths of one render are carried by the launches of the next ones instead of a tail kernel per render.
+struct DRoll {
+    uint64_t seed, path_offset;
+    float *hist;                // this render's histogram (device)
+    bf_path_record *records;    // this render's per-path records (device) or nullptr
+};
+constexpr uint32_t kRollRing = 256;    // renders per sequence (descriptor ring; the host flushes a longer one in between)
+constexpr uint32_t kRollWindow = 4;    // newest renders whose histogram blocks a workgroup privatises in LDS; older ones take global atomics
+
 struct DLaunch {
     uint32_t mode, color_mode;
     uint64_t n_paths, path_offset, seed;
@@ -124,6 +136,10 @@ struct DLaunch {
     uint32_t mix;                   // BF_FLAG_MIX_RESAMPLE (receive modes): the ADC's frequency axis is the beat frequency
     uint32_t doppler;               // BF_FLAG_DOPPLER (receive modes): Shape::doppler shifts the path's wavelength
     float box_slack;                // offsets only: node boxes widened by this much on the ray's side (bf_device_core.h: RayBox)
+    // Rolling sequence (batch = 1, batch_paths = paths per render, n_paths = supply so far): descriptor ring [kRollRing]
+    const DRoll *roll;              // nullptr: not a rolling launch
+    uint32_t roll_newest;           // render index of the call this launch belongs to
+    uint32_t roll_lo;               // oldest render whose histogram block is in the LDS window [roll_lo, roll_newest]
 };
 
 // device counters (uint64 each)

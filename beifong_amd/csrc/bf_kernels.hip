@@ -551,42 +551,29 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
 }
 
 // wavefront tail: finish the `n_slots` paths of queue `it` in one launch
+//   tail_waves : 3 waves per SIMD (168 VGPRs, some scratch) unless 2 asks for the scratch-free build: alone on the GPU a
+//                small pool's tail is 2-3 % faster with 2, but with several renders in flight 3 leave room for the
+//                neighbours (C3 0.74 -> 0.69 ms per render, C4 shard 0.96 -> 0.88; profiles/r02_retune_hw_queues.txt)
+//   spread     : spread the survivors thinly while the chip has room: a wave that starts with ~16 paths instead of 64
+//                runs them four lanes per ray (traverse_quad) from its first bounce and waits for the longest of 16
+//   block_cap  : at most this many workgroups (0: no cap)
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, int tail_waves, unsigned spread, unsigned block_cap) {
     // one lane per live slot (gathered from the alive masks), at most one thread per pool slot
     // (any grid finishes the job: waves loop over their segment of the alive masks; the cap keeps the
     // launch within the scene's traversal-spill columns)
     unsigned grid = (std::min(n_slots, wf->n_slots) + bfd::kBlock - 1) / bfd::kBlock;
     {
-        // spread the survivors thinly while the chip has room: a wave that starts with ~16 paths instead of 64 runs
-        // them four lanes per ray (traverse_quad) from its first bounce and waits for the longest of 16, not of 64
-        static const unsigned spread = [] {
-            const char *e = getenv("BF_TAIL_SPREAD");
-            return e ? (unsigned) std::max(1, atoi(e)) : 1u;
-        }();
         const unsigned resident = (sc->spill_stride / bfd::kBlock) * 3u / bfd::kTraceBlocksPerCU;
         if (spread > 1 && grid < resident) grid = std::min(grid * spread, resident);
     }
     grid = std::min(grid, sc->spill_stride / bfd::kBlock);
-    {
-        static const unsigned cap = [] {
-            const char *e = getenv("BF_TAIL_BLOCKS");
-            return e ? (unsigned) atoi(e) : 0u;
-        }();
-        if (cap) grid = std::min(grid, cap);
-    }
+    if (block_cap) grid = std::min(grid, block_cap);
     if (grid == 0) return hipSuccess;
     const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
     unsigned long long *counters = wf->counters;
-    static const int tw_env = [] {
-        const char *e = getenv("BF_TAIL_WAVES");
-        return e ? atoi(e) : 0;
-    }();
-    // 3 waves per SIMD (168 VGPRs, some scratch) unless BF_TAIL_WAVES=2 asks for the 2-wave build (no scratch): alone on the
-    // GPU a small pool's tail is 2-3 % faster with 2, but with several renders in flight 3 leave room for the neighbours
-    // (C3 0.74 -> 0.69 ms per render, C4 shard 0.96 -> 0.88; profiles/r02_retune_hw_queues.txt)
-    const bool two = tw_env == 2;
+    const bool two = tail_waves == 2;
 #define BF_TAIL_LAUNCH(S, P)                                                                                                           \
     if (two)                                                                                                                           \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 2>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
@@ -602,6 +589,17 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
         else { BF_TAIL_LAUNCH(false, false); }
     }
 #undef BF_TAIL_LAUNCH
+    return hipGetLastError();
+}
+
+namespace bfd {
+// one descriptor of a rolling sequence's ring (kernel arguments are captured at launch: no staging buffer to keep alive)
+__global__ void bf_roll_set_kernel(DRoll *ring, uint32_t idx, DRoll d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ring[idx] = d;
+}
+}  // namespace bfd
+extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, uint32_t idx, const bfd::DRoll *d, hipStream_t stream) {
+    hipLaunchKernelGGL(bfd::bf_roll_set_kernel, dim3(1), dim3(64), 0, stream, ring, idx, *d);
     return hipGetLastError();
 }
 

@@ -393,15 +393,21 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
     const bool receive = mode_receive<RX>(lp);
     s.path_i = path_i;
     s.render = 0u;
-    uint64_t seed = lp.seed;
+    uint64_t seed = lp.seed, path_offset = lp.path_offset;
     if (lp.batch != 0u) {
         // batched launch: global index -> (render, local path); every render is an ordinary render of its own seed
         s.render = (uint32_t) (path_i / lp.batch_paths);
         path_i -= (uint64_t) s.render * lp.batch_paths;
-        if (lp.batch_seeds) seed = lp.batch_seeds[s.render];
+        if (lp.roll) {                      // rolling sequence: the render's own seed and shard offset
+            const DRoll &rr = lp.roll[s.render & (kRollRing - 1u)];
+            seed = rr.seed;
+            path_offset = rr.path_offset;
+        } else if (lp.batch_seeds) {
+            seed = lp.batch_seeds[s.render];
+        }
     }
     // per-path stream: sampler->seed(base_seed + path) (sampler.cpp:83-96)
-    pcg_seed(s.rng, seed + lp.path_offset + path_i);
+    pcg_seed(s.rng, seed + path_offset + path_i);
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
     float ax = .5f, ay = .5f;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
@@ -696,6 +702,27 @@ BF_DEV void hist_add(float *s_hist, float *g_hist, bool lds, uint32_t idx, float
     else
         atomicAdd(&g_hist[idx], v);     // global_atomic_add_f32
 }
+// Where the samples of render `render` go: plain launch = the histogram; batched launch = block `render` of it (LDS and
+// global alike); rolling sequence = the render's own histogram (DRoll::hist), privatised in LDS only for the newest
+// kRollWindow renders (the few stragglers of older renders take global atomics).
+struct HistDst {
+    float *s, *g;
+    bool lds;
+};
+BF_DEV HistDst hist_dst(const DLaunch &lp, uint32_t render, float *s_hist, float *g_hist, bool lds_hist) {
+    HistDst h;
+    if (lp.roll) {
+        h.g = lp.roll[render & (kRollRing - 1u)].hist;
+        h.lds = lds_hist && render >= lp.roll_lo;
+        h.s = s_hist + (h.lds ? (render - lp.roll_lo) * lp.n_chan : 0u);
+    } else {
+        const uint32_t hb = lp.batch != 0u ? render * lp.n_chan : 0u;
+        h.g = g_hist + hb;
+        h.s = s_hist + hb;
+        h.lds = lds_hist;
+    }
+    return h;
+}
 
 struct FilmAcc {
     float X, Y, Z, A, W;    // base channels of the 1x1 film (render modes)
@@ -707,7 +734,10 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                      FilmAcc &acc, bf_path_record *records) {
     const bool valid = (s.flags & kFlagValid) != 0;
     float rec_L, rec_aux;
-    const uint32_t hb = lp.batch != 0u ? s.render * lp.n_chan : 0u;      // this render's block of the histogram
+    const HistDst hd = hist_dst(lp, s.render, s_hist, g_hist, lds_hist);      // this render's block of the histogram
+    s_hist = hd.s;
+    g_hist = hd.g;
+    lds_hist = hd.lds;
     if (mode_receive<RX>(lp)) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
@@ -746,7 +776,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
         ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
         if (ok) {
-            uint32_t off = hb + (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
+            uint32_t off = (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
             if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 0u, a0);
             if (a1 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 1u, a1);
             hist_add(s_hist, g_hist, lds_hist, off + 2u, 1.f);
@@ -777,7 +807,10 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         if (is_range || is_time) ok = ok && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
         // multi-pixel film: every channel of the sample goes to its pixel's block of the histogram; the 1 x 1 film
         // keeps the five base channels in registers until film_flush
-        uint32_t pix = hb;
+        uint32_t pix = 0u;
+        // the five base channels of a 1 x 1 film are summed in registers while every lane of the wave feeds the same
+        // histogram: a plain launch, or the newest render of a rolling sequence
+        const bool use_acc = lp.batch == 0u || (lp.roll != nullptr && s.render == lp.roll_newest);
         if (lp.spp) {
             const uint64_t q = (lp.path_offset + s.path_i) / lp.spp;
             const uint32_t px = (uint32_t) (q % lp.film_w) - ((s.flags & kFlagFilmLeft) ? 1u : 0u);
@@ -791,21 +824,21 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 2u, Z);
                 if (valid) hist_add(s_hist, g_hist, lds_hist, pix + 3u, 1.f);
                 hist_add(s_hist, g_hist, lds_hist, pix + 4u, 1.f);
-            } else if (lp.batch != 0u) {
+            } else if (!use_acc) {
                 // batched launch: the wave's lanes hold paths of different renders, so the base channels cannot be
                 // summed in registers; each sample goes to its render's block
-                if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 0u, X);
-                if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 1u, Y);
-                if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, hb + 2u, Z);
-                if (valid) hist_add(s_hist, g_hist, lds_hist, hb + 3u, 1.f);
-                hist_add(s_hist, g_hist, lds_hist, hb + 4u, 1.f);
+                if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, 0u, X);
+                if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, 1u, Y);
+                if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, 2u, Z);
+                if (valid) hist_add(s_hist, g_hist, lds_hist, 3u, 1.f);
+                hist_add(s_hist, g_hist, lds_hist, 4u, 1.f);
             } else {
                 acc.X += X;
                 acc.Y += Y;
                 acc.Z += Z;
                 acc.A += valid ? 1.f : 0.f;
+                acc.W += 1.f;
             }
-            acc.W += 1.f;
             if (is_range || is_time) {
                 // range.cpp:141-161 / time.cpp:134-153: bin i takes the sample iff
                 // (float)i*w <= aux < (float)i*w + w, evaluated exactly as written
@@ -832,13 +865,18 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         rec_L = L;
         rec_aux = s.aux;
     }
+    uint64_t rec_i = s.path_i;
+    if (lp.roll) {              // rolling sequence: the render's own record array, indexed by the local path
+        records = lp.roll[s.render & (kRollRing - 1u)].records;
+        rec_i -= (uint64_t) s.render * lp.batch_paths;
+    }
     if (records) {
         bf_path_record r;
         r.L = rec_L;
         r.aux = rec_aux;
         r.valid = valid ? 1u : 0u;
         r.n_rays = s.n_rays;
-        records[s.path_i] = r;
+        records[rec_i] = r;
     }
 }
 
@@ -855,19 +893,32 @@ template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, fl
             acc.A += __shfl_down(acc.A, off);
             acc.W += __shfl_down(acc.W, off);
         }
-        if (lane == 0 && acc.W != 0.f && !lp.spp && lp.batch == 0u) {
-            hist_add(s_hist, g_hist, lds_hist, 0, acc.X);
-            hist_add(s_hist, g_hist, lds_hist, 1, acc.Y);
-            hist_add(s_hist, g_hist, lds_hist, 2, acc.Z);
-            hist_add(s_hist, g_hist, lds_hist, 3, acc.A);
-            hist_add(s_hist, g_hist, lds_hist, 4, acc.W);
+        if (lane == 0 && acc.W != 0.f && !lp.spp && (lp.batch == 0u || lp.roll != nullptr)) {
+            const HistDst hd = hist_dst(lp, lp.roll ? lp.roll_newest : 0u, s_hist, g_hist, lds_hist);
+            hist_add(hd.s, hd.g, hd.lds, 0, acc.X);
+            hist_add(hd.s, hd.g, hd.lds, 1, acc.Y);
+            hist_add(hd.s, hd.g, hd.lds, 2, acc.Z);
+            hist_add(hd.s, hd.g, hd.lds, 3, acc.A);
+            hist_add(hd.s, hd.g, hd.lds, 4, acc.W);
         }
     }
     if (lds_hist) {
         __syncthreads();
-        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) {
-            float v = s_hist[i];
-            if (v != 0.f) atomicAdd(&g_hist[i], v);
+        if (lp.roll) {
+            // one block per render of the LDS window, each flushed into that render's own histogram
+            for (uint32_t r = lp.roll_lo; r <= lp.roll_newest; ++r) {
+                float *gh = lp.roll[r & (kRollRing - 1u)].hist;
+                const float *sh = s_hist + (r - lp.roll_lo) * lp.n_chan;
+                for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
+                    float v = sh[i];
+                    if (v != 0.f) atomicAdd(&gh[i], v);
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) {
+                float v = s_hist[i];
+                if (v != 0.f) atomicAdd(&g_hist[i], v);
+            }
         }
     }
 }

@@ -29,10 +29,15 @@ namespace bfd {
 // aligned rounds (every lane holds slot batch*64 + lane) store the ballot
 // directly; gathered rounds use atomicOr on the (pre-zeroed) words — spread over
 // many addresses, non-returning.
-BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, uint32_t batch0, uint32_t slot, bool valid_lane, bool bit) {
+BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, bool merge, uint32_t batch0, uint32_t slot, bool valid_lane, bool bit) {
     if (aligned) {
         unsigned long long w = __ballot(bit);
-        if ((threadIdx.x & 63) == 0 && w) m_out[batch0] = w;
+        if ((threadIdx.x & 63) == 0 && w) {
+            if (merge)
+                atomicOr(&m_out[batch0], w);      // wake launch: wf_shade<0> of the same iteration wrote this word before
+            else
+                m_out[batch0] = w;
+        }
     } else if (valid_lane && bit) {
         atomicOr(&m_out[slot >> 6], 1ull << (slot & 63u));
     }
@@ -77,7 +82,13 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
 }
 
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
-//   FIRST = true : bounce 0, every slot < n_slots starts its first path.
+//   FIRST = 0 : walk the alive masks of the current parity.
+//   FIRST = 1 : bounce 0 of a render (or of a rolling sequence): every slot < n_slots starts its first path.
+//   FIRST = 2 : "wake" launch of a rolling sequence (bf_render_device with BF_FLAG_ROLLING): the path supply has just
+//               grown by one render, so every slot that is NOT alive — it ran out of paths during an earlier call —
+//               starts its next path (the one after the last it finished: wf.sd keeps that index for dead slots).
+//               The slots that ARE alive belong to wf_shade<0> of the same iteration; both publish into the same
+//               next-parity masks.
 #ifdef BF_SHADE_PROF
 // developer build (tools/shade_profile.py): cycles of the wave between consecutive stamps, by section (the stamps sit in
 // wave-uniform control flow); SLP (bf_path_logic.h) counts wave entries and lanes per section
@@ -90,7 +101,7 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
 #else
 #define SLT(k)
 #endif
-template <bool FIRST, int W, int RX>
+template <int FIRST, int W, int RX>
 __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                       bf_path_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     MaskCursor cur_alive;
     if (!FIRST) cursor_init(cur_alive, wf.m_alive[cur], b0, b1, lane);
     uint32_t first_b = b0;
+    const bool rolling = lp.roll != nullptr;
 
     while (true) {
         // ---- gather up to 64 live slots of the segment into the lanes -----------
@@ -142,8 +154,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             aligned = whole && got == 64 && slot == batch_before * 64u + (uint32_t) lane;
             aligned = __all(aligned);
         }
-        const bool has = (uint32_t) lane < got;
+        bool has = (uint32_t) lane < got;
         const uint32_t batch0 = slot >> 6;
+        if (FIRST == 2) has = ((wf.m_alive[cur][batch0] >> lane) & 1ull) == 0ull;      // wake: only the slots without a live path
 
         PathState s;
         s.render = 0u;                 // lanes without a path still index the batch tables (path_shift)
@@ -161,6 +174,13 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         if (has) {
             if (FIRST) {
                 need_gen = true;
+                // the path BEFORE the one this slot starts now: slot - n_slots for a fresh pool (wraps: + n_slots = slot),
+                // the slot's last finished path in a wake launch
+                s.path_i = (uint64_t) slot - (uint64_t) wf.n_slots;
+                if (FIRST == 2) {
+                    const uint4 d = wf.sd[slot];
+                    s.path_i = ((uint64_t) d.w << 32) | d.z;
+                }
             } else {
                 load_state(wf, slot, receive, s);
                 ++c_loads;
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             if (!settled && need_gen) {
                 need_gen = false;
                 cont = false;
-                uint64_t path_i = (FIRST && round == 0) ? (uint64_t) slot : s.path_i + wf.n_slots;
+                const uint64_t path_i = s.path_i + wf.n_slots;
                 if (path_i < lp.n_paths) {
                     generate_path<RX>(sc, lp, path_i, s);
                     sh.want = false;
@@ -288,13 +308,17 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 wf.sh2[slot] = sh.c;
                 if (receive && lp.iq) wf.sh3[slot] = sh.c_im;
             }
+        } else if (has && rolling) {
+            // the slot has run out of paths for now: remember the last one it rendered, so that the wake launch of the
+            // sequence's next call continues from there (a path that started and ended within this visit was never stored)
+            wf.sd[slot] = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
         }
         cont = has && cont;
         tracing = cont && tracing;
         shadowing = cont && shadowing;
-        publish_masks(m_alive, aligned, batch0, slot, has, cont);
-        publish_masks(m_trace, aligned, batch0, slot, has, tracing);
-        publish_masks(m_shadow, aligned, batch0, slot, has, shadowing);
+        publish_masks(m_alive, aligned, FIRST == 2, batch0, slot, has, cont);
+        publish_masks(m_trace, aligned, FIRST == 2, batch0, slot, has, tracing);
+        publish_masks(m_shadow, aligned, FIRST == 2, batch0, slot, has, shadowing);
         c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
         c_shq += shadowing ? 1u : 0u;
         SLT(6);
@@ -567,14 +591,16 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
     else                                                                                                                         \
         hipLaunchKernelGGL((bfd::wf_shade<F, W, 0>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
                            records)
-    if (first) {
-        BF_SHADE_LAUNCH(true, 3);
+    if (first == 2) {
+        BF_SHADE_LAUNCH(2, 3);
+    } else if (first) {
+        BF_SHADE_LAUNCH(1, 3);
     } else {
         switch (waves) {
-            case 2: BF_SHADE_LAUNCH(false, 2); break;
-            case 3: BF_SHADE_LAUNCH(false, 3); break;
-            case 4: BF_SHADE_LAUNCH(false, 4); break;
-            default: BF_SHADE_LAUNCH(false, 1); break;
+            case 2: BF_SHADE_LAUNCH(0, 2); break;
+            case 3: BF_SHADE_LAUNCH(0, 3); break;
+            case 4: BF_SHADE_LAUNCH(0, 4); break;
+            default: BF_SHADE_LAUNCH(0, 1); break;
         }
     }
 #undef BF_SHADE_LAUNCH

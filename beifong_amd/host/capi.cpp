@@ -22,6 +22,11 @@ static thread_local std::string g_err;
 extern "C" {
 
 const char *bfh_last_error(void) { return g_err.c_str(); }
+/* handshake with the binding (beifong_amd/mitsuba/_host.py checks these at load) */
+int bfh_abi_version(void) { return BF_ABI_VERSION; }
+unsigned long long bfh_abi_fingerprint(void) { return abi_fingerprint_of_host(); }
+unsigned bfh_sizeof_launch(void) { return (unsigned) sizeof(bf_launch); }
+unsigned bfh_sizeof_stats(void) { return (unsigned) sizeof(bf_stats); }
 int bfh_set_variant(const char *v) { BFH_TRY(set_variant(v)) }
 const char *bfh_variant(void) { return variant().c_str(); }
 int bfh_set_log_level(int level) { BFH_TRY(set_log_level((LogLevel) level)) }

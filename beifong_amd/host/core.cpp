@@ -299,6 +299,14 @@ void PluginManager::ensure_plugin_loaded(const std::string &name) {
     auto pn = (StringFunc) dlsym(h, "plugin_name");
     auto pd = (StringFunc) dlsym(h, "plugin_descr");
     if (!pn || !pd) Throw("Could not resolve symbol \"plugin_name\"/\"plugin_descr\" in \"%s\"", path.c_str());
+    // ours, not the reference's: the plugin and this library must have been compiled against the same C-ABI structs
+    using AbiFunc = unsigned long long (*)();
+    auto pa = (AbiFunc) dlsym(h, "plugin_abi");
+    if (!pa || pa() != abi_fingerprint_of_host()) {
+        dlclose(h);
+        Throw("Plugin \"%s\" was built against another version of include/beifong_hip.h / render.h than libbeifong_host.so "
+              "(stale plugins/%s.so): rebuild the host layer (make -C beifong_amd/host)", name.c_str(), name.c_str());
+    }
     m_plugins[name] = Plugin{h, pn(), pd()};
     Log(Debug, "Loaded plugin \"%s\" (%s)", pn(), pd());
 }

@@ -225,12 +225,20 @@ private:
 const std::string &variant();
 void set_variant(const std::string &v);
 
+/// C-ABI layout word of the headers THIS translation unit was compiled against (include/beifong_hip.h:
+/// BF_ABI_FINGERPRINT) mixed with the size of the host classes that embed C-ABI structs.  The PluginManager refuses a
+/// plugin whose word differs from the host library's: a stale plugins/<x>.so would construct objects with another
+/// layout than libbeifong_host.so reads (the segfault of round 2, DESIGN.md "ABI handshake").
+unsigned long long abi_fingerprint_of_host();            // as libbeifong_host.so was compiled
+inline unsigned long long abi_fingerprint_of_this_build();
+
 // every plugin translation unit ends with this (class.h:195-211: the reference's
-// MTS_EXPORT_PLUGIN emits the same two extern "C" symbols)
+// MTS_EXPORT_PLUGIN emits the same two extern "C" symbols; plugin_abi is ours)
 #define BF_EXPORT_PLUGIN(ClassName, ParentName, PluginName, Descr)                                            \
     extern "C" {                                                                                              \
     __attribute__((visibility("default"))) const char *plugin_name() { return PluginName; }                  \
     __attribute__((visibility("default"))) const char *plugin_descr() { return Descr; }                      \
+    __attribute__((visibility("default"))) unsigned long long plugin_abi() { return ::bfh::abi_fingerprint_of_this_build(); } \
     }                                                                                                         \
     static ::bfh::Object *bf_construct_##ClassName(const ::bfh::Properties &p) { return new ClassName(p); }  \
     static ::bfh::Class bf_class_##ClassName(PluginName, ParentName, "", bf_construct_##ClassName);

@@ -477,7 +477,24 @@ const bf_scene_desc *Scene::flat_desc(const Endpoint *endpoint) {
     return &m_flat->desc;
 }
 
+unsigned long long abi_fingerprint_of_host() { return abi_fingerprint_of_this_build(); }
+
+/// libbeifong_hip.so must have been compiled against the header this library was: a core whose bf_stats / bf_launch has
+/// another size would write past Integrator::m_stats (the host-side segfault of round 2: a stale libbeifong_host.so
+/// against a rebuilt core, DESIGN.md "ABI handshake")
+static void check_core_abi() {
+    static const bool ok = [] {
+        if (bf_version() != BF_ABI_VERSION || bf_abi_fingerprint() != (uint64_t) BF_ABI_FINGERPRINT)
+            Throw("libbeifong_hip.so has ABI version %d / layout %016llx, libbeifong_host.so was built for version %d / layout "
+                  "%016llx: rebuild both (python -c 'import __graft_entry__ as g; g.build()')",
+                  bf_version(), (unsigned long long) bf_abi_fingerprint(), BF_ABI_VERSION, (unsigned long long) BF_ABI_FINGERPRINT);
+        return true;
+    }();
+    (void) ok;
+}
+
 bf_scene *Scene::device_scene(const Endpoint *endpoint) {
+    check_core_abi();
     flat_desc(endpoint);
     if (!m_flat->device) {
         bf_status st = bf_scene_create(&m_flat->desc, &m_flat->device);

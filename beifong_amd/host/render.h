@@ -303,6 +303,11 @@ ref<Object> load_file(const std::string &filename, const ParameterList &params =
 ref<Object> load_string(const std::string &xml, const ParameterList &params = {}, const std::string &base_dir = ".");
 }  // namespace xml
 
+inline unsigned long long host_class_layout_inline() {
+    return (unsigned long long) sizeof(Integrator) << 40 ^ (unsigned long long) sizeof(Scene) << 20 ^ (unsigned long long) sizeof(RenderStats);
+}
+inline unsigned long long abi_fingerprint_of_this_build() { return (unsigned long long) BF_ABI_FINGERPRINT ^ (host_class_layout_inline() * 0x9e3779b97f4a7c15ull); }
+
 /// file lookup relative to the scene file (FileResolver)
 std::string resolve_path(const std::string &path);
 void push_search_path(const std::string &dir);

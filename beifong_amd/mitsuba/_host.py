@@ -24,6 +24,15 @@ def lib():
     capi.load_library()            # libbeifong_hip.so first (same instance for both)
     l = C.CDLL(LIB_PATH)
     vp, cp = C.c_void_p, C.c_char_p
+    # ABI handshake: the host library embeds bf_launch / bf_stats (Integrator::m_stats) and hands them to this binding
+    for f in ("bfh_abi_version", "bfh_sizeof_launch", "bfh_sizeof_stats"):
+        if not hasattr(l, f):
+            raise HostError(f"{LIB_PATH} is stale (no {f}): rebuild the host layer (make -C beifong_amd/host)")
+    if (l.bfh_abi_version() != capi.BF_ABI_VERSION or l.bfh_sizeof_launch() != C.sizeof(capi.bf_launch)
+            or l.bfh_sizeof_stats() != C.sizeof(capi.bf_stats)):
+        raise HostError(f"{LIB_PATH}: ABI version {l.bfh_abi_version()}, sizeof(bf_launch) {l.bfh_sizeof_launch()}, sizeof(bf_stats) "
+                        f"{l.bfh_sizeof_stats()}; this binding has {capi.BF_ABI_VERSION}, {C.sizeof(capi.bf_launch)}, "
+                        f"{C.sizeof(capi.bf_stats)} — rebuild the host layer (make -C beifong_amd/host)")
     l.bfh_last_error.restype = cp
     l.bfh_variant.restype = cp
     l.bfh_set_variant.argtypes = [cp]

@@ -406,7 +406,8 @@ def fast_oracle_path():
         key = "unknown"
     tag = hashlib.sha256(key.encode()).hexdigest()[:10]
     out = os.path.join(ROOT, "oracle", "_fast", "libbf_oracle_fast_%s.so" % tag)
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(ROOT, "oracle", "bf_oracle.cpp")):
+    newest = max(os.path.getmtime(os.path.join(ROOT, "oracle", "bf_oracle.cpp")), os.path.getmtime(os.path.join(ROOT, "include", "beifong_hip.h")))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "fast", "FAST_OUT=" + out], check=True)
     return out
 

@@ -22,7 +22,11 @@
  * bf_scene_create (they are deep-copied to the device) and owns every output
  * buffer.  A bf_scene handle runs ONE render at a time (it owns the path pool
  * the render's state lives in); concurrent renders of one scene on several
- * streams use one handle each — bf_scene_clone shares the geometry.
+ * streams use one handle each — bf_scene_clone shares the geometry.  This is
+ * enforced, not just asked for: a second HOST THREAD entering a call on a
+ * handle that is inside one gets BF_ERR_INVALID, and a call whose stream
+ * differs from the handle's previous call waits (on the device) for that
+ * call's work, so successive renders of one handle are always ordered.
  *
  * Conventions: all arithmetic fp32, indices uint32, RNG state uint64.
  * Matrices are row-major float[16].  Spectra are a single grey lane (all
@@ -38,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 2
+#define BF_ABI_VERSION 3
 
 typedef int bf_status;
 enum {
@@ -236,6 +240,9 @@ enum {
                                   :1604-1623).  The two differ only by the Doppler hook, so without BF_FLAG_DOPPLER the beat is
                                   exactly 0 and every sample falls outside the ADC (ceil(0 - 1) = -1), as at the reference's HEAD.
                                   receive_type "mixer" (:1624-1634) is an empty branch there and has no counterpart here. */
+    BF_FLAG_ROLLING = 32u,     /* bf_render_device only: the render joins the handle's ROLLING SEQUENCE (below, bf_scene_flush) */
+    BF_FLAG_TIMING = 64u,      /* rolling sequences: HIP events around every kernel launch; bf_scene_flush's statistics carry
+                                  the per-kernel sums (trace_ms / shade_ms / tail_ms).  Set it on every render of the sequence. */
     BF_FLAG_DOPPLER = 8u       /* receive modes: the Doppler hook the reference carries commented out
                                   ("Took doppler out to test", pathtimefrequency.cpp:124-126,141-144,180-183):
                                   the path's wavelength is shifted by Shape::doppler(si) =
@@ -283,6 +290,8 @@ typedef struct bf_stats {
     uint64_t n_shade_rays;     /* rays generated by wf_shade (rectangle + root-box test each) */
     uint64_t n_guard;          /* rays dropped by wf_trace's iteration guard: always 0, else the
                                   render call fails with BF_ERR_DEVICE                        */
+    uint32_t n_launches_tail;  /* tail kernel launches (timed renders / sequences)            */
+    uint32_t reserved_;
 } bf_stats;
 
 typedef struct bf_scene_info {
@@ -292,11 +301,26 @@ typedef struct bf_scene_info {
     float bbox_min[3], bbox_max[3];
     uint32_t bvh_depth;       /* levels of the four-wide tree                  */
     uint32_t bvh_stack_need;  /* worst-case traversal stack entries (<= 31)    */
-    uint32_t trace_node_bytes; /* bytes per node as the throughput traversal kernel (wf_trace) reads them: 64
-                                  (quantised child boxes) — node_bytes (128, fp32 boxes) is what the other kernels read */
+    uint32_t trace_node_bytes; /* bytes per node as the throughput traversal kernel (wf_trace) reads them: node_bytes (128,
+                                  fp32 child boxes) by default, 64 with the opt-in quantised nodes (BF_QUANT_BVH=1) */
 } bf_scene_info;
 
 /* ---------------- entry points --------------------------------------------- */
+/* ABI handshake.  bf_version() is BF_ABI_VERSION as the LIBRARY was compiled and bf_abi_sizeof(k) the size of struct k
+ * there; a caller compares both with its own build before the first call (BF_ABI_MATCHES below; the host layer, every
+ * plugin and the ctypes binding do) — a component built against an older header would otherwise have the library
+ * write a larger bf_stats / read a larger bf_launch than the caller allocated. */
+enum {
+    BF_ABI_MATERIAL = 0, BF_ABI_SHAPE, BF_ABI_EMITTER, BF_ABI_SENSOR, BF_ABI_SCENE_DESC, BF_ABI_LAUNCH,
+    BF_ABI_PATH_RECORD, BF_ABI_STATS, BF_ABI_SCENE_INFO, BF_ABI_BATCH, BF_ABI_STRUCTS
+};
+uint32_t bf_abi_sizeof(uint32_t which);          /* 0 for an unknown index */
+/* the caller's side of the handshake: a word every component compiled against THIS header agrees on */
+#define BF_ABI_FINGERPRINT                                                                                              \
+    ((uint64_t) BF_ABI_VERSION << 48 ^ (uint64_t) sizeof(bf_launch) << 36 ^ (uint64_t) sizeof(bf_stats) << 24 ^        \
+     (uint64_t) sizeof(bf_scene_desc) << 12 ^ (uint64_t) sizeof(bf_shape) << 6 ^ (uint64_t) sizeof(bf_emitter) ^        \
+     (uint64_t) sizeof(bf_scene_info) << 18 ^ (uint64_t) sizeof(bf_batch) << 30)
+uint64_t bf_abi_fingerprint(void);               /* BF_ABI_FINGERPRINT as the library was compiled */
 int bf_version(void);
 const char *bf_last_error(void);                 /* thread-local              */
 int bf_device_count(void);
@@ -351,6 +375,34 @@ uint32_t bf_launch_channels(const bf_launch *launch);
 bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch,
                            float *hist_dev, bf_path_record *records_dev,
                            void *stream, bf_stats *stats_out);
+
+/* ROLLING SEQUENCES.  Every render ends in a latency-bound tail: a few Russian-roulette survivors of 100+ bounces
+ * that a nearly empty GPU finishes one dependent bounce after the other (a quarter of a 2^24-path render's time, three
+ * quarters of a 2^20-path one).  Loops that render the SAME scene again and again — the accumulation passes of a long
+ * Monte-Carlo render, the pulses of a coherent interval (python_scripts/animated_trans_rad.py:307-384, Receive.ipynb
+ * cell 30; the reference's own sample loop is src/librender/integrator.cpp:659-663) — need not pay it per render:
+ * with BF_FLAG_ROLLING, bf_render_device enqueues only the throughput part of the render and LEAVES ITS LONG PATHS ALIVE
+ * in the handle's pool, where the launches of the handle's next rolling renders carry them along (a path is the same
+ * path whichever launch advances it: its own PCG32 stream, sampler.cpp:83-96).  One tail runs per sequence:
+ *
+ *   bf_scene_flush(scene, stream, stats)   finishes every path still alive (stream-ordered; asynchronous unless
+ *                                          `stats` is given).  After it — and a stream synchronisation — every
+ *                                          histogram of the sequence is complete.
+ *
+ * Rules: the renders of a sequence share mode, n_paths (at most the handle's pool, 2^24), bins, depth limits and flags;
+ * they may differ in seed, path_offset, hist_dev and records_dev (one histogram / record array PER RENDER, all of which
+ * must stay valid until the flush has completed).  stats_out must be NULL.  A render that does not fit the open sequence
+ * (or the 256th of a sequence), a plain or batched render, bf_scene_update_endpoints, bf_scene_translate_meshes and
+ * bf_scene_clone flush the sequence first, so no call ever sees another scene than the one it was issued for;
+ * bf_scene_destroy abandons it.  Renders without the flag behave exactly as before. */
+bf_status bf_scene_flush(bf_scene *scene, void *stream, bf_stats *stats_out);
+
+/* Flush, wait for everything enqueued on the handle and report a device-side failure of ANY render since the last check:
+ * a planned render (the second and later ones of a launch shape run without a host round trip) returns BF_OK before its
+ * kernels have run, so wf_trace's iteration guard — dropped rays, i.e. a wrong histogram: never expected — can only be
+ * reported afterwards: here (BF_ERR_DEVICE; the error refers to an EARLIER render of the handle), by the handle's next
+ * render, or by a render with stats_out.  Call it at the end of a sweep. */
+bf_status bf_scene_sync(bf_scene *scene);
 
 /* Convenience: render into a HOST buffer (zeroed by the callee). */
 bf_status bf_render(const bf_scene *scene, const bf_launch *launch,

@@ -2011,6 +2011,9 @@ static thread_local std::string g_err;
 // C interface (prefix bfo_): same POD structs as include/beifong_hip.h
 // ===========================================================================
 extern "C" {
+// layout word of the header this checker was compiled against (tests/oracle_lib.py compares it with the product's)
+unsigned long long bfo_abi_fingerprint(void) { return (unsigned long long) BF_ABI_FINGERPRINT; }
+
 
 struct bfo_scene {
     OScene sc;

@@ -20,9 +20,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    src = os.path.join(ORACLE_DIR, "bf_oracle.cpp")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        build()
+    build()          # make: a no-op unless bf_oracle.cpp or include/beifong_hip.h is newer than the library
     _lib = load_from(LIB)
     return _lib
 
@@ -31,6 +29,12 @@ def load_from(path):
     """Bind an oracle build (the checker's -O2 library, or bench.py's -O3 -march=native timing build of the same source)."""
     lib = C.CDLL(path)
     vp = C.c_void_p
+    # the checker shares the C-ABI structs (bf_launch, bf_stats, bf_scene_desc ...) with the product: same header or bust
+    lib.bfo_abi_fingerprint.restype = C.c_uint64
+    prod = capi.load_library()
+    prod.bf_abi_fingerprint.restype = C.c_uint64
+    if lib.bfo_abi_fingerprint() != prod.bf_abi_fingerprint():
+        raise RuntimeError(f"{path} was built against another include/beifong_hip.h than libbeifong_hip.so: make -C oracle")
     lib.bfo_last_error.restype = C.c_char_p
     lib.bfo_scene_create.argtypes = [C.POINTER(capi.bf_scene_desc), C.c_int, C.POINTER(vp)]
     lib.bfo_scene_destroy.argtypes = [vp]

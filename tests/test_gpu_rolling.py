@@ -1,0 +1,278 @@
+"""Rolling sequences (BF_FLAG_ROLLING + bf_scene_flush): consecutive renders of one handle leave their long paths alive in
+the pool, the next renders' launches carry them, one tail runs per sequence (include/beifong_hip.h).
+
+The reference runs such loops one render() / receive() per frame (python_scripts/animated_trans_rad.py:307-384,
+Receive.ipynb cell 30; sample loop src/librender/integrator.cpp:659-663).  Whatever launch advances a path, it must be
+the path a stand-alone render traces: every per-path record of every render of a sequence is held to the stand-alone
+render's and to the oracle's, bit for bit, and every histogram is complete after the flush."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from beifong_amd import capi, scenes
+from tests.oracle_lib import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_records(a, b):
+    for k in ("L", "aux"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(a["n_rays"], b["n_rays"]) and np.array_equal(a["valid"], b["valid"])
+
+
+def _close_hist(hb, hs, n_paths, amax):
+    atol = n_paths * 2.0 ** -24 * max(amax, 1.0) * 4
+    assert np.allclose(hb, hs, rtol=2e-5, atol=atol), float(np.abs(hb - hs).max())
+
+
+def _launch_like(lp, seed, flags=0, n_paths=None, path_offset=0):
+    return capi.make_launch(lp.mode, int(lp.n_paths if n_paths is None else n_paths), seed=seed, path_offset=path_offset, bins=lp.bins,
+                            bins_y=lp.bins_y, bin_width=lp.bin_width, color_mode=lp.color_mode, max_depth=lp.max_depth,
+                            rr_depth=lp.rr_depth, time_c=lp.time_c, phase_bins=lp.phase_bins, flags=flags)
+
+
+class _Sequence:
+    """K rolling renders of one handle with device buffers (torch), then a flush."""
+
+    def __init__(self, g, lp, seeds, offsets=None, extra_flags=0, records=True):
+        import torch
+        self.torch = torch
+        self.g, self.lp, self.seeds = g, lp, list(seeds)
+        K, n = len(self.seeds), g.channels(lp)
+        self.hist = torch.zeros((K, n), dtype=torch.float32, device="cuda")
+        self.rec = torch.zeros((K, int(lp.n_paths), 4), dtype=torch.int32, device="cuda") if records else None
+        self.offsets = list(offsets) if offsets is not None else [0] * K
+        self.flags = capi.BF_FLAG_ROLLING | extra_flags
+
+    def issue(self, ks=None, stream=0):
+        for k in (range(len(self.seeds)) if ks is None else ks):
+            l = _launch_like(self.lp, self.seeds[k], flags=self.flags | self.lp.flags, path_offset=self.offsets[k])
+            self.g.render_device(l, self.hist[k].data_ptr(), stream=stream,
+                                 records_ptr=self.rec[k].data_ptr() if self.rec is not None else None)
+
+    def results(self):
+        self.torch.cuda.synchronize()
+        h = self.hist.cpu().numpy()
+        r = self.rec.cpu().numpy().view(np.uint32).reshape(len(self.seeds), -1, 4) if self.rec is not None else None
+        recs = None
+        if r is not None:
+            recs = [np.ascontiguousarray(r[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1) for k in range(len(self.seeds))]
+        return h, recs
+
+
+def _check_against_stand_alone(g, lp, seq, h, recs, oracle=None, offsets=None):
+    rays = 0
+    for k, seed in enumerate(seq.seeds):
+        l1 = _launch_like(lp, seed, flags=lp.flags, path_offset=seq.offsets[k])
+        hs, rs, ss = g.render(l1, records=True)
+        _same_records(recs[k], rs)
+        _close_hist(h[k], hs, lp.n_paths, float(np.abs(rs["L"]).max()))
+        rays += ss.n_rays_closest + ss.n_rays_shadow
+        if oracle is not None:
+            l1.flags = 0
+            _, ro, _ = oracle.render(l1, records=True, threads=8)
+            _same_records(recs[k], ro)
+    return rays
+
+
+@pytest.mark.parametrize("iters", ["", "1", "5"])
+def test_rolling_range_sequence_every_path_bit_exact(hiplib, iters, monkeypatch):
+    """C2-class scene, range mode: eight rolling renders with their own seeds; per-path records == stand-alone renders ==
+    the oracle, histograms complete after the flush, the sequence's counters == the sum of the renders'.  BF_ROLL_ITERS=1
+    lets the backlog of late-started paths grow until the flush; 5 runs most iterations over a nearly idle pool."""
+    if iters:
+        monkeypatch.setenv("BF_ROLL_ITERS", iters)
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 16, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    seeds = [11, 7, 123456789, 11, 2 ** 40 + 5, 3, 4, 5]
+    seq = _Sequence(g, lp, seeds, extra_flags=capi.BF_FLAG_STATS)
+    seq.issue()
+    st = g.flush(want_stats=True)
+    h, recs = seq.results()
+    rays = _check_against_stand_alone(g, lp, seq, h, recs, oracle=OracleScene(sd))
+    assert st.n_rays_closest + st.n_rays_shadow == rays and st.n_paths == lp.n_paths * len(seeds)
+    assert st.n_guard == 0 and st.n_launches_tail <= 1
+    assert np.array_equal(recs[0]["L"], recs[3]["L"])          # same seed, same render
+    assert all(hk[4] == lp.n_paths for hk in h)                # the weight channel: every path of every render landed
+
+
+def test_rolling_receive_sequence_and_second_sequence(hiplib):
+    """gen-3 receive (the RX = 1 kernels) with I/Q; a second sequence on the same handle after the flush starts afresh."""
+    sd, lp = scenes.bus_receive(n_tris=20000, n_paths=20000, t_bins=256, dr=0.1)
+    lp.mode = capi.BF_MODE_RECEIVE_IQ
+    g = capi.Scene(sd)
+    o = OracleScene(sd)
+    for seeds in ([5, 6, 7, 8, 9], [100, 5]):
+        seq = _Sequence(g, lp, seeds)
+        seq.issue()
+        g.flush()
+        h, recs = seq.results()
+        _check_against_stand_alone(g, lp, seq, h, recs, oracle=o)
+
+
+@pytest.mark.parametrize("n_paths", [1, 63, 1000, 4097])
+def test_rolling_ragged_pools(hiplib, n_paths):
+    """Path counts that are no multiple of 64: the pool's spare slots belong to the NEXT render's paths (slot i renders the
+    global paths i, i + n_slots, ...), so renders overlap inside the pool."""
+    sd, lp = scenes.bus_radar(n_tris=5000, n_paths=n_paths, bins=64, dr=0.4)
+    g = capi.Scene(sd)
+    seeds = list(range(50, 57))
+    seq = _Sequence(g, lp, seeds)
+    seq.issue()
+    g.flush()
+    h, recs = seq.results()
+    _check_against_stand_alone(g, lp, seq, h, recs, oracle=OracleScene(sd))
+
+
+def test_rolling_sequence_longer_than_the_descriptor_ring(hiplib):
+    """300 renders: the 257th flushes the first 256 behind the scenes (kRollRing descriptors); every render is complete."""
+    sd, lp = scenes.bus_radar(n_tris=5000, n_paths=512, bins=64, dr=0.4)
+    g = capi.Scene(sd)
+    seeds = [1000 + 17 * k for k in range(300)]
+    seq = _Sequence(g, lp, seeds)
+    seq.issue()
+    g.flush()
+    h, recs = seq.results()
+    assert all(hk[4] == lp.n_paths for hk in h)
+    o = OracleScene(sd)
+    for k in (0, 1, 255, 256, 257, 299):
+        l1 = _launch_like(lp, seeds[k])
+        _, ro, _ = o.render(l1, records=True, threads=4)
+        _same_records(recs[k], ro)
+
+
+def test_rolling_path_offsets_shard_a_render(hiplib):
+    """The shards of one render as a rolling sequence (path_offset per render): the union is the unsharded sample set."""
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 14, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    K = 4
+    seq = _Sequence(g, lp, [lp.seed] * K, offsets=[k * int(lp.n_paths) for k in range(K)])
+    seq.issue()
+    g.flush()
+    h, recs = seq.results()
+    whole = _launch_like(lp, lp.seed, n_paths=K * int(lp.n_paths))
+    hw, rw, _ = g.render(whole, records=True)
+    _same_records(np.concatenate(recs), rw)
+    _close_hist(h.sum(axis=0), hw, K * lp.n_paths, float(np.abs(rw["L"]).max()))
+
+
+def test_everything_else_flushes_an_open_sequence(hiplib):
+    """A plain render, an endpoint update, a translation and a clone each finish the open sequence first: its paths see the
+    scene they were issued for, and its histograms are complete once the other call's stream work is."""
+    import torch
+    sd, lp = scenes.bus_receive(n_tris=20000, n_paths=8192, t_bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    ref_h, ref_r = {}, {}
+    for seed in (1, 2, 3, 4):
+        ref_h[seed], ref_r[seed], _ = g.render(_launch_like(lp, seed), records=True)
+
+    def run(seed, then):
+        seq = _Sequence(g, lp, [seed])
+        seq.issue()
+        then()
+        h, recs = seq.results()              # no explicit flush
+        _same_records(recs[0], ref_r[seed])
+        _close_hist(h[0], ref_h[seed], lp.n_paths, float(np.abs(ref_r[seed]["L"]).max()))
+
+    run(1, lambda: g.render(_launch_like(lp, 77)))
+    sd2, _ = scenes.bus_receive(n_tris=20000, n_paths=8192, t_bins=256, dr=0.1)
+    run(2, lambda: g.update_endpoints(sd2))
+    run(3, lambda: g.translate_meshes((0.0, 0.0, 0.0)))
+    run(4, lambda: g.clone())
+    # a render of another shape opens a new sequence behind the flushed one
+    seq_a = _Sequence(g, lp, [1])
+    seq_a.issue()
+    lp_b = _launch_like(lp, 2, n_paths=4096)
+    seq_b = _Sequence(g, lp_b, [2])
+    seq_b.issue()
+    g.flush()
+    ha, ra = seq_a.results()
+    _same_records(ra[0], ref_r[1])
+    hb, rb = seq_b.results()
+    _, rs, _ = g.render(_launch_like(lp_b, 2), records=True)
+    _same_records(rb[0], rs)
+    torch.cuda.synchronize()
+
+
+def test_rolling_rejects_what_cannot_roll(hiplib):
+    sd, lp = scenes.bus_radar(n_tris=5000, n_paths=4096, bins=64, dr=0.4)
+    g = capi.Scene(sd)
+    l = _launch_like(lp, 1, flags=capi.BF_FLAG_ROLLING)
+    hist = np.zeros(g.channels(l), np.float32)
+    st = capi.bf_stats()
+    # host-buffer renders and stats requests are synchronous by nature
+    assert hiplib.bf_render(g.handle, C.byref(l), hist.ctypes.data_as(C.c_void_p), None, C.byref(st)) == capi.BF_ERR_INVALID
+    l2 = _launch_like(lp, 1, flags=capi.BF_FLAG_ROLLING | capi.BF_FLAG_MEGAKERNEL)
+    import torch
+    d = torch.zeros(g.channels(l), dtype=torch.float32, device="cuda")
+    assert hiplib.bf_render_device(g.handle, C.byref(l2), C.c_void_p(d.data_ptr()), None, None, None) == capi.BF_ERR_UNSUPPORTED
+    assert g.flush(want_stats=True).n_paths == 0           # nothing open: a no-op
+
+
+def test_guard_trip_of_the_last_render_is_reported_by_sync(hiplib):
+    """a planned render returns BF_OK before its kernels ran, so a guard trip of the LAST render of a sequence
+    used to go unreported.  The guard word is sticky now and bf_scene_sync reports it (test hook: pre-load the word)."""
+    import torch
+    sd, lp = scenes.bus_radar(n_tris=5000, n_paths=1 << 14, bins=64, dr=0.4)
+    g = capi.Scene(sd)
+    d = torch.zeros(g.channels(lp), dtype=torch.float32, device="cuda")
+    for k in range(3):                                      # the first learns the plan, the others are planned (asynchronous)
+        g.render_device(_launch_like(lp, k), d.data_ptr())
+    g.sync()                                                # clean
+    hiplib.bfdbg_preload_guard.argtypes = [C.c_void_p, C.c_ulonglong]
+    assert hiplib.bfdbg_preload_guard(g.handle, 5) == capi.BF_OK
+    g.render_device(_launch_like(lp, 9), d.data_ptr())      # planned: returns BF_OK, does not clear the word
+    with pytest.raises(capi.BeifongError, match="dropped 5 rays"):
+        g.sync()
+    g.sync()                                                # reported once, then clean again
+    # the synchronous path (stats) reports it too
+    assert hiplib.bfdbg_preload_guard(g.handle, 2) == capi.BF_OK
+    with pytest.raises(capi.BeifongError, match="dropped 2 rays"):
+        g.render(_launch_like(lp, 1))
+    g.render(_launch_like(lp, 1))
+
+
+def test_one_host_thread_per_handle(hiplib):
+    """A second host thread inside a call on the same handle gets BF_ERR_INVALID instead of a race on the handle's pool
+    (test hook holds the flag the way a concurrent call would)."""
+    sd, lp = scenes.bus_radar(n_tris=5000, n_paths=4096, bins=64, dr=0.4)
+    g = capi.Scene(sd)
+    hiplib.bfdbg_hold_busy.argtypes = [C.c_void_p, C.c_int]
+    assert hiplib.bfdbg_hold_busy(g.handle, 1) == capi.BF_OK
+    with pytest.raises(capi.BeifongError, match="in use by another host thread"):
+        g.render(_launch_like(lp, 1))
+    with pytest.raises(capi.BeifongError, match="in use by another host thread"):
+        g.flush()
+    with pytest.raises(capi.BeifongError, match="in use by another host thread"):
+        g.clone()
+    assert hiplib.bfdbg_hold_busy(g.handle, 0) == capi.BF_OK
+    g.render(_launch_like(lp, 1))
+    c = g.clone()                                           # the clone has its own flag
+    assert hiplib.bfdbg_hold_busy(g.handle, 1) == capi.BF_OK
+    c.render(_launch_like(lp, 1))
+    assert hiplib.bfdbg_hold_busy(g.handle, 0) == capi.BF_OK
+
+
+def test_renders_of_one_handle_on_two_streams_are_ordered(hiplib):
+    """Successive renders of ONE handle on different streams used to race on the pool (a header comment asked callers not
+    to); the second now waits on the device for the first."""
+    import torch
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 18, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    n = g.channels(lp)
+    d = torch.zeros((6, n), dtype=torch.float32, device="cuda")
+    r = torch.zeros((6, int(lp.n_paths), 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(6):
+        s = s1 if k % 2 == 0 else s2
+        g.render_device(_launch_like(lp, 40 + k), d[k].data_ptr(), stream=s.cuda_stream, records_ptr=r[k].data_ptr())
+    g.sync()
+    torch.cuda.synchronize()
+    rr = r.cpu().numpy().view(np.uint32)
+    for k in (0, 1, 5):
+        _, rs, _ = g.render(_launch_like(lp, 40 + k), records=True)
+        _same_records(np.ascontiguousarray(rr[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1), rs)
