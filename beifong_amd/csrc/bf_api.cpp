@@ -115,6 +115,7 @@ struct bf_tunables {
     unsigned tail_spread = 1, tail_blocks = 0;
     bool allow_plan = true;                  // BF_WF_SYNC=1 turns launch plans off
     uint32_t roll_iters = 0;                 // BF_ROLL_ITERS: bounce iterations per call of a rolling sequence (0: adaptive)
+    uint32_t roll_live = 1u << 20;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
     bool no_wide = false, quant = false;
     int wide_rows_log = -1;
 };
@@ -140,6 +141,7 @@ static bf_tunables read_tunables() {
     t.tail_blocks = (unsigned) std::max<long long>(0, num("BF_TAIL_BLOCKS", 0));
     t.allow_plan = num("BF_WF_SYNC", 0) == 0;
     t.roll_iters = (uint32_t) std::max<long long>(0, std::min<long long>(32, num("BF_ROLL_ITERS", 0)));
+    t.roll_live = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_ROLL_LIVE", 1ll << 20), 1ll << 30));
     t.no_wide = getenv("BF_NO_WIDE_BVH") != nullptr;
     t.quant = num("BF_QUANT_BVH", 0) != 0;
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
@@ -187,7 +189,7 @@ struct bf_scene {
     mutable std::vector<hipEvent_t> wf_timing;   // event pool for per-kernel timing (stats only): pair k = events 2k, 2k + 1
     mutable std::vector<int> wf_ev_kind;         // kind of every recorded pair: 0 trace, 1 shade, 2 tail
     mutable float wf_ms[3] = {0, 0, 0};          // trace, shade, tail of the last stats render / rolling sequence
-    mutable uint32_t wf_iters = 0, wf_trace_launches = 0, wf_tail_launches = 0;
+    mutable uint32_t wf_iters = 0, wf_trace_launches = 0, wf_tail_launches = 0, wf_shade_launches = 0;
     // Rolling sequence (bf_render_device with BF_FLAG_ROLLING, bf_scene_flush): see wf_roll_render
     struct Roll {
         bool open = false;
@@ -1111,6 +1113,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     HIP_TRY(alloc((void **) &scene->roll_ring, bfd::kRollRing * sizeof(bfd::DRoll)));
+    HIP_TRY(alloc((void **) &wf.surv_cursor, 64));
     wf.counters = scene->counters;
     wf.capacity = capacity;
     if (!scene->wf_host) HIP_TRY(hipHostMalloc((void **) &scene->wf_host, 64));
@@ -1168,7 +1171,7 @@ static hipError_t wf_toc(const WfCtx &c) {
 // wait for the stream and add the recorded pairs up by kind (wf_ms), then forget them
 static bf_status wf_collect_timing(const bf_scene *scene, hipStream_t stream) {
     scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
-    scene->wf_tail_launches = 0;
+    scene->wf_tail_launches = scene->wf_shade_launches = 0;
     if (scene->wf_ev_kind.empty()) return BF_OK;
     HIP_TRY(hipStreamSynchronize(stream));
     for (size_t k = 0; k < scene->wf_ev_kind.size(); ++k) {
@@ -1176,6 +1179,7 @@ static bf_status wf_collect_timing(const bf_scene *scene, hipStream_t stream) {
         HIP_TRY(hipEventElapsedTime(&ms, scene->wf_timing[2 * k], scene->wf_timing[2 * k + 1]));
         scene->wf_ms[scene->wf_ev_kind[k]] += ms;
         if (scene->wf_ev_kind[k] == 2) ++scene->wf_tail_launches;
+        if (scene->wf_ev_kind[k] == 1) ++scene->wf_shade_launches;
     }
     scene->wf_ev_kind.clear();
     return BF_OK;
@@ -1183,13 +1187,21 @@ static bf_status wf_collect_timing(const bf_scene *scene, hipStream_t stream) {
 
 // pool size, masks, scheduling knobs and grids for `lp` on this handle
 static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_t pool_paths, float *hist_dev, bf_path_record *records_dev,
-                          hipStream_t stream, bool count_nodes, bool timed, WfCtx &c) {
+                          hipStream_t stream, bool count_nodes, bool timed, WfCtx &c, bool rolling = false) {
     uint64_t want = std::min<uint64_t>(scene->tun.pool, std::max<uint64_t>(pool_paths, 64));
-    uint32_t cap = (uint32_t) ((want + 63) & ~uint64_t(63));
-    bf_status st = wf_ensure(scene, cap);
+    uint32_t n_main = (uint32_t) ((want + 63) & ~uint64_t(63)), n_surv = 0;
+    if (rolling) {
+        // two renders' worth of main slots (a slot's next path is supplied two calls after its current one) + the
+        // survivor area for the paths that are still alive by then (bf_wavefront.h)
+        n_main = (uint32_t) ((std::max<uint64_t>(2 * pool_paths, 128) + 63) & ~uint64_t(63));
+        n_surv = std::max<uint32_t>(1u << 16, std::min<uint32_t>(1u << 21, (n_main / 8 + 63) & ~63u));
+    }
+    bf_status st = wf_ensure(scene, n_main + n_surv);
     if (st != BF_OK) return st;
     bfd::WF &wf = scene->wf;
-    wf.n_slots = (uint32_t) ((std::min<uint64_t>(wf.capacity, pool_paths) + 63) & ~uint64_t(63));
+    wf.n_main = rolling ? n_main : (uint32_t) ((std::min<uint64_t>(wf.capacity, pool_paths) + 63) & ~uint64_t(63));
+    wf.n_surv = n_surv;
+    wf.n_slots = wf.n_main + wf.n_surv;
     wf.trace_refill = scene->tun.trace_refill;
     wf.trace_stragglers = scene->tun.trace_stragglers;
     wf.shade_chain = scene->tun.shade_chain;
@@ -1213,7 +1225,7 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.count_nodes = count_nodes;
     c.timed = timed;
     c.mask_bytes = 3 * nb * sizeof(unsigned long long);
-    c.lds_shade = lp.lds_hist ? ((sizeof(float) * lp.n_chan_all + 15) & ~size_t(15)) : 0;
+    c.lds_shade = (sizeof(float) * lp.lds_floats + 15) & ~size_t(15);
     c.lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + c.lds_shade;
     // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
     // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)
@@ -1221,7 +1233,8 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
     c.grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, scene->tun.shade_waves), max_blocks));
     c.grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) scene->tun.trace_waves, max_blocks));
-    c.tail_max = wf_tail_threshold(scene, wf.n_slots);
+    c.tail_max = wf_tail_threshold(scene, rolling ? wf.n_main / 2 : wf.n_slots);
+    wf.surv_claims_max = std::max<uint32_t>(1u, (wf.n_surv / 64u) / std::max(1u, c.grid_shade * batches_per_block));
     return BF_OK;
 }
 // One bounce iteration `it`: clear the next parity's masks, shade (first: 0 alive masks, 1 first bounce of a pool, 2 alive
@@ -1232,8 +1245,10 @@ static bf_status wf_iteration(const WfCtx &c, uint32_t it, int first) {
     const int nxt = (it & 1) ^ 1;
     HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, c.mask_bytes, c.stream));     // alive, trace, shadow are contiguous
     if (first != 1) {
+        // first launch of a rolling call (first == 2): the evicting variant — long paths make room for the new render's
         HIP_TRY(wf_tic(c, 1));
-        HIP_TRY(bfk_wf_shade(&scene->d, c.lp, &wf, it, 0, c.hist, c.rec, c.grid_shade, c.lds_shade, c.stream, scene->tun.shade_waves));
+        HIP_TRY(bfk_wf_shade(&scene->d, c.lp, &wf, it, first == 2 ? 3 : 0, c.hist, c.rec, c.grid_shade, c.lds_shade, c.stream,
+                             scene->tun.shade_waves));
         HIP_TRY(wf_toc(c));
     }
     if (first != 0) {
@@ -1249,8 +1264,18 @@ static bf_status wf_trace_launch(const WfCtx &c, uint32_t it) {
     HIP_TRY(wf_toc(c));
     return BF_OK;
 }
-static bf_status wf_tail_launch(const WfCtx &c, uint32_t it, uint32_t est_live) {
+static bf_status wf_tail_launch(const WfCtx &c, uint32_t it, uint32_t est_live, bool alone = false) {
     const bf_scene *scene = c.scene;
+    // `alone`: nothing else wants the CUs (the flush of a rolling sequence): spread the paths thinly — up to four waves
+    // share a batch, so a wave starts with <= 16 paths and walks four lanes per ray from its first bounce instead of
+    // waiting for the longest of 64 lane-per-ray walks (half of a tail's cycles are those dense iterations)
+    uint32_t share = 1;
+    if (alone) {
+        const uint32_t resident = (uint32_t) scene->n_cus * 4u * 3u;          // waves at 3 per SIMD
+        while (share < 4u && (uint64_t) est_live * (share * 2u) / 64u <= resident) share *= 2u;
+        est_live = (uint32_t) std::min<uint64_t>((uint64_t) est_live * share, 1u << 30);
+    }
+    scene->wf.tail_share = share;
     HIP_TRY(wf_tic(c, 2));
     HIP_TRY(bfk_launch_tail(&scene->d, c.lp, &scene->wf, it, est_live, c.hist, c.rec, c.count_nodes ? 1 : 0, c.lds_tail, c.stream,
                             scene->tun.tail_waves, scene->tun.tail_spread, scene->tun.tail_blocks));
@@ -1417,15 +1442,19 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         scene->wf_ev_kind.clear();
         scene->wf_iters = scene->wf_trace_launches = 0;
     }
+    const bool fresh_pool = opening;
     const uint32_t k = r.count;
     bfd::DLaunch &lp = r.lp;
     lp.n_paths = (uint64_t) (k + 1u) * lp.batch_paths;
     lp.roll_newest = k;
     lp.roll_lo = k + 1u > r.window ? k + 1u - r.window : 0u;
     lp.n_chan_all = (lp.roll_newest - lp.roll_lo + 1u) * lp.n_chan;
+    lp.base_off = lp.lds_hist ? r.window * lp.n_chan : 0u;        // fixed for the sequence: behind the full window
+    lp.lds_floats = lp.base_off + 5u * bfd::kRollBase;
     WfCtx c;
-    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c)) != BF_OK) return st;
+    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
     lp.roll = scene->roll_ring;           // wf_setup may have (re)allocated the pool and the ring with it
+    if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, sizeof(uint32_t), stream));
     {
         bfd::DRoll d;
         d.seed = launch->seed;
@@ -1435,19 +1464,20 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         HIP_TRY(bfk_roll_set(scene->roll_ring, k & (bfd::kRollRing - 1u), &d, stream));
     }
     // ---- how many bounce iterations this call enqueues ------------------------------------------------
-    // The pool has one slot per path of a render, and a call adds one path per slot to the supply, so the calls keep up
-    // if a slot finishes one path per call on average.  Too few iterations and the backlog of started-late paths grows
-    // until the flush; too many and the late ones run over a nearly empty pool.  Steered by the live counts that come
-    // back (without ever waiting for them): aim at 1/8 .. 1/2 of the pool still busy when a call's launches end.
+    // A launch that finds fewer live slots than fill the chip a few times over runs at its latency floor whatever it
+    // holds, so a call stops iterating once that few are left (roll_live, 2^20 by default) and leaves them to the next
+    // call's launches: too few iterations and too many paths have to move to the survivor area, too many and the late ones
+    // run over a nearly empty pool.  Steered by the live counts that come back (without ever waiting for them).
     const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
     (void) hipGetLastError();
     if (fb_ready) {
         scene->wf_fb_pending = false;
         const uint32_t n = r.fb_call_iters;
         if (n && !r.fb_is_flush && !scene->tun.roll_iters) {
-            const uint32_t live_end = scene->wf_feedback[n - 1];
-            if (live_end > scene->wf.n_slots / 2 && r.iters < 16) ++r.iters;
-            else if (live_end < scene->wf.n_slots / 8 && r.iters > 1) --r.iters;
+            const uint32_t *nl = scene->wf_feedback;
+            uint32_t k = 0;
+            while (k < n && nl[k] > scene->tun.roll_live) ++k;
+            r.iters = std::min<uint32_t>(k < n ? k + 1u : n + 1u, 16u);
         }
         r.fb_call_iters = 0;
     }
@@ -1490,7 +1520,7 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
     }
     bfd::DLaunch &lp = r.lp;
     WfCtx c;
-    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c)) != BF_OK) return st;
+    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
     bfd::WF &wf = scene->wf;
     volatile uint32_t *hq = scene->wf_host;
     const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
@@ -1524,7 +1554,7 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
             ++done_iters;
         }
         const uint32_t est = std::max<uint32_t>(r.flush_live + r.flush_live / 4, 64u * bfd::kBlock);
-        if ((st = wf_tail_launch(c, r.it, est)) != BF_OK) return st;
+        if ((st = wf_tail_launch(c, r.it, est, true)) != BF_OK) return st;
         if (!scene->wf_fb_pending && done_iters) {
             HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live + it0, done_iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
@@ -1548,7 +1578,7 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
         r.flush_iters = done_iters;
         r.flush_live = n_live;
         if (n_live) {
-            if ((st = wf_tail_launch(c, r.it, n_live)) != BF_OK) return st;
+            if ((st = wf_tail_launch(c, r.it, n_live, true)) != BF_OK) return st;
         }
     }
     scene->wf_iters += done_iters;
@@ -1586,6 +1616,7 @@ static void fill_stats(const bf_scene *scene, const unsigned long long *c, uint6
     st->n_launches_trace = scene->wf_trace_launches;
     st->n_bounce_iters = scene->wf_iters;
     st->n_launches_tail = scene->wf_tail_launches;
+    st->n_launches_shade = scene->wf_shade_launches;
 }
 
 // Stream order between the successive uses of a handle's pool: work enqueued on another stream than the previous
@@ -1705,6 +1736,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;
     lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
+    lp.lds_floats = lp.lds_hist ? lp.n_chan_all : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);
     lds = (lds + 15) & ~size_t(15);
     if (batch) {
@@ -1782,7 +1814,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
         HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
         if ((launch->flags & BF_FLAG_MEGAKERNEL) || !launch->n_paths) {
             scene->wf_ms[0] = scene->wf_ms[1] = scene->wf_ms[2] = 0.f;
-            scene->wf_trace_launches = scene->wf_iters = scene->wf_tail_launches = 0;
+            scene->wf_trace_launches = scene->wf_iters = scene->wf_tail_launches = scene->wf_shade_launches = 0;
         }
         fill_stats(scene, c, lp.n_paths, stats_out);
         float ms = 0.f;

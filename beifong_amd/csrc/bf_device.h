@@ -112,6 +112,8 @@ struct DRoll {
 };
 constexpr uint32_t kRollRing = 256;    // renders per sequence (descriptor ring; the host flushes a longer one in between)
 constexpr uint32_t kRollWindow = 4;    // newest renders whose histogram blocks a workgroup privatises in LDS; older ones take global atomics
+constexpr uint32_t kRollBase = 32;     // newest renders whose five BASE channels (X, Y, Z, alpha, weight: one address each per render, so
+                                       // global float atomics on them serialise at L2) a workgroup sums in LDS behind the window
 
 struct DLaunch {
     uint32_t mode, color_mode;
@@ -140,6 +142,9 @@ struct DLaunch {
     const DRoll *roll;              // nullptr: not a rolling launch
     uint32_t roll_newest;           // render index of the call this launch belongs to
     uint32_t roll_lo;               // oldest render whose histogram block is in the LDS window [roll_lo, roll_newest]
+    uint32_t lds_floats;            // floats of dynamic LDS the histogram code zeroes: the privatised histogram (n_chan_all, if lds_hist)
+                                    // followed, in a rolling launch, by the base-channel table [kRollBase][5] at float offset base_off
+    uint32_t base_off;
 };
 
 // device counters (uint64 each)

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const bool lds_hist = lp.lds_hist != 0;
-    if (lds_hist) {
-        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) s_hist[i] = 0.f;
+    if (lp.lds_floats) {
+        for (uint32_t i = tid; i < lp.lds_floats; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
     int *stack = s_stack + tid;
@@ -85,17 +85,20 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     // RESUME: this wave's segment of the pool's alive mask; lanes adopt live slots
     // from it whenever they are free (same on-the-fly compaction as wf_shade)
     uint32_t resume_slots = 0;
+    bool regen_ok = true;          // RESUME: the adopted slot is a main slot (survivor-area slots of a rolling sequence never regenerate)
     MaskCursor rcur;
     rcur.masks = nullptr;
     rcur.b = rcur.b_end = rcur.win = 0;
+    rcur.g = 64u;
+    rcur.stride = 64u;
+    rcur.sub = ~0ull;
     rcur.m = rcur.w = rcur.nz = 0ull;
     if (RESUME) {
-        resume_slots = wf.n_slots;
+        resume_slots = wf.n_main;
         const uint32_t n_batches = wf.n_slots >> 6;
         const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
-        const uint32_t per = (n_batches + n_waves - 1) / n_waves;
-        const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
-        cursor_init(rcur, wf.m_alive[wf_it & 1], b0, b1, lane);
+        // fine interleave (windows of at most 4 batches): the survivors of a rolling sequence sit densely in the survivor area
+        cursor_init(rcur, wf.m_alive[wf_it & 1], wave_id, n_waves, n_batches, lane, 4u, max(1u, wf.tail_share));
     }
 
 #ifdef BF_TAIL_PROF
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             if (!alive && !done) {
                 if (rank < got) {
                     load_state(wf, slot, receive, s);
+                    regen_ok = slot < wf.n_main;
                     alive = true;
                     need_closest = false;          // traced (and counted) by wf_trace already
                     film = false;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             if (RESUME) {
                 // the slot's static path sequence: i, i + n_slots, i + 2 n_slots, ...
                 uint64_t next_path = s.path_i + resume_slots;
-                if (next_path < lp.n_paths) {
+                if (regen_ok && next_path < lp.n_paths) {
                     generate_path(sc, lp, next_path, s);
                     alive = true;
                     need_closest = true;

@@ -121,12 +121,19 @@ BF_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
 // coalesced load and a few scalar bit operations per 64 batches instead of one dependent
 // memory round trip per word (which made every late, nearly empty bounce iteration cost
 // 200-400 us whatever little work it held).
+//
+// A wave's share of the mask array is INTERLEAVED, not contiguous: windows of `g` batches, wave w owning windows
+// w, w + n_waves, w + 2 n_waves, ...  Live slots are not spread evenly over a pool — a rolling sequence keeps one
+// render in each half of the main slots and all its old paths in the survivor area behind them (bf_wavefront.h) — and
+// with contiguous segments the few waves that own the busy region did all the work while the others idled.
 struct MaskCursor {
     const unsigned long long *masks;
-    uint32_t b, b_end;          // current / end batch of the segment (wave-uniform)
+    uint32_t b, b_end;          // current batch / number of batches (wave-uniform)
     unsigned long long m;       // unconsumed bits of batch b (wave-uniform)
     uint32_t win;               // first batch of the fetched window (wave-uniform)
-    unsigned long long w;       // this lane's word of the window: masks[win + lane]
+    uint32_t g, stride;         // window width in batches (<= 64, a power of two) / distance between this wave's windows
+    unsigned long long sub;     // slots of a batch this wave serves (all ones, or a 32- / 16-slot share: the tail's spreading)
+    unsigned long long w;       // this lane's word of the window: masks[win + lane] & sub (lanes >= g: 0)
     unsigned long long nz;      // wave-uniform: window words that are non-zero and not consumed yet
 };
 BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
@@ -143,29 +150,46 @@ BF_DEV void cursor_seek(MaskCursor &c, int lane) {
             c.m = wave_read_u64(c.w, k);
             return;
         }
-        c.win += 64u;
+        c.win += c.stride;
         if (c.win >= c.b_end) {
             c.b = c.b_end;
             c.m = 0ull;
             return;
         }
-        c.w = (c.win + (uint32_t) lane < c.b_end) ? c.masks[c.win + (uint32_t) lane] : 0ull;
+        c.w = ((uint32_t) lane < c.g && c.win + (uint32_t) lane < c.b_end) ? (c.masks[c.win + (uint32_t) lane] & c.sub) : 0ull;
         c.nz = __ballot(c.w != 0ull);
     }
 }
-BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t b0, uint32_t b1, int lane) {
+// windows wide enough for one coalesced fetch each, narrow enough that every wave owns a few of them
+BF_DEV uint32_t cursor_window(uint32_t n_batches, uint32_t n_waves, uint32_t g_max) {
+    uint32_t g = g_max;
+    while (g > 1u && n_batches / g < 4u * n_waves) g >>= 1;
+    return g;
+}
+// `share` (1, 2 or 4): that many consecutive waves serve the same windows, each one its own 64 / share slots of every batch
+BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t wave_id, uint32_t n_waves, uint32_t n_batches, int lane,
+                        uint32_t g_max = 64u, uint32_t share = 1u) {
+    c.sub = ~0ull;
+    if (share > 1u) {
+        const uint32_t width = 64u / share, q = wave_id % share;
+        c.sub = ((1ull << width) - 1ull) << (width * q);
+        wave_id /= share;
+        n_waves = max(1u, n_waves / share);
+    }
     c.masks = masks;
-    c.b_end = b1;
-    c.win = b0;
-    c.b = b0;
+    c.b_end = n_batches;
+    c.g = cursor_window(n_batches, n_waves, g_max);
+    c.stride = c.g * n_waves;
+    c.win = c.g * wave_id;
+    c.b = c.win;
     c.m = 0ull;
     c.w = 0ull;
     c.nz = 0ull;
-    if (b0 >= b1) {
-        c.b = b1;
+    if (c.win >= n_batches) {
+        c.b = n_batches;
         return;
     }
-    c.w = (b0 + (uint32_t) lane < b1) ? masks[b0 + (uint32_t) lane] : 0ull;
+    c.w = ((uint32_t) lane < c.g && c.win + (uint32_t) lane < n_batches) ? (masks[c.win + (uint32_t) lane] & c.sub) : 0ull;
     c.nz = __ballot(c.w != 0ull);
     cursor_seek(c, lane);
 }
@@ -734,6 +758,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                      FilmAcc &acc, bf_path_record *records) {
     const bool valid = (s.flags & kFlagValid) != 0;
     float rec_L, rec_aux;
+    float *const s_base = s_hist + lp.base_off;                               // rolling launches: base-channel table (DLaunch::base_off)
     const HistDst hd = hist_dst(lp, s.render, s_hist, g_hist, lds_hist);      // this render's block of the histogram
     s_hist = hd.s;
     g_hist = hd.g;
@@ -826,12 +851,20 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 hist_add(s_hist, g_hist, lds_hist, pix + 4u, 1.f);
             } else if (!use_acc) {
                 // batched launch: the wave's lanes hold paths of different renders, so the base channels cannot be
-                // summed in registers; each sample goes to its render's block
-                if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, 0u, X);
-                if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, 1u, Y);
-                if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, 2u, Z);
-                if (valid) hist_add(s_hist, g_hist, lds_hist, 3u, 1.f);
-                hist_add(s_hist, g_hist, lds_hist, 4u, 1.f);
+                // summed in registers; each sample goes to its render's block.  A rolling sequence's older renders (behind
+                // the LDS window) would hit the same five GLOBAL addresses from every wave: they go through the
+                // workgroup's base-channel table instead (kRollBase renders; film_flush adds it up)
+                float *bs = s_hist;
+                bool bl = lds_hist;
+                if (lp.roll && !lds_hist && lp.roll_newest - s.render < kRollBase) {
+                    bs = s_base + 5u * (lp.roll_newest - s.render);
+                    bl = true;
+                }
+                if (X != 0.f) hist_add(bs, g_hist, bl, 0u, X);
+                if (Y != 0.f) hist_add(bs, g_hist, bl, 1u, Y);
+                if (Z != 0.f) hist_add(bs, g_hist, bl, 2u, Z);
+                if (valid) hist_add(bs, g_hist, bl, 3u, 1.f);
+                hist_add(bs, g_hist, bl, 4u, 1.f);
             } else {
                 acc.X += X;
                 acc.Y += Y;
@@ -919,6 +952,16 @@ template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, fl
                 float v = s_hist[i];
                 if (v != 0.f) atomicAdd(&g_hist[i], v);
             }
+        }
+    }
+    if (lp.roll && !mode_receive<RX>(lp)) {
+        // base-channel table of the renders behind the window: entry [age][channel], age = roll_newest - render
+        if (!lds_hist) __syncthreads();
+        const float *s_base = s_hist + lp.base_off;
+        for (uint32_t i = tid; i < 5u * kRollBase; i += kBlock) {
+            const float v = s_base[i];
+            const uint32_t age = i / 5u;
+            if (v != 0.f && age <= lp.roll_newest) atomicAdd(&lp.roll[(lp.roll_newest - age) & (kRollRing - 1u)].hist[i - 5u * age], v);
         }
     }
 }

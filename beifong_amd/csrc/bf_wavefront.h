@@ -57,8 +57,18 @@ struct WF {
     uint32_t iq;                               // BF_MODE_RECEIVE_IQ
     uint32_t shade_chain;                      // wf_shade: vertices a lane may shade per visit while its rays resolve early
     uint32_t row_jobs;                         // tail: waves holding at most this many rays trace them one per 16-lane row (traverse_row16)
-    uint32_t n_slots;               // slots in use this render (multiple of 64)
+    uint32_t n_slots;               // slots in use this render (multiple of 64): n_main + n_surv
     uint32_t capacity;              // slots allocated
+    // Rolling sequences: slots [0, n_main) render the static path sequence g = slot, slot + n_main, ... (n_main = two
+    // renders' worth, so a slot's next path is supplied two calls after its current one: plenty of time to finish);
+    // slots [n_main, n_main + n_surv) are the SURVIVOR AREA: a path that is still alive when its slot's next path has
+    // been supplied moves there (wf_shade<0> writes its state back to a free survivor slot instead of its own), so the
+    // slot starts the new render's path on time and the wake launch stays one coherent generate pass.  Survivor slots
+    // never regenerate.  Plain renders: n_main = n_slots, n_surv = 0.
+    uint32_t n_main, n_surv;
+    uint32_t *surv_cursor;          // survivor batches claimed so far (device; one returning atomic per claim)
+    uint32_t tail_share;            // tail kernel: 1, 2 or 4 waves share every batch (16 paths per wave walk four lanes per ray from the first bounce)
+    uint32_t surv_claims_max;       // claims one wave may make per launch: n_waves * max <= survivor batches, so no batch is claimed twice in a launch
 };
 
 }  // namespace bfd

@@ -81,9 +81,46 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
            (__float_as_int(ch.w) != kNoNode && slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, ohi, mint, tmax, tn));
 }
 
+// Survivor-area allocation of a wave (rolling sequences, bf_wavefront.h: WF::n_surv).  The wave claims whole survivor
+// batches with one returning atomic each and hands their free slots — bits not alive in the parity being consumed; the
+// claim is exclusive for the launch — to the lanes that evict a path.  A wave that exhausts its claims (or finds only
+// full batches) leaves the remaining paths where they are: they then run late, which is slower, never wrong.
+struct SurvAlloc {
+    unsigned long long free;    // unclaimed free slots of the current batch (wave-uniform)
+    uint32_t batch, claims;
+};
+BF_DEV void surv_take(const WF &wf, int cur, SurvAlloc &sv, unsigned long long em, bool &evict, uint32_t &dst, int lane) {
+    const uint32_t need = (uint32_t) __popcll(em), rank = (uint32_t) __popcll(em & ((1ull << lane) - 1ull));
+    const uint32_t main_b = wf.n_main >> 6, surv_b = wf.n_surv >> 6;
+    uint32_t served = 0;
+    while (served < need) {
+        if (sv.free == 0ull) {
+            if (sv.claims >= wf.surv_claims_max || surv_b == 0u) break;
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(wf.surv_cursor, 1u);
+            c = (uint32_t) __shfl((int) c, 0);
+            sv.batch = main_b + c % surv_b;
+            sv.free = ~wf.m_alive[cur][sv.batch];
+            ++sv.claims;
+            continue;
+        }
+        const uint32_t cnt = (uint32_t) __popcll(sv.free), take = min(need - served, cnt);
+        if (evict && rank >= served && rank < served + take) dst = sv.batch * 64u + nth_set_bit(sv.free, rank - served);
+        if (take == cnt) {
+            sv.free = 0ull;
+        } else {
+            const uint32_t p = nth_set_bit(sv.free, take - 1u);
+            sv.free &= ~((2ull << p) - 1ull);
+        }
+        served += take;
+    }
+    if (evict && rank >= served) evict = false;        // no room: the path stays in its slot
+}
+
 // wf_shade: one lane per live slot (see the file header of bf_wavefront.h).
 //   FIRST = 0 : walk the alive masks of the current parity.
 //   FIRST = 1 : bounce 0 of a render (or of a rolling sequence): every slot < n_slots starts its first path.
+//   FIRST = 3 : as 0, and paths whose slot is due for its next path move to the survivor area (first launch of a rolling call).
 //   FIRST = 2 : "wake" launch of a rolling sequence (bf_render_device with BF_FLAG_ROLLING): the path supply has just
 //               grown by one render, so every slot that is NOT alive — it ran out of paths during an earlier call —
 //               starts its next path (the one after the last it finished: wf.sd keeps that index for dead slots).
@@ -107,15 +144,20 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     extern __shared__ __align__(16) unsigned char s_raw[];
     float *s_hist = reinterpret_cast<float *>(s_raw);
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr bool WALK = FIRST == 0 || FIRST == 3;      // the launch walks the alive masks (else: whole batches of main slots)
+    constexpr bool EVICT = FIRST == 3;                   // ... and moves long paths to the survivor area (own variant: the
+                                                         // allocator's live values would cost wf_shade<0> its scratch-free build)
     const bool lds_hist = lp.lds_hist != 0;
-    if (lds_hist) {
-        for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) s_hist[i] = 0.f;
+    if (lp.lds_floats) {
+        for (uint32_t i = tid; i < lp.lds_floats; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
     const int cur = it & 1, nxt = cur ^ 1;
     const bool receive = mode_receive<RX>(lp);
-    const uint32_t n_batches = wf.n_slots >> 6;
+    // the first / wake launches start paths: main slots only (the survivor area never regenerates)
+    const uint32_t n_batches = (WALK ? wf.n_slots : wf.n_main) >> 6;
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
+    SurvAlloc sv = {0ull, 0u, 0u};
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
     uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0, c_loads = 0, c_shq = 0;
@@ -125,25 +167,23 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     unsigned long long slt_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    // contiguous segment of batches per wave
+    // interleaved share of the batches per wave (MaskCursor; the first / wake launches: batches wave_id, wave_id + n_waves, ...)
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
-    const uint32_t per = (n_batches + n_waves - 1) / n_waves;
-    const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
     MaskCursor cur_alive;
-    if (!FIRST) cursor_init(cur_alive, wf.m_alive[cur], b0, b1, lane);
-    uint32_t first_b = b0;
+    if (WALK) cursor_init(cur_alive, wf.m_alive[cur], wave_id, n_waves, n_batches, lane);
+    uint32_t first_b = wave_id;
     const bool rolling = lp.roll != nullptr;
 
     while (true) {
         // ---- gather up to 64 live slots of the segment into the lanes -----------
         uint32_t slot = 0, got;
         bool aligned;
-        if (FIRST) {
-            if (first_b >= b1) break;
+        if (!WALK) {
+            if (first_b >= n_batches) break;
             slot = first_b * 64u + lane;
             got = 64;
             aligned = true;
-            ++first_b;
+            first_b += n_waves;
         } else {
             cursor_skip_empty(cur_alive, lane);
             if (cursor_empty(cur_alive)) break;
@@ -156,7 +196,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         }
         bool has = (uint32_t) lane < got;
         const uint32_t batch0 = slot >> 6;
-        if (FIRST == 2) has = ((wf.m_alive[cur][batch0] >> lane) & 1ull) == 0ull;      // wake: only the slots without a live path
+        // wake: only the slots without a live path — as of NOW: wf_shade<0> of this iteration has run, so a slot whose path
+        // ended there, or moved to the survivor area, is free
+        if (FIRST == 2) has = ((m_alive[batch0] >> lane) & 1ull) == 0ull;
 
         PathState s;
         s.render = 0u;                 // lanes without a path still index the batch tables (path_shift)
@@ -172,11 +214,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         SLP(0, has);
         SLT(0);
         if (has) {
-            if (FIRST) {
+            if (!WALK) {
                 need_gen = true;
                 // the path BEFORE the one this slot starts now: slot - n_slots for a fresh pool (wraps: + n_slots = slot),
                 // the slot's last finished path in a wake launch
-                s.path_i = (uint64_t) slot - (uint64_t) wf.n_slots;
+                s.path_i = (uint64_t) slot - (uint64_t) wf.n_main;
                 if (FIRST == 2) {
                     const uint4 d = wf.sd[slot];
                     s.path_i = ((uint64_t) d.w << 32) | d.z;
@@ -209,6 +251,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         // visit.  Two thirds of all rays resolve that way; each chained round saves a state round trip
         // through HBM and, for paths that leave the scene, a whole bounce iteration.
         bool settled = !has;          // this lane's outcome for the launch is final
+        // the slot's path index in wf.sd needs (re)writing if its path ends here: always, except for the idle slots a wake
+        // launch finds not due yet (their entry stands); the first launch of a pool writes the initial entries
+        bool touched = FIRST != 2;
         bool tracing = false, shadowing = false;
         for (uint32_t round = 0;; ++round) {
             // ---- vertex logic ---------------------------------------------------------------
@@ -236,8 +281,9 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             if (!settled && need_gen) {
                 need_gen = false;
                 cont = false;
-                const uint64_t path_i = s.path_i + wf.n_slots;
-                if (path_i < lp.n_paths) {
+                const uint64_t path_i = s.path_i + wf.n_main;
+                if (slot < wf.n_main && path_i < lp.n_paths) {
+                    touched = true;
                     generate_path<RX>(sc, lp, path_i, s);
                     sh.want = false;
                     ++c_closest;
@@ -294,21 +340,30 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         // ---- write back in place ----------------------------------------------------------------
         SLP(20, has && cont);
         SLP(21, has && cont && shadowing);
+        // rolling sequence, first launch of a call: a path that goes on while its slot's NEXT path has been supplied moves
+        // to the survivor area (its state is in registers anyway: the write-back simply goes to another slot)
+        bool evict = false;
+        uint32_t dst = slot;
+        if (EVICT) {
+            evict = has && cont && slot < wf.n_main && s.path_i + wf.n_main < lp.n_paths;
+            const unsigned long long em = __ballot(evict);
+            if (em) surv_take(wf, cur, sv, em, evict, dst, lane);
+        }
         if (has && cont) {
             if (!(s.flags & kFlagTermPending)) {
                 // resolved rays carry their final hit; the others start wf_trace from the rectangle hit
-                wf.hit[slot] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
-                wf.hit_prim[slot] = hit.prim;
+                wf.hit[dst] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
+                wf.hit_prim[dst] = hit.prim;
             }
-            store_state(wf, slot, receive, s);
+            store_state(wf, dst, receive, s);
             ++c_live;
             if (shadowing) {
-                wf.sh0[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
-                wf.sh1[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
-                wf.sh2[slot] = sh.c;
-                if (receive && lp.iq) wf.sh3[slot] = sh.c_im;
+                wf.sh0[dst] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
+                wf.sh1[dst] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
+                wf.sh2[dst] = sh.c;
+                if (receive && lp.iq) wf.sh3[dst] = sh.c_im;
             }
-        } else if (has && rolling) {
+        } else if (has && rolling && touched) {
             // the slot has run out of paths for now: remember the last one it rendered, so that the wake launch of the
             // sequence's next call continues from there (a path that started and ended within this visit was never stored)
             wf.sd[slot] = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
@@ -316,9 +371,15 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         cont = has && cont;
         tracing = cont && tracing;
         shadowing = cont && shadowing;
-        publish_masks(m_alive, aligned, FIRST == 2, batch0, slot, has, cont);
-        publish_masks(m_trace, aligned, FIRST == 2, batch0, slot, has, tracing);
-        publish_masks(m_shadow, aligned, FIRST == 2, batch0, slot, has, shadowing);
+        publish_masks(m_alive, aligned, FIRST == 2, batch0, slot, has, cont && !evict);
+        publish_masks(m_trace, aligned, FIRST == 2, batch0, slot, has, tracing && !evict);
+        publish_masks(m_shadow, aligned, FIRST == 2, batch0, slot, has, shadowing && !evict);
+        if (evict) {                 // the moved path's bits go to its new slot (the batch's owner ORs its own in as well)
+            const unsigned long long bit = 1ull << (dst & 63u);
+            atomicOr(&m_alive[dst >> 6], bit);
+            if (tracing) atomicOr(&m_trace[dst >> 6], bit);
+            if (shadowing) atomicOr(&m_shadow[dst >> 6], bit);
+        }
         c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
         c_shq += shadowing ? 1u : 0u;
         SLT(6);
@@ -395,10 +456,8 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     LaneStack<kLdsStack, true> st = make_stack<kLdsStack, true>(sc, stack);
     const uint32_t n_batches = wf.n_slots >> 6;
-    const uint32_t per = (n_batches + n_waves - 1) / n_waves;
-    const uint32_t b0 = min(wave_id * per, n_batches), b1 = min(b0 + per, n_batches);
     MaskCursor cursor;
-    cursor_init(cursor, wf.m_shadow[nxt], b0, b1, lane);
+    cursor_init(cursor, wf.m_shadow[nxt], wave_id, n_waves, n_batches, lane);
     bool phase_shadow = true;       // wave-uniform: which job list the cursor walks
 
     bool has = false, any = false;
@@ -472,7 +531,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 want -= got;
                 if (want && cursor_empty(cursor) && phase_shadow) {
                     phase_shadow = false;                       // shadow rays done: closest-hit rays next
-                    cursor_init(cursor, wf.m_trace[nxt], b0, b1, lane);
+                    cursor_init(cursor, wf.m_trace[nxt], wave_id, n_waves, n_batches, lane);
                 }
             }
         }
@@ -591,7 +650,9 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
     else                                                                                                                         \
         hipLaunchKernelGGL((bfd::wf_shade<F, W, 0>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
                            records)
-    if (first == 2) {
+    if (first == 3) {
+        BF_SHADE_LAUNCH(3, 3);
+    } else if (first == 2) {
         BF_SHADE_LAUNCH(2, 3);
     } else if (first) {
         BF_SHADE_LAUNCH(1, 3);

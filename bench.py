@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-paths", type=int, default=0, help="bounded sample for the CPU baseline; 0 = the config's")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams (scene handles) the steps rotate over; 0 = the config's")
+    ap.add_argument("--rolling", type=int, default=1, help="1: the steps of a handle form a rolling sequence (BF_FLAG_ROLLING), flushed at the "
+                    "end of the timed region; 0: every step is a stand-alone render with its own tail (round 2's scheme)")
     return ap.parse_args()
 
 
@@ -86,14 +88,14 @@ class Workload:
             self.label = ("C2 bus_radar: synthetic %d-triangle bus (Bus.obj stand-in) + 20x20 m ground, monostatic 20x50 mm TX "
                           "aperture + perspective RX, gen-2 range(pathlength) integrator, 256 range bins dr=0.1 m, 64 spp x %d "
                           "pulses = %d paths per GPU per step")
-            self.streams = args.streams or 8
+            self.streams = args.streams or (2 if args.rolling else 8)
             self.cpu_paths = args.cpu_paths or (1 << 24)
         elif cfg == "c3":
             paths = args.paths or (1 << 20)
             self.sd, self.lp = scenes.car_radar(n_tris=1_000_000, n_paths=paths, bins=1024, dr=0.03, seed=2)
             self.label = ("C3 car_radar: synthetic %d-triangle car-body shell with vertex normals (Car-body.ply stand-in) + "
                           "ground, gen-2 range(pathlength), 1024 range bins dr=0.03 m, 2^20 primary rays: %d x 64 = %d paths per GPU per step")
-            self.streams = args.streams or 8
+            self.streams = args.streams or (4 if args.rolling else 8)
             self.cpu_paths = args.cpu_paths or (1 << 22)
         elif cfg in ("c4shard", "c4"):
             total = 4096 << 10
@@ -101,7 +103,7 @@ class Workload:
             self.sd, self.lp = scenes.multi_mesh_radar(n_paths=paths, bins=4096, dr=0.01, seed=3)
             self.label = ("C4 multi_mesh_radar: bus + car + motorbike (%d triangles) on the ground, gen-2 range(pathlength), 4096 "
                           "range bins; %d x 64 = %d paths per step (the configured 4096 spp x 2^10 = 2^22 paths are 8 such shards)")
-            self.streams = args.streams or 8
+            self.streams = args.streams or (4 if args.rolling else 8)
             self.cpu_paths = args.cpu_paths or (1 << 22)
         else:
             paths = args.paths or (1 << 20)
@@ -147,7 +149,8 @@ STAT_KEYS = ("n_paths", "n_rays_closest", "n_rays_shadow", "n_nodes_visited", "n
 def add_stats(acc, st):
     for k in STAT_KEYS:
         acc[k] = acc.get(k, 0) + getattr(st, k)
-    acc["n_tail_launches"] = acc.get("n_tail_launches", 0) + (1 if st.tail_ms > 0 else 0)
+    acc["n_tail_launches"] = acc.get("n_tail_launches", 0) + (st.n_launches_tail or (1 if st.tail_ms > 0 else 0))
+    acc["n_shade_launches"] = acc.get("n_shade_launches", 0) + (st.n_launches_shade or st.n_bounce_iters)
 
 
 def main():
@@ -183,29 +186,31 @@ def main():
 
     w = Workload(args, rank, world, capi, scenes)
     n_streams = max(1, w.streams)
+    rolling = bool(args.rolling) and not w.sweep
     first = capi.Scene(w.sd, lib)                                  # ONE BVH build / upload ...
     handles = [first] + [first.clone() for _ in range(n_streams - 1)]   # ... shared by the stream handles
     info = first.info()
     n_chan = first.channels(w.lp)
-    n_hist = n_chan * (w.n_pulses if w.sweep else 1)
-    hists = [torch.zeros(n_hist, dtype=torch.float32, device=dev) for _ in range(n_streams)]
+    # one histogram PER STEP (a rolling render's histogram is complete only after the flush), one cube per sweep
+    n_rows = 1 if w.sweep else max(args.steps, args.warmup, n_streams)
+    hists = torch.zeros((n_rows, n_chan * (w.n_pulses if w.sweep else 1)), dtype=torch.float32, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    roll_flag = capi.BF_FLAG_ROLLING if rolling else 0
 
-    def step(i, acc=None, flags=0):
-        """Issue step i; with `acc` (a dict) the call is synchronous and the step's bf_stats are added to it."""
-        want = acc is not None
-        l = w.launch(i, flags)
+    def step(i, acc=None, flags=0, only=None):
+        """Issue step i (on handle `only`, else i mod n_streams).  Stand-alone renders with `acc` (a dict) are synchronous
+        and add their bf_stats to it; rolling renders report through finish()."""
+        want = acc is not None and not rolling
+        l = w.launch(i, flags | roll_flag)
         if not w.sweep:
-            j = i % n_streams
+            j = i % n_streams if only is None else only
             with torch.cuda.stream(streams[j]):
-                hists[j].zero_()
-                st = handles[j].render_device(l, hists[j].data_ptr(), stream=streams[j].cuda_stream, want_stats=want)
-                if world > 1:
-                    dist.all_reduce(hists[j])     # RCCL sum of the per-GPU range histograms over xGMI
+                st = handles[j].render_device(l, hists[i].data_ptr(), stream=streams[j].cuda_stream, want_stats=want)
             if want:
                 add_stats(acc, st)
             return
         # c5: one sweep = n_streams batches of pulses (one launch sequence each), cube accumulated in hists[0]
+        want = acc is not None
         cube = hists[0]
         for s in streams:
             s.wait_stream(torch.cuda.current_stream(dev))
@@ -229,34 +234,82 @@ def main():
             with torch.cuda.stream(streams[0]):
                 dist.all_reduce(cube)             # one all-reduce of the whole slow-time x fast-time cube
 
+    def begin(n):
+        """Zero the histograms of the next n steps (stream-ordered before every handle's work)."""
+        if w.sweep:
+            return
+        hists[:n].zero_()
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(dev))
+
+    def finish(n, acc=None):
+        """End of a region of n steps: flush every handle's rolling sequence (the ONE tail per handle), then, for N > 1, one
+        RCCL all-reduce of all n per-step range histograms over xGMI (they are complete only now)."""
+        if w.sweep:
+            return
+        for j in range(n_streams):
+            st = handles[j].flush(stream=streams[j].cuda_stream, want_stats=acc is not None and rolling)
+            if st is not None and st.n_paths:
+                add_stats(acc, st)
+        if world > 1:
+            cur = torch.cuda.current_stream(dev)
+            for s in streams:
+                cur.wait_stream(s)
+            dist.all_reduce(hists[:n])
+
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # every scene handle allocates its path pool and learns its launch plan on first use: touch each once (untimed,
-    # before the W warm-up steps) so neither pass below pays for that
-    for j in range(n_streams if not w.sweep else 1):
-        step(j)
-    sync()
+    # every scene handle allocates its path pool and learns its launch plan (and its flush plan) on first use: touch each
+    # once (untimed, before the W warm-up steps) so neither pass below pays for that
+    for rep in range(2 if rolling else 1):
+        begin(n_streams)
+        for j in range(n_streams if not w.sweep else 1):
+            step(j)
+        finish(n_streams)
+        sync()
+    begin(args.warmup)
     for i in range(args.warmup):
         step(i)
+    finish(args.warmup)
     sync()
 
     # (A) counters of the timed region's steps: BF_FLAG_STATS counts node visits and triangle tests per kernel (the
     #     instrumented kernel variants; untimed).  (B) per-kernel HIP-event durations of the same steps, serial,
-    #     product kernels.  Same seeds as the timed region below => same rays.
+    #     product kernels.  Same seeds as the timed region below => same rays.  With rolling sequences both passes run the
+    #     K steps as ONE sequence on ONE handle (every launch alone on the GPU) and read the sequence's totals at its flush.
     cnt, tim = {}, {}
+    one = 0 if rolling else None
+    begin(args.steps)
     for i in range(args.steps):
-        step(i, acc=cnt, flags=capi.BF_FLAG_STATS)
+        step(i, acc=cnt, flags=capi.BF_FLAG_STATS, only=one)
+    finish(args.steps, acc=cnt)
+    sync()
+    begin(args.steps)
     for i in range(args.steps):
-        step(i, acc=tim)
+        step(i, acc=tim, flags=capi.BF_FLAG_TIMING if rolling else 0, only=one)
+    finish(args.steps, acc=tim)
+    sync()
 
-    # timed region: EXACTLY `steps` steps, no instrumentation, barrier + synchronize on both sides
+    # (C) a few stand-alone renders (their own tail each, nothing else on the GPU): the latency of ONE render, which is what
+    #     an 8-GPU strong-scaled render of this config cannot go below (DESIGN.md 6)
+    iso = {}
+    if not w.sweep:
+        for i in range(min(args.steps, 5)):
+            with torch.cuda.stream(streams[0]):
+                add_stats(iso, handles[0].render_device(w.launch(i, 0), hists[i].data_ptr(), stream=streams[0].cuda_stream, want_stats=True))
+        iso["n"] = min(args.steps, 5)
+
+    # timed region: EXACTLY `steps` steps, no instrumentation, barrier + synchronize on both sides; every histogram of the
+    # region is complete (flushed, and reduced for N > 1) when the clock stops
     sync()
     t0 = time.perf_counter()
+    begin(args.steps)
     for i in range(args.steps):
         step(i)
+    finish(args.steps)
     sync()
     dt = time.perf_counter() - t0
 
@@ -283,18 +336,26 @@ def main():
         # algorithmic bytes: traversal = V_n S_n + V_t S_t + S_q per ray with the node size of
         # the tree that was walked; shading = state rows read / written + triangle & normals of the shaded hit (96 B) +
         # the root node (128 B) each new ray is tested against in wf_shade
-        b_trace = n4_trace * S_n + t_trace * S_t + cnt["n_rays_traced"] * S_q
+        # Node visits of wf_trace served from its LDS copy of the tree's top 85 nodes never reach the memory pipe: they are
+        # NOT priced (pricing them at 128 B each made the headline 0.47 instead of 0.32); the figure with them
+        # is printed next to it (frac_with_lds_served_nodes: the letter of SURVEY 8d, every visit x node size)
+        n4_lds = cnt["n_nodes_lds"]
+        b_trace_lds = n4_lds * S_n
+        b_trace = (n4_trace - n4_lds) * S_n + t_trace * S_t + cnt["n_rays_traced"] * S_q
         b_tail = (n4_tail * S_n + n16_tail * S_w + cnt["n_tris_tail"] * S_t + cnt["n_rays_tail"] * S_q + cnt["n_bounces_tail"] * 96.0)
         b_shade = (cnt["n_shade_loads"] * row + cnt["n_shade_stores"] * row + cnt["n_shade_shadow"] * 36.0 +
                    (cnt["n_bounces"] - cnt["n_bounces_tail"]) * 96.0 + cnt["n_shade_rays"] * S_n)
-        b_traversal_all = (n4_trace + n4_tail) * S_n + n16_tail * S_w + cnt["n_tris_tested"] * S_t + rays * S_q
+        b_traversal_all = (n4_trace - n4_lds + n4_tail) * S_n + n16_tail * S_w + cnt["n_tris_tested"] * S_t + rays * S_q
         ms = {"wf_trace": tim["trace_ms"], "wf_shade": tim["shade_ms"], "tail": tim["tail_ms"]}
-        launches = {"wf_trace": max(tim["n_launches_trace"], 1), "wf_shade": max(tim["n_bounce_iters"], 1),
+        launches = {"wf_trace": max(tim["n_launches_trace"], 1), "wf_shade": max(tim["n_shade_launches"], 1),
                     "tail": max(tim["n_tail_launches"], 1)}
         bytes_ = {"wf_trace": b_trace, "wf_shade": b_shade, "tail": b_tail}
-        names = {"wf_trace": "bfd::wf_trace<false, 5, %s>" % ("true" if w.sweep else "false"),
-                 "wf_shade": "bfd::wf_shade<*, 3>", "tail": "bfd::bf_render_kernel<false, true, *> (tail)"}
-        traffic = pmc_traffic(w, args)
+        # the symbols rocprofv3 prints (template arguments: wf_trace<STATS, W, SHIFT, QUANT>, wf_shade<FIRST, W, RX> with
+        # FIRST = 0 alive masks / 1 first bounce / 2 wake launch, bf_render_kernel<STATS, RESUME, SPILL, TW>)
+        names = {"wf_trace": "bfd::wf_trace<false, 5, %s, false>" % ("true" if w.sweep else "false"),
+                 "wf_shade": "bfd::wf_shade<0|1|2, 3, %d>" % (1 if w.receive else 0),
+                 "tail": "bfd::bf_render_kernel<false, true, %s, 3> (tail)" % ("true" if info.bvh_stack_need > 32 else "false")}
+        traffic = pmc_traffic(w, args, rolling, n_streams)
         total_ms = sum(ms.values()) or 1.0
         kernels = []
         for k in sorted(ms, key=lambda k: -ms[k]):
@@ -308,10 +369,15 @@ def main():
                 "algorithmic_bytes_per_launch": round(per_launch), "achieved": round(ach, 2), "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "frac_of_cache_gather_ceiling": round(ach / CACHE_GATHER_GBS, 5),
                 "traffic": tr, "traffic_over_algorithmic": (round(tr / per_launch, 3) if tr and per_launch else None),
+                "frac_by_counter_traffic": (round(tr / avg_s / 1e9 / HBM_PEAK_GBS, 5) if tr and avg_s > 0 else None),
             })
+            if k == "wf_trace":
+                kernels[-1]["frac_with_lds_served_nodes"] = round((per_launch + b_trace_lds / launches[k]) / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else 0.0
         step_s = dt / K
         whole = b_traversal_all / K / step_s / 1e9
         whole_serial = b_traversal_all / (tim["kernel_ms"] / 1e3) / 1e9
+        whole_with_lds = (b_traversal_all + b_trace_lds) / K / step_s / 1e9
+        traffic_step = (sum(kk["traffic"] * kk["launches_per_step"] for kk in kernels) if traffic and all(kk["traffic"] for kk in kernels) else None)
         mrays = rays_all / dt / 1e6
         out = {
             "metric": "Mrays/s (closest + any-hit BVH queries), %s" % {"c2": "Bus.obj-class radar scene", "c3": "Car-body.ply-class scene",
@@ -337,21 +403,26 @@ def main():
                 "bvh_nodes": int(info.n_bvh_nodes),
                 "parallelism": "sample-sharded x%d (%s), RCCL all-reduce of the histogram" % (world, args.scaling),
                 "streams": n_streams,
+                "rolling": rolling,
                 "mpaths_per_s": round(paths_all / dt / 1e6, 2),
                 "rays_per_path": round(rays_all / paths_all, 3),
             },
             "roofline": {
                 "bound": "hbm",
-                "scope": "whole path: traversal bytes of ALL rays of a step (V_n S_n + V_t S_t + S_q, SURVEY 8d) / ms_per_step",
+                "scope": "whole path: traversal bytes of ALL rays of a step (V_n S_n + V_t S_t + S_q, SURVEY 8d; node visits served from "
+                         "wf_trace's LDS copy of the top of the tree are not priced) / ms_per_step",
                 "kernel": kernels[0]["kernel"],
                 "achieved": round(whole, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(whole / HBM_PEAK_GBS, 5),
                 "frac_serial": round(whole_serial / HBM_PEAK_GBS, 5),
-                "traffic": (round(sum(kk["traffic"] * kk["launches_per_step"] for kk in kernels)) if traffic and all(kk["traffic"] for kk in kernels) else None),
+                "frac_with_lds_served_nodes": round(whole_with_lds / HBM_PEAK_GBS, 5),
+                "frac_by_counter_traffic": (round(traffic_step / step_s / 1e9 / HBM_PEAK_GBS, 5) if traffic_step else None),
+                "traffic": (round(traffic_step) if traffic_step else None),
                 "traffic_note": "HBM bytes per step / per launch: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes, "
-                                "profiles/r02_pmc_traffic.json (tools/profile_r02.sh); null when this run's shape differs from the profiled one",
+                                "profiles/r03_pmc_traffic.json (tools/profile_r03.sh), stamped with a hash of beifong_amd/csrc: null when "
+                                "the kernels, the workload shape or the scheduling (rolling, streams) differ from the profiled run",
                 "bytes_per_ray": round(b_traversal_all / rays, 1),
                 "nodes_per_ray": round((n4_trace + n4_tail + n16_tail) / rays, 2),
                 "tris_per_ray": round(cnt["n_tris_tested"] / rays, 2),
@@ -371,7 +442,8 @@ def main():
         if world == 1 and w.cfg in ("c3", "c4shard", "c4", "c2"):
             # what an 8-GPU strong-scaled render of this config would see: per-GPU time of 1/8 of the paths cannot drop
             # below the tail
-            out["config"]["isolated_step_ms"] = round(tim["kernel_ms"] / K, 3)
+            out["config"]["isolated_step_ms"] = round(iso["kernel_ms"] / iso["n"], 3)
+            out["config"]["isolated_tail_ms"] = round(iso["tail_ms"] / iso["n"], 3)
             out["config"]["tail_ms_per_step"] = round(tim["tail_ms"] / K, 3)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, args)
@@ -381,14 +453,28 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(w, args):
+def csrc_hash():
+    """sha256 over the kernel and host sources of libbeifong_hip.so (what the committed PMC summary was measured on)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "beifong_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(w, args, rolling, n_streams):
     """HBM bytes per launch of each kernel from the committed PMC summary of the same workload shape (PMC counters cannot
-    be read from inside this process: separate rocprofv3 --pmc passes, tools/profile_r02.sh)."""
+    be read from inside this process: separate rocprofv3 --pmc passes, tools/profile_r03.sh).  The summary carries a hash
+    of beifong_amd/csrc: a kernel change makes it stale and the entry null, not silently wrong."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             pt = json.load(f)
         e = pt.get(w.cfg)
-        if not e or e.get("paths") != w.paths or args.tris not in (0, 200_000):
+        if pt.get("csrc_sha16") != csrc_hash() or not e or e.get("paths") != w.paths or args.tris not in (0, 200_000):
+            return None
+        if bool(e.get("rolling")) != bool(rolling):
             return None
         return {k: float(v) for k, v in e["traffic_bytes_per_launch"].items()}
     except (OSError, ValueError, KeyError):

@@ -291,7 +291,8 @@ typedef struct bf_stats {
     uint64_t n_guard;          /* rays dropped by wf_trace's iteration guard: always 0, else the
                                   render call fails with BF_ERR_DEVICE                        */
     uint32_t n_launches_tail;  /* tail kernel launches (timed renders / sequences)            */
-    uint32_t reserved_;
+    uint32_t n_launches_shade; /* wf_shade launches (timed renders / sequences: a rolling call has one more than
+                                  bounce iterations, its wake launch)                          */
 } bf_stats;
 
 typedef struct bf_scene_info {
