@@ -113,7 +113,7 @@ class bf_scene_info(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("n_rects", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("n_bvh_nodes", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32), ("trace_node_bytes", C.c_uint32)]
+                ("bvh_depth", C.c_uint32), ("bvh_stack_need", C.c_uint32), ("trace_node_bytes", C.c_uint32), ("device", C.c_int32)]
 
 
 class bf_batch(C.Structure):
@@ -127,7 +127,7 @@ ABI_STRUCTS = [bf_material, bf_shape, bf_emitter, bf_sensor, bf_scene_desc, bf_l
 EXPORTED_SYMBOLS = [
     "bf_abi_sizeof", "bf_abi_fingerprint", "bf_version", "bf_last_error", "bf_device_count", "bf_set_device", "bf_scene_create",
     "bf_scene_destroy", "bf_scene_update_endpoints", "bf_scene_translate_meshes", "bf_scene_get_info", "bf_scene_clone", "bf_launch_channels", "bf_render_device", "bf_render",
-    "bf_scene_flush", "bf_scene_sync",
+    "bf_scene_flush", "bf_scene_sync", "bf_shard_range", "bf_render_sharded_device", "bf_render_sharded", "bf_allreduce_device",
     "bf_render_batch_device", "bf_render_batch",
     "bf_trace_closest", "bf_trace_any", "bf_ray_intersect", "bf_eval_elementary",
 ]
@@ -176,6 +176,11 @@ def load_library(path=None):
     lib.bf_render.argtypes = [vp, C.POINTER(bf_launch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_scene_flush.argtypes = [vp, vp, C.POINTER(bf_stats)]
     lib.bf_scene_sync.argtypes = [vp]
+    lib.bf_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bf_shard_range.restype = None
+    lib.bf_render_sharded_device.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(bf_launch), C.POINTER(vp), C.POINTER(vp), C.POINTER(bf_stats)]
+    lib.bf_render_sharded.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(bf_launch), vp, C.POINTER(bf_stats)]
+    lib.bf_allreduce_device.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp), C.c_uint64, C.POINTER(vp)]
     lib.bf_render_batch_device.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, vp, C.POINTER(bf_stats)]
     lib.bf_render_batch.argtypes = [vp, C.POINTER(bf_launch), C.POINTER(bf_batch), vp, vp, C.POINTER(bf_stats)]
     lib.bf_trace_closest.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
@@ -209,6 +214,35 @@ def make_launch(mode, n_paths, seed=0, path_offset=0, bins=0, bin_width=0.0, col
     lp.bins_y = bins_y
     lp.phase_bins = phase_bins
     return lp
+
+
+def shard_range(n_paths, shard, n_shards, lib=None):
+    """bf_shard_range: (offset, count) of shard `shard` of `n_shards` — the partition every multi-GPU driver uses
+    (beifong_amd.dist.shard_range is the same arithmetic in Python)."""
+    lib = lib or load_library()
+    off, cnt = C.c_uint64(), C.c_uint64()
+    lib.bf_shard_range(n_paths, shard, n_shards, C.byref(off), C.byref(cnt))
+    return off.value, cnt.value
+
+
+def render_sharded(scenes, launch, lib=None):
+    """bf_render_sharded: ONE render split over the GPUs of `scenes` (one handle per GPU), host histogram + summed stats."""
+    lib = lib or load_library()
+    n = scenes[0].channels(launch)
+    hist = np.zeros(n, dtype=np.float32)
+    st = bf_stats()
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    check(lib, lib.bf_render_sharded(handles, len(scenes), C.byref(launch), _ptr(hist), C.byref(st)), "bf_render_sharded")
+    return hist, st
+
+
+def render_sharded_device(scenes, launch, hist_ptrs, streams=None, lib=None):
+    """bf_render_sharded_device: hist_ptrs[g] is a device pointer on scenes[g]'s GPU; all-reduced on completion."""
+    lib = lib or load_library()
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    hp = (C.c_void_p * len(scenes))(*[C.c_void_p(int(p)) for p in hist_ptrs])
+    sp = (C.c_void_p * len(scenes))(*[C.c_void_p(int(x)) if x else None for x in streams]) if streams is not None else None
+    check(lib, lib.bf_render_sharded_device(handles, len(scenes), C.byref(launch), hp, sp, None), "bf_render_sharded_device")
 
 
 class Scene:

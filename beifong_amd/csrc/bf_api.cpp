@@ -14,6 +14,12 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (bf_allreduce_device)
+
+#include <map>
+#include <mutex>
+
 #include "bf_bvh.h"
 #include "bf_device.h"
 #include "bf_wavefront.h"
@@ -244,8 +250,17 @@ namespace {
 struct BusyGuard {
     const bf_scene *s;
     bool ok;
-    explicit BusyGuard(const bf_scene *sc) : s(sc), ok(sc && !sc->busy.test_and_set(std::memory_order_acquire)) {}
+    int prev_device = -1;
+    // ... and every call runs on the handle's own device, whatever the caller's current one is (one host thread may
+    // drive the handles of several GPUs: bf_render_sharded_device), restored on return
+    explicit BusyGuard(const bf_scene *sc) : s(sc), ok(sc && !sc->busy.test_and_set(std::memory_order_acquire)) {
+        if (ok) {
+            int cur = -1;
+            if (hipGetDevice(&cur) == hipSuccess && cur != sc->device && hipSetDevice(sc->device) == hipSuccess) prev_device = cur;
+        }
+    }
     ~BusyGuard() {
+        if (prev_device >= 0) (void) hipSetDevice(prev_device);
         if (ok) s->busy.clear(std::memory_order_release);
     }
 };
@@ -966,6 +981,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
 bf_status bf_scene_get_info(const bf_scene *scene, bf_scene_info *info) {
     if (!scene || !info) return fail(BF_ERR_INVALID, "null argument");
     *info = scene->info;
+    info->device = scene->device;
     return BF_OK;
 }
 
@@ -1908,6 +1924,195 @@ bf_status bfdbg_hold_busy(bf_scene *scene, int on) {
         scene->busy.clear(std::memory_order_release);
     }
     return BF_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// One process, several GPUs (bf_launch.device_mask; 8e: sample shards + one all-reduce).  Paths are i.i.d.:
+// GPU g of G renders the global path indices bf_shard_range(n, g, G) of the launch through bf_launch.path_offset — the
+// union is the sample set of a one-GPU render — and the per-GPU range histograms are summed by ONE ncclAllReduce(float,
+// sum) over xGMI.  RCCL is loaded on first use (dlopen: a process that never shards needs no librccl, and one that
+// already carries a copy — PyTorch ships its own — keeps using that one).
+// ---------------------------------------------------------------------------
+void bf_shard_range(uint64_t n_paths, uint32_t shard, uint32_t n_shards, uint64_t *offset, uint64_t *count) {
+    if (n_shards == 0) n_shards = 1;
+    // floor(n s / S) without overflowing 64 bits for n < 2^63, S < 2^32
+    auto cut = [&](uint64_t k) -> uint64_t { return (uint64_t) (((unsigned __int128) n_paths * k) / n_shards); };
+    const uint64_t lo = cut(shard), hi = cut((uint64_t) shard + 1u);
+    if (offset) *offset = lo;
+    if (count) *count = hi - lo;
+}
+
+extern "C++" {
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string why;
+};
+Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl q;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)      // a copy that is already in the process (torch's) first
+            if ((q.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+        for (const char *n : names) {
+            if (q.lib) break;
+            q.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!q.lib) {
+            q.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            return q;
+        }
+        q.comm_init_all = (decltype(q.comm_init_all)) dlsym(q.lib, "ncclCommInitAll");
+        q.comm_destroy = (decltype(q.comm_destroy)) dlsym(q.lib, "ncclCommDestroy");
+        q.all_reduce = (decltype(q.all_reduce)) dlsym(q.lib, "ncclAllReduce");
+        q.group_start = (decltype(q.group_start)) dlsym(q.lib, "ncclGroupStart");
+        q.group_end = (decltype(q.group_end)) dlsym(q.lib, "ncclGroupEnd");
+        q.error_string = (decltype(q.error_string)) dlsym(q.lib, "ncclGetErrorString");
+        if (!q.comm_init_all || !q.comm_destroy || !q.all_reduce || !q.group_start || !q.group_end || !q.error_string) {
+            q.why = "librccl.so lacks ncclCommInitAll / ncclAllReduce / ncclGroupStart / ncclGroupEnd";
+            q.lib = nullptr;
+        }
+        return q;
+    }();
+    return r;
+}
+// one communicator set per ordered device list, created on first use and kept for the life of the process
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
+}  // namespace
+}  // extern "C++"
+
+bf_status bf_allreduce_device(const int *devices, uint32_t n_devices, float *const *bufs, uint64_t count, void *const *streams) {
+    if (!devices || !bufs || n_devices == 0) return fail(BF_ERR_INVALID, "bf_allreduce_device: null argument");
+    if (count == 0) return BF_OK;
+    for (uint32_t g = 0; g < n_devices; ++g)
+        if (!bufs[g]) return fail(BF_ERR_INVALID, "bf_allreduce_device: buffer %u is null", g);
+    Rccl &r = rccl();
+    if (!r.lib) return fail(BF_ERR_UNSUPPORTED, "bf_allreduce_device: %s", r.why.c_str());
+    std::vector<int> key(devices, devices + n_devices);
+    for (uint32_t a = 0; a < n_devices; ++a)
+        for (uint32_t b = a + 1; b < n_devices; ++b)
+            if (key[a] == key[b]) return fail(BF_ERR_INVALID, "bf_allreduce_device: device %d is listed twice", key[a]);
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    auto it = g_comms.find(key);
+    if (it == g_comms.end()) {
+        std::vector<ncclComm_t> comms(n_devices);
+        ncclResult_t nr = r.comm_init_all(comms.data(), (int) n_devices, key.data());
+        if (nr != ncclSuccess) return fail(BF_ERR_DEVICE, "ncclCommInitAll(%u devices): %s", n_devices, r.error_string(nr));
+        it = g_comms.emplace(key, std::move(comms)).first;
+    }
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    ncclResult_t nr = r.group_start();
+    for (uint32_t g = 0; g < n_devices && nr == ncclSuccess; ++g) {
+        if (hipSetDevice(key[g]) != hipSuccess) {
+            (void) r.group_end();
+            if (prev >= 0) (void) hipSetDevice(prev);
+            return fail(BF_ERR_DEVICE, "bf_allreduce_device: hipSetDevice(%d) failed", key[g]);
+        }
+        nr = r.all_reduce(bufs[g], bufs[g], (size_t) count, ncclFloat, ncclSum, it->second[g],
+                          reinterpret_cast<hipStream_t>(streams ? streams[g] : nullptr));
+    }
+    ncclResult_t ne = r.group_end();
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return fail(BF_ERR_DEVICE, "ncclAllReduce: %s", r.error_string(nr));
+    return BF_OK;
+}
+
+bf_status bf_render_sharded_device(bf_scene *const *scenes, uint32_t n_devices, const bf_launch *launch, float *const *hist_dev,
+                                   void *const *streams, bf_stats *stats_out) {
+    if (!scenes || !launch || !hist_dev || n_devices == 0) return fail(BF_ERR_INVALID, "bf_render_sharded_device: null argument");
+    std::vector<int> devices(n_devices);
+    for (uint32_t g = 0; g < n_devices; ++g) {
+        if (!scenes[g] || !hist_dev[g]) return fail(BF_ERR_INVALID, "bf_render_sharded_device: scene / histogram %u is null", g);
+        devices[g] = scenes[g]->device;
+    }
+    if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out));
+    // every GPU's launches are enqueued before any of them is waited for (statistics wait per device, afterwards)
+    std::vector<bf_stats> per(stats_out ? n_devices : 0);
+    for (uint32_t g = 0; g < n_devices; ++g) {
+        bf_launch lg = *launch;
+        uint64_t off = 0, cnt = 0;
+        bf_shard_range(launch->n_paths, g, n_devices, &off, &cnt);
+        lg.n_paths = cnt;
+        lg.path_offset = launch->path_offset + off;
+        if (cnt == 0) continue;
+        // a render with statistics is synchronous: with them the devices take turns (diagnostics, not the fast path)
+        bf_status st = bf_render_device(scenes[g], &lg, hist_dev[g], nullptr, streams ? streams[g] : nullptr, stats_out ? &per[g] : nullptr);
+        if (st != BF_OK) return st;
+    }
+    if (stats_out) {
+        for (uint32_t g = 0; g < n_devices; ++g) {
+            const bf_stats &p = per[g];
+            stats_out->n_paths += p.n_paths;
+            stats_out->n_rays_closest += p.n_rays_closest;
+            stats_out->n_rays_shadow += p.n_rays_shadow;
+            stats_out->n_nodes_visited += p.n_nodes_visited;
+            stats_out->n_tris_tested += p.n_tris_tested;
+            stats_out->n_invalid += p.n_invalid;
+            stats_out->n_bounces += p.n_bounces;
+            stats_out->n_rays_tail += p.n_rays_tail;
+            stats_out->n_rays_traced += p.n_rays_traced;
+            stats_out->n_nodes_lds += p.n_nodes_lds;
+            stats_out->kernel_ms = std::max(stats_out->kernel_ms, p.kernel_ms);      // the devices run side by side
+            stats_out->trace_ms = std::max(stats_out->trace_ms, p.trace_ms);
+            stats_out->shade_ms = std::max(stats_out->shade_ms, p.shade_ms);
+            stats_out->tail_ms = std::max(stats_out->tail_ms, p.tail_ms);
+        }
+    }
+    // a rolling render's histogram is complete only after bf_scene_flush: the caller reduces then (bf_allreduce_device)
+    if (launch->flags & BF_FLAG_ROLLING) return BF_OK;
+    if (n_devices == 1) return BF_OK;          // a communicator of one: the sum is the histogram itself
+    return bf_allreduce_device(devices.data(), n_devices, hist_dev, bf_launch_channels(launch), streams);
+}
+
+bf_status bf_render_sharded(bf_scene *const *scenes, uint32_t n_devices, const bf_launch *launch, float *hist_out, bf_stats *stats_out) {
+    if (!scenes || !launch || !hist_out || n_devices == 0) return fail(BF_ERR_INVALID, "bf_render_sharded: null argument");
+    if (launch->flags & BF_FLAG_ROLLING) return fail(BF_ERR_INVALID, "bf_render_sharded: host-buffer renders are synchronous (no BF_FLAG_ROLLING)");
+    const uint64_t n = bf_launch_channels(launch);
+    if (n == 0) return fail(BF_ERR_INVALID, "unknown mode");
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    std::vector<float *> bufs(n_devices, nullptr);
+    auto cleanup = [&]() {
+        for (uint32_t g = 0; g < n_devices; ++g)
+            if (bufs[g] && scenes[g] && hipSetDevice(scenes[g]->device) == hipSuccess) (void) hipFree(bufs[g]);
+        if (prev >= 0) (void) hipSetDevice(prev);
+    };
+    for (uint32_t g = 0; g < n_devices; ++g) {
+        if (!scenes[g]) {
+            cleanup();
+            return fail(BF_ERR_INVALID, "bf_render_sharded: scene %u is null", g);
+        }
+        hipError_t e = hipSetDevice(scenes[g]->device);
+        if (e == hipSuccess) e = hipMalloc((void **) &bufs[g], n * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(bufs[g], 0, n * sizeof(float));
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(BF_ERR_DEVICE, "bf_render_sharded: device %d: %s", scenes[g]->device, hipGetErrorString(e));
+        }
+    }
+    bf_status st = bf_render_sharded_device(scenes, n_devices, launch, bufs.data(), nullptr, stats_out);
+    for (uint32_t g = 0; g < n_devices && st == BF_OK; ++g) {
+        hipError_t e = hipSetDevice(scenes[g]->device);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) st = fail(BF_ERR_DEVICE, "bf_render_sharded: device %d: %s", scenes[g]->device, hipGetErrorString(e));
+    }
+    if (st == BF_OK) {
+        hipError_t e = hipSetDevice(scenes[0]->device);
+        if (e == hipSuccess) e = hipMemcpy(hist_out, bufs[0], n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(BF_ERR_DEVICE, "bf_render_sharded copy back: %s", hipGetErrorString(e));
+    }
+    cleanup();
+    return st;
 }
 
 static bf_status render_host(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_out,

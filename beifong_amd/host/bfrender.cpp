@@ -4,6 +4,7 @@
 // film / ADC storage as OpenEXR (like `mitsuba scene.xml -o out.exr`, mitsuba.cpp:283-290) or, for `-o x.npy`, as a
 // little-endian float32 .npy.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -29,6 +30,7 @@ static void save_npy(const std::string &path, const float *data, unsigned rows, 
 int main(int argc, char **argv) {
     std::string variant_name = "scalar_rgb", output, scene_file;
     bool do_receive = false;
+    int n_gpus = 1;
     xml::ParameterList params;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -37,6 +39,7 @@ int main(int argc, char **argv) {
         else if (a == "-r") do_receive = true;
         else if (a == "-v") set_log_level(Debug);
         else if (a == "-t" && i + 1 < argc) ++i;    // thread count: the work runs on the GPU
+        else if (a == "--gpus" && i + 1 < argc) n_gpus = atoi(argv[++i]);   // sample shards over N GPUs + RCCL all-reduce (ours)
         else if (a.rfind("-D", 0) == 0) {
             std::string kv = a.size() > 2 ? a.substr(2) : (i + 1 < argc ? argv[++i] : "");
             size_t k = kv.find('=');
@@ -46,7 +49,7 @@ int main(int argc, char **argv) {
             }
             params.emplace_back(kv.substr(0, k), kv.substr(k + 1));
         } else if (a == "-h" || a == "--help") {
-            printf("usage: bfrender [-m variant] [-D name=value]... [-r] [-o out.exr|out.npy] [-v] scene.xml\n");
+            printf("usage: bfrender [-m variant] [-D name=value]... [-r] [--gpus N] [-o out.exr|out.npy] [-v] scene.xml\n");
             return 0;
         } else {
             scene_file = a;
@@ -58,6 +61,7 @@ int main(int argc, char **argv) {
     }
     try {
         set_variant(variant_name);
+        set_gpu_count(n_gpus);
         ref<Object> obj = xml::load_file(scene_file, params);
         auto *scene = dynamic_cast<Scene *>(obj.get());
         if (!scene) Throw("top-level object is not a scene");

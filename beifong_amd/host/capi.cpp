@@ -30,6 +30,8 @@ unsigned bfh_sizeof_stats(void) { return (unsigned) sizeof(bf_stats); }
 int bfh_set_variant(const char *v) { BFH_TRY(set_variant(v)) }
 const char *bfh_variant(void) { return variant().c_str(); }
 int bfh_set_log_level(int level) { BFH_TRY(set_log_level((LogLevel) level)) }
+int bfh_set_gpu_count(int n) { BFH_TRY(set_gpu_count(n)) }
+int bfh_gpu_count(void) { return gpu_count(); }
 
 static xml::ParameterList make_params(int n, const char **keys, const char **values) {
     xml::ParameterList p;

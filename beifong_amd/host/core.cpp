@@ -10,6 +10,12 @@
 namespace bfh {
 
 static LogLevel g_level = Warn;
+static int g_gpu_count = 1;
+void set_gpu_count(int n) {
+    if (n < 1) Throw("gpu count must be >= 1 (got %d)", n);
+    g_gpu_count = n;
+}
+int gpu_count() { return g_gpu_count; }
 void set_log_level(LogLevel l) { g_level = l; }
 
 void Throw(const char *fmt, ...) {

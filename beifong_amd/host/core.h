@@ -34,6 +34,10 @@ namespace bfh {
 enum LogLevel { Trace = 0, Debug = 100, Info = 200, Warn = 300, Error = 400 };
 void Log(LogLevel level, const char *fmt, ...);
 void set_log_level(LogLevel level);
+/// GPUs a render / receive call is sharded over (ours: the reference is single-host TBB; bfrender --gpus N, Python
+/// set_gpu_count): sample shards per GPU, one RCCL all-reduce of the histogram (bf_render_sharded).  Default 1.
+void set_gpu_count(int n);
+int gpu_count();
 
 // ---------------------------------------------------------------------------
 // Object + intrusive reference counting

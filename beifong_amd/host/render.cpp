@@ -343,6 +343,11 @@ struct Scene::Flat {
     std::vector<bf_emitter> emitters;
     bf_scene_desc desc;
     bf_scene *device = nullptr;
+    std::vector<bf_scene *> more;      // GPUs 1, 2, ... (device_scenes)
+    ~Flat() {
+        if (device) bf_scene_destroy(device);
+        for (bf_scene *s : more) bf_scene_destroy(s);
+    }
 };
 
 Scene::Scene(const Properties &props) {
@@ -379,9 +384,7 @@ Scene::Scene(const Properties &props) {
         m_integrator = dynamic_cast<Integrator *>(pm->create_object(Properties("path"), "Integrator").get());
     }
 }
-Scene::~Scene() {
-    if (m_flat && m_flat->device) bf_scene_destroy(m_flat->device);
-}
+Scene::~Scene() {}
 
 static void copy16(float *dst, const Matrix4f &m) { std::memcpy(dst, m.m, 16 * sizeof(float)); }
 
@@ -468,8 +471,7 @@ void Scene::flatten(const Endpoint *endpoint) {
     fl->desc.n_materials = (uint32_t) fl->materials.size();
     fl->desc.emitters = fl->emitters.data();
     fl->desc.n_emitters = (uint32_t) fl->emitters.size();
-    if (m_flat && m_flat->device) bf_scene_destroy(m_flat->device);
-    m_flat = std::move(fl);
+    m_flat = std::move(fl);      // (the old description's device scenes go with it)
 }
 
 const bf_scene_desc *Scene::flat_desc(const Endpoint *endpoint) {
@@ -501,6 +503,36 @@ bf_scene *Scene::device_scene(const Endpoint *endpoint) {
         if (st != BF_OK) Throw("bf_scene_create failed (status %d): %s", st, bf_last_error());
     }
     return m_flat->device;
+}
+
+std::vector<bf_scene *> Scene::device_scenes(const Endpoint *endpoint, int n) {
+    std::vector<bf_scene *> r = {device_scene(endpoint)};
+    if (n > bf_device_count()) Throw("%d GPUs requested, %d visible", n, bf_device_count());
+    bf_scene_info info;
+    if (bf_scene_get_info(r[0], &info) != BF_OK) Throw("bf_scene_get_info: %s", bf_last_error());
+    int home = info.device;
+    for (int g = 1; g < n; ++g) {
+        if ((int) m_flat->more.size() < g) {
+            // GPU 0 is wherever the first scene lives; the others are the remaining devices in order
+            int dev = g <= home ? g - 1 : g;
+            if (bf_set_device(dev) != BF_OK) Throw("bf_set_device(%d): %s", dev, bf_last_error());
+            bf_scene *s = nullptr;
+            bf_status st = bf_scene_create(&m_flat->desc, &s);
+            (void) bf_set_device(home);
+            if (st != BF_OK) Throw("bf_scene_create on GPU %d failed (status %d): %s", dev, st, bf_last_error());
+            m_flat->more.push_back(s);
+        }
+        r.push_back(m_flat->more[g - 1]);
+    }
+    return r;
+}
+
+/// one render on gpu_count() GPUs: the plain entry for one, sample shards + RCCL all-reduce for more (bf_render_sharded)
+static bf_status render_on_gpus(Scene *scene, const Endpoint *endpoint, const bf_launch &lp, float *hist, bf_stats *stats) {
+    const int n = gpu_count();
+    if (n <= 1) return bf_render(scene->device_scene(endpoint), &lp, hist, nullptr, stats);
+    std::vector<bf_scene *> scenes = scene->device_scenes(endpoint, n);
+    return bf_render_sharded(scenes.data(), (uint32_t) scenes.size(), &lp, hist, stats);
 }
 
 // ---- integrator ------------------------------------------------------------------
@@ -550,7 +582,7 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
         Throw("internal error: channel count mismatch (%u vs %zu)", n, channels.size() * film->width() * film->height());
     std::vector<float> hist(n);
     auto t0 = std::chrono::steady_clock::now();
-    bf_status st = bf_render(scene->device_scene(sensor), &lp, hist.data(), nullptr, &m_stats.stats);
+    bf_status st = render_on_gpus(scene, sensor, lp, hist.data(), &m_stats.stats);
     if (st != BF_OK) Throw("bf_render failed (status %d): %s", st, bf_last_error());
     m_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     film->put(hist.data(), hist.size());
@@ -592,7 +624,7 @@ bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {
     uint32_t n = bf_launch_channels(&lp);
     std::vector<float> hist(n);
     auto t0 = std::chrono::steady_clock::now();
-    bf_status st = bf_render(scene->device_scene(receiver), &lp, hist.data(), nullptr, &m_stats.stats);
+    bf_status st = render_on_gpus(scene, receiver, lp, hist.data(), &m_stats.stats);
     if (st != BF_OK) Throw("bf_render failed (status %d): %s", st, bf_last_error());
     m_stats.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     adc->put(hist.data(), hist.size());

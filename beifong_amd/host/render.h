@@ -281,6 +281,8 @@ public:
     Integrator *integrator() const { return m_integrator.get(); }
     /// flattened description + device scene for the given endpoint (cached)
     bf_scene *device_scene(const Endpoint *endpoint);
+    /// one device scene per GPU 0 .. n - 1 (cached; [0] is device_scene()): the handles bf_render_sharded takes
+    std::vector<bf_scene *> device_scenes(const Endpoint *endpoint, int n);
     const bf_scene_desc *flat_desc(const Endpoint *endpoint);
     const Class *class_() const override;
 

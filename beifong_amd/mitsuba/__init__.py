@@ -24,3 +24,13 @@ def variant():
 
 def variants():
     return ["scalar_rgb", "scalar_mono", "scalar_spectral"]
+
+
+def set_gpu_count(n):
+    """Ours, not the reference's: shard every render() / receive() over the first n GPUs of this process (sample shards +
+    one RCCL all-reduce of the histogram, bf_render_sharded; `bfrender --gpus N` is the same switch)."""
+    _host.check(_host.lib().bfh_set_gpu_count(int(n)))
+
+
+def gpu_count():
+    return _host.lib().bfh_gpu_count()

@@ -304,6 +304,7 @@ typedef struct bf_scene_info {
     uint32_t bvh_stack_need;  /* worst-case traversal stack entries (<= 31)    */
     uint32_t trace_node_bytes; /* bytes per node as the throughput traversal kernel (wf_trace) reads them: node_bytes (128,
                                   fp32 child boxes) by default, 64 with the opt-in quantised nodes (BF_QUANT_BVH=1) */
+    int32_t  device;          /* HIP device the scene lives on (the current device when it was created)              */
 } bf_scene_info;
 
 /* ---------------- entry points --------------------------------------------- */
@@ -404,6 +405,31 @@ bf_status bf_scene_flush(bf_scene *scene, void *stream, bf_stats *stats_out);
  * reported afterwards: here (BF_ERR_DEVICE; the error refers to an EARLIER render of the handle), by the handle's next
  * render, or by a render with stats_out.  Call it at the end of a sweep. */
 bf_status bf_scene_sync(bf_scene *scene);
+
+/* ONE PROCESS, SEVERAL GPUs (SURVEY 8b "device_mask", 8e).  The reference has no multi-device path (TBB over image
+ * blocks of one host, src/librender/integrator.cpp:125-159); paths are i.i.d., so GPU g of G renders the global path
+ * indices bf_shard_range(launch->n_paths, g, G) of ONE render through bf_launch.path_offset — the union is the sample
+ * set of a one-GPU render — and the per-GPU histograms are summed by one ncclAllReduce(float, sum) over xGMI.
+ *
+ *   scenes[g]   a handle of the scene created on GPU g (bf_set_device(g); bf_scene_create(...)): every entry point of
+ *               this header runs on its handle's device, whatever the caller's current device is
+ *   hist_dev[g] float[bf_launch_channels(launch)] on that GPU, zeroed by the caller; on completion of streams[g] it
+ *               holds the histogram of the WHOLE render (all-reduced), on every GPU
+ *   streams[g]  a hipStream_t of that GPU (the array, or an entry, may be NULL: default stream)
+ *
+ * All GPUs' launches are enqueued by the calling thread before anything is waited for.  launch->n_paths is the TOTAL.
+ * With BF_FLAG_ROLLING the shards join their handles' rolling sequences and NO all-reduce is issued: flush every handle,
+ * then call bf_allreduce_device on the histograms.  RCCL (librccl.so) is loaded on first use; without it the calls that
+ * need a collective fail with BF_ERR_UNSUPPORTED (one GPU needs none).  bf_render_sharded is the host-buffer form
+ * (histogram zeroed by the callee; statistics summed over the GPUs, times = the slowest GPU's). */
+void bf_shard_range(uint64_t n_paths, uint32_t shard, uint32_t n_shards, uint64_t *offset, uint64_t *count);
+bf_status bf_render_sharded_device(bf_scene *const *scenes, uint32_t n_devices, const bf_launch *launch,
+                                   float *const *hist_dev, void *const *streams, bf_stats *stats_out);
+bf_status bf_render_sharded(bf_scene *const *scenes, uint32_t n_devices, const bf_launch *launch,
+                            float *hist_out, bf_stats *stats_out);
+/* in-place sum of count floats over the GPUs `devices` (bufs[g] on devices[g]), stream-ordered on streams[g] */
+bf_status bf_allreduce_device(const int *devices, uint32_t n_devices, float *const *bufs, uint64_t count,
+                              void *const *streams);
 
 /* Convenience: render into a HOST buffer (zeroed by the callee). */
 bf_status bf_render(const bf_scene *scene, const bf_launch *launch,

@@ -109,3 +109,21 @@ def test_two_rank_pulse_cube_equals_single_run(tmp_path):
     assert np.allclose(c0, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
     assert np.array_equal(c0[:, 2], ref[:, 2])             # W: the count of samples put, exact
     assert np.abs(ref[:, :2]).max() > 0 and not np.allclose(ref[0, :2], ref[1, :2])   # the phase moves with the plate
+
+
+def test_shard_range_of_the_c_abi_is_the_partition_dist_uses():
+    """bf_shard_range (what bf_render_sharded_device cuts a render with) == dist.shard_range (what bench.py --scaling
+    strong and the torch path use): contiguous, exhaustive, non-overlapping, for sizes up to 2^62."""
+    import random
+    from beifong_amd import capi, dist
+    lib = capi.load_library()
+    rnd = random.Random(7)
+    for _ in range(500):
+        n = rnd.choice([0, 1, 7, 2 ** 19, 2 ** 22, 4096 << 10, rnd.randrange(1, 2 ** 40), 2 ** 62 + 12345])
+        w = rnd.choice([1, 2, 3, 4, 7, 8, 64, 1000])
+        tot = 0
+        for r in range(w):
+            a = capi.shard_range(n, r, w, lib)
+            assert a == dist.shard_range(n, r, w) and a[0] == tot
+            tot += a[1]
+        assert tot == n
