@@ -1184,6 +1184,17 @@ struct DirectionSample {
     float pdf = 0, dist = 0, time = 0;
     bool delta = false;
 };
+// DirectionSample(it, ref) — include/mitsuba/render/records.h:168-174: d = it.p - ref.p, dist = norm(d), d /= dist
+// (the environment-emitter branch, d = -it.wi for an invalid `it`, is never taken: both call sites hold a valid hit)
+static DirectionSample direction_sample_between(V3 it_p, V3 it_n, V3 ref_p) {
+    DirectionSample ds;
+    ds.p = it_p;
+    ds.n = it_n;
+    ds.d = it_p - ref_p;
+    ds.dist = norm(ds.d);
+    ds.d = ds.d / ds.dist;
+    return ds;
+}
 
 // SpotLight::falloff_curve — src/emitters/spot.cpp:97-116
 static float spot_falloff(const Emitter &e, V3 d) {
@@ -1425,12 +1436,7 @@ static PathResult path_sample(const OScene &sc, const bf_launch &lp, Sampler &sm
         emitter = si_bsdf.valid() ? sc.shapes[si_bsdf.shape].emitter : -1;
         if (emitter >= 0) {
             // DirectionSample(si_bsdf, si) — records.h:168-174
-            DirectionSample ds;
-            ds.p = si_bsdf.p;
-            ds.n = si_bsdf.sh.n;
-            ds.d = si_bsdf.p - si.p;
-            ds.dist = norm(ds.d);
-            ds.d = ds.d / ds.dist;
+            DirectionSample ds = direction_sample_between(si_bsdf.p, si_bsdf.sh.n, si.p);
             float emitter_pdf = bs.delta ? 0.f : scene_pdf_emitter_direction(sc, emitter, ds);
             emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }
@@ -1756,12 +1762,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
         cur_phase = phase_update(0.f, -si_bsdf.t, sc.physics.lambda_min_nm, sc.physics.lambda_max_nm);
         tx = si_bsdf.valid() ? sc.shapes[si_bsdf.shape].emitter : -1;
         if (tx >= 0) {
-            DirectionSample ds;
-            ds.p = si_bsdf.p;
-            ds.n = si_bsdf.sh.n;
-            ds.d = si_bsdf.p - si.p;
-            ds.dist = norm(ds.d);
-            ds.d = ds.d / ds.dist;
+            DirectionSample ds = direction_sample_between(si_bsdf.p, si_bsdf.sh.n, si.p);
             float tpdf = transmitter_pdf_direction(sc, sc.emitters[tx], ds, cx);
             if (sc.emitters.size() != 1) tpdf *= 1.f / (float) sc.emitters.size();
             emission_weight = mis_weight(bs.pdf, tpdf);
@@ -2380,6 +2381,25 @@ float bfo_bsdf_sample(const bf_material *m, const float *wi, float s1, float s2x
     return w;
 }
 float bfo_erfinv(float x) { return erfinv_giles(x); }
+/* batch forms for the chi^2 tests (tests/test_oracle_chi2.py): samples [n][3] = (sample1, sample2.x, sample2.y) */
+void bfo_bsdf_sample_n(const bf_material *m, const float *wi, uint64_t n, const float *samples, float *wo_out, float *weight_out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        BSDFSample bs;
+        float w = bsdf_sample(*m, V3{wi[0], wi[1], wi[2]}, samples[3 * i], samples[3 * i + 1], samples[3 * i + 2], bs);
+        wo_out[3 * i] = bs.wo.x; wo_out[3 * i + 1] = bs.wo.y; wo_out[3 * i + 2] = bs.wo.z;
+        weight_out[i] = w;
+    }
+}
+void bfo_bsdf_pdf_n(const bf_material *m, const float *wi, uint64_t n, const float *wo, float *pdf_out) {
+    for (uint64_t i = 0; i < n; ++i) pdf_out[i] = bsdf_pdf(*m, V3{wi[0], wi[1], wi[2]}, V3{wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]});
+}
+/* fresnel_conductor(cos_theta_i, eta + i k) — include/mitsuba/render/fresnel.h:92-116 */
+float bfo_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+/* DirectionSample(it, ref) — records.h:168-174: out = d.xyz, dist */
+void bfo_direction_sample(const float *it_p, const float *ref_p, float *out) {
+    DirectionSample ds = direction_sample_between(V3{it_p[0], it_p[1], it_p[2]}, V3{0, 0, 1}, V3{ref_p[0], ref_p[1], ref_p[2]});
+    out[0] = ds.d.x; out[1] = ds.d.y; out[2] = ds.d.z; out[3] = ds.dist;
+}
 /* ImageBlock::put (box filter) on a caller-owned double[h][w][nchan] block; returns 1 if the sample landed.
  * spectrum != 0: the put(pos, wavelengths, spectrum, alpha) overload for a grey RGB value value[0]
  * (imageblock.h: XYZ = srgb_to_xyz(rgb), then alpha, then weight 1): nchan must be 5. */

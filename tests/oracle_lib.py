@@ -60,6 +60,14 @@ def load_from(path):
     lib.bfo_bsdf_pdf.restype = C.c_float
     lib.bfo_bsdf_sample.argtypes = [C.POINTER(capi.bf_material), vp, C.c_float, C.c_float, C.c_float, vp, vp]
     lib.bfo_bsdf_sample.restype = C.c_float
+    lib.bfo_bsdf_sample_n.argtypes = [C.POINTER(capi.bf_material), vp, C.c_uint64, vp, vp, vp]
+    lib.bfo_bsdf_sample_n.restype = None
+    lib.bfo_bsdf_pdf_n.argtypes = [C.POINTER(capi.bf_material), vp, C.c_uint64, vp, vp]
+    lib.bfo_bsdf_pdf_n.restype = None
+    lib.bfo_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.bfo_fresnel_conductor.restype = C.c_float
+    lib.bfo_direction_sample.argtypes = [vp, vp, vp]
+    lib.bfo_direction_sample.restype = None
     lib.bfo_erfinv.argtypes = [C.c_float]
     lib.bfo_erfinv.restype = C.c_float
     lib.bfo_elementary.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]

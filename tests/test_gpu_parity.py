@@ -385,10 +385,14 @@ def test_full_size_c3_car_bit_exact(hiplib):
 
 
 def test_full_size_c4_multi_mesh_sharded(hiplib):
-    """BASELINE configs[3] geometry (bus 200 k + car 1 M + motorbike 300 k triangles): one shard of the
-    8-way sample split against the oracle, and the 8 shards' histograms sum to the unsharded render."""
-    n = 1 << 19
+    """BASELINE configs[3] AT ITS CONFIGURED SIZE (bus 200 k + car 1 M + motorbike 300 k triangles, 4096 spp x 2^10 = 2^22
+    paths in 8 shards of 2^19): one whole shard against the oracle path by path; the 8 shards' histograms sum to the
+    unsharded 2^22-path render; and the 8 shards issued as ONE rolling sequence (what a GPU that renders several
+    shards back to back does) give every shard the stand-alone shard's records."""
+    torch = pytest.importorskip("torch")
+    n = 4096 << 10
     sd, lp = scenes.multi_mesh_radar(n_paths=n)
+    assert lp.n_paths == n and lp.bins == 4096
     shard = capi.make_launch(lp.mode, n // 8, seed=lp.seed, path_offset=3 * (n // 8), bins=lp.bins, bin_width=lp.bin_width,
                              color_mode=lp.color_mode)
     _render_compare(sd, shard)
@@ -396,14 +400,34 @@ def test_full_size_c4_multi_mesh_sharded(hiplib):
     h_all, _, st_all = g.render(lp)
     acc = np.zeros_like(h_all, dtype=np.float64)
     rays = 0
+    recs = []
     for k in range(8):
         lpk = capi.make_launch(lp.mode, n // 8, seed=lp.seed, path_offset=k * (n // 8), bins=lp.bins, bin_width=lp.bin_width,
                                color_mode=lp.color_mode)
-        h, _, st = g.render(lpk)
+        h, r, st = g.render(lpk, records=k in (0, 7))
+        recs.append(r)
         acc += h
         rays += st.n_rays_closest + st.n_rays_shadow
     assert rays == st_all.n_rays_closest + st_all.n_rays_shadow
+    assert acc[4] == n and h_all[4] == n
     assert np.allclose(acc, h_all, rtol=1e-4, atol=1e-2)
+    # the shards as a rolling sequence on one handle
+    hist = torch.zeros((8, g.channels(lp)), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((8, n // 8, 4), dtype=torch.int32, device="cuda")
+    for k in range(8):
+        lpk = capi.make_launch(lp.mode, n // 8, seed=lp.seed, path_offset=k * (n // 8), bins=lp.bins, bin_width=lp.bin_width,
+                               color_mode=lp.color_mode, flags=capi.BF_FLAG_ROLLING)
+        g.render_device(lpk, hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
+    g.flush()
+    g.sync()
+    hr = hist.cpu().numpy()
+    assert np.allclose(hr.astype(np.float64).sum(axis=0), h_all, rtol=1e-4, atol=1e-2) and all(hk[4] == n // 8 for hk in hr)
+    rr = rec.cpu().numpy().view(np.uint32)
+    for k in (0, 7):
+        got = np.ascontiguousarray(rr[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+        for f in ("L", "aux"):
+            assert np.array_equal(got[f].view(np.uint32), recs[k][f].view(np.uint32)), (k, f)
+        assert np.array_equal(got["n_rays"], recs[k]["n_rays"])
 
 
 def test_concurrent_renders_on_two_streams(hiplib):

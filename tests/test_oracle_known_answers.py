@@ -603,3 +603,46 @@ def test_twosided_sample_eval_pdf_over_the_sphere(oracle):
                         assert np.isclose(pdf.value, p_pdf, rtol=1e-6)
                         checked += 1
     assert checked >= 200          # wi.z == 0 (the equator of the grid) and grazing samples fail, as in the reference
+
+
+def _fresnel_dielectric(cos_theta_i, eta):
+    """fresnel(cos_theta_i, eta) — include/mitsuba/render/fresnel.h:33-70, restated in numpy float32 (F only)."""
+    c = np.asarray(cos_theta_i, f32)
+    eta = f32(eta)
+    outside = c >= 0
+    rcp_eta = f32(1) / eta
+    eta_it = np.where(outside, eta, rcp_eta).astype(f32)
+    eta_ti = np.where(outside, rcp_eta, eta).astype(f32)
+    cos_t_sqr = f32(1) - (f32(1) - c * c) * (eta_ti * eta_ti)
+    ci = np.abs(c)
+    ct = np.sqrt(np.maximum(cos_t_sqr, f32(0)))
+    a_s = (ci - eta_it * ct) / (ci + eta_it * ct)
+    a_p = (ct - eta_it * ci) / (ct + eta_it * ci)
+    r = f32(0.5) * (a_s * a_s + a_p * a_p)
+    r = np.where((eta == 1) | (ci == 0), f32(0) if eta == 1 else f32(1), r)
+    return r.astype(f32)
+
+
+def test_fresnel_conductor_agrees_with_the_dielectric_at_a_real_ior(oracle):
+    # src/librender/tests/test_fresnel.py:63-76 (test03_fresnel_conductor): "the conductive and dielectric variants should
+    # agree given a real-valued IOR", 20 angles in [0, pi/2], eta = 1.5 and 1/1.5, ek.allclose defaults (rtol 1e-5, atol 1e-8)
+    cos_theta_i = np.cos(np.linspace(0, np.pi / 2, 20)).astype(f32)
+    for eta in (1.5, 1 / 1.5):
+        r = _fresnel_dielectric(cos_theta_i, eta)
+        r2 = np.array([oracle.bfo_fresnel_conductor(float(c), eta, 0.0) for c in cos_theta_i], f32)
+        # total internal reflection (eta < 1 beyond the critical angle) is 1 in both
+        assert np.allclose(r, r2, rtol=1e-5, atol=2e-6), (eta, np.abs(r - r2).max())
+    # the radar scenes' default conductor (eta = 0, k = 1) reflects everything: F = 1 at every angle
+    assert all(abs(oracle.bfo_fresnel_conductor(float(c), 0.0, 1.0) - 1.0) < 1e-6 for c in cos_theta_i[:-1])
+
+
+def test_direction_sample_from_two_interactions(oracle):
+    # src/librender/tests/test_records.py:143-152 (test04_direction_sample_construction_single): DirectionSample3f(its, ref)
+    # with its.p = [20, 3, 40.02], ref.p = [1.6, -2, 35]: ds.d starts at the REFERENCE point
+    its_p = np.array([20, 3, 40.02], f32)
+    ref_p = np.array([1.6, -2, 35], f32)
+    out = np.zeros(4, f32)
+    oracle.bfo_direction_sample(_ptr(its_p), _ptr(ref_p), _ptr(out))
+    d = (its_p - ref_p) / np.linalg.norm(its_p - ref_p)
+    assert np.allclose(out[:3], d, rtol=1e-5, atol=1e-8)
+    assert np.isclose(out[3], np.linalg.norm(its_p.astype(np.float64) - ref_p.astype(np.float64)), rtol=1e-6)
