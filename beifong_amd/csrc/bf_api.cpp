@@ -1210,7 +1210,10 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
         // two renders' worth of main slots (a slot's next path is supplied two calls after its current one) + the
         // survivor area for the paths that are still alive by then (bf_wavefront.h)
         n_main = (uint32_t) ((std::max<uint64_t>(2 * pool_paths, 128) + 63) & ~uint64_t(63));
-        n_surv = std::max<uint32_t>(1u << 16, std::min<uint32_t>(1u << 21, (n_main / 8 + 63) & ~63u));
+        // at least one survivor batch per shading wave: a wave claims whole batches (surv_claims_max each per launch) and
+        // all the claims of one launch must be distinct batches (wf_shade: surv_take)
+        const uint32_t surv_min = (uint32_t) scene->n_cus * 4u * (uint32_t) std::max(2, scene->tun.shade_waves) * 64u;
+        n_surv = std::max<uint32_t>(surv_min, std::min<uint32_t>(1u << 21, (n_main / 8 + 63) & ~63u));
     }
     bf_status st = wf_ensure(scene, n_main + n_surv);
     if (st != BF_OK) return st;
@@ -1250,7 +1253,7 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, scene->tun.shade_waves), max_blocks));
     c.grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) scene->tun.trace_waves, max_blocks));
     c.tail_max = wf_tail_threshold(scene, rolling ? wf.n_main / 2 : wf.n_slots);
-    wf.surv_claims_max = std::max<uint32_t>(1u, (wf.n_surv / 64u) / std::max(1u, c.grid_shade * batches_per_block));
+    wf.surv_claims_max = (wf.n_surv / 64u) / std::max(1u, c.grid_shade * batches_per_block);      // >= 1 by the sizing above
     return BF_OK;
 }
 // One bounce iteration `it`: clear the next parity's masks, shade (first: 0 alive masks, 1 first bounce of a pool, 2 alive

@@ -99,6 +99,29 @@ def test_rolling_range_sequence_every_path_bit_exact(hiplib, iters, monkeypatch)
     assert all(hk[4] == lp.n_paths for hk in h)                # the weight channel: every path of every render landed
 
 
+@pytest.mark.parametrize("bins,iters", [(4096, "1"), (4096, ""), (256, "1")])
+def test_rolling_heavy_eviction_loses_no_path(hiplib, bins, iters, monkeypatch):
+    """Twelve renders of 2^17 paths with one bounce iteration per call: a third of every render's paths moves to the
+    survivor area.  Regression: with fewer survivor batches than shading waves two waves could claim the same batch in
+    one launch and hand its free slots out twice (~600 of 131072 paths per render lost).  4096 bins leave an LDS window
+    of two renders, so most late samples also take the base-channel table / global-atomic route."""
+    if iters:
+        monkeypatch.setenv("BF_ROLL_ITERS", iters)
+    n = 1 << 17
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=n, bins=bins, dr=25.6 / bins)
+    g = capi.Scene(sd)
+    seeds = list(range(100, 112))
+    seq = _Sequence(g, lp, seeds)
+    seq.issue()
+    g.flush()
+    h, recs = seq.results()
+    assert [float(hk[4]) for hk in h] == [float(n)] * len(seeds)
+    for k in (0, 5, 11):
+        hs, rs, _ = g.render(_launch_like(lp, seeds[k]), records=True)
+        _same_records(recs[k], rs)
+        _close_hist(h[k], hs, n, float(np.abs(rs["L"]).max()))
+
+
 def test_rolling_receive_sequence_and_second_sequence(hiplib):
     """gen-3 receive (the RX = 1 kernels) with I/Q; a second sequence on the same handle after the flush starts afresh."""
     sd, lp = scenes.bus_receive(n_tris=20000, n_paths=20000, t_bins=256, dr=0.1)
