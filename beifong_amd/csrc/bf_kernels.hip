@@ -88,17 +88,15 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     bool regen_ok = true;          // RESUME: the adopted slot is a main slot (survivor-area slots of a rolling sequence never regenerate)
     MaskCursor rcur;
     rcur.masks = nullptr;
-    rcur.b = rcur.b_end = rcur.win = 0;
-    rcur.g = 64u;
-    rcur.stride = 64u;
+    rcur.b = rcur.b_end = rcur.base = rcur.k = 0;
+    rcur.stride = 1u;
     rcur.sub = ~0ull;
     rcur.m = rcur.w = rcur.nz = 0ull;
     if (RESUME) {
         resume_slots = wf.n_main;
         const uint32_t n_batches = wf.n_slots >> 6;
         const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
-        // fine interleave (windows of at most 4 batches): the survivors of a rolling sequence sit densely in the survivor area
-        cursor_init(rcur, wf.m_alive[wf_it & 1], wave_id, n_waves, n_batches, lane, 4u, max(1u, wf.tail_share));
+        cursor_init(rcur, wf.m_alive[wf_it & 1], wave_id, n_waves, n_batches, lane, max(1u, wf.tail_share));
     }
 
 #ifdef BF_TAIL_PROF

@@ -116,59 +116,59 @@ BF_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
     return pos;
 }
 
-// Walks the set bits of a wave's segment of a batch-mask array.  The words are fetched 64 at a
-// time — lane l holds masks[win + l] — so skipping the empty words of a sparse pool costs one
-// coalesced load and a few scalar bit operations per 64 batches instead of one dependent
-// memory round trip per word (which made every late, nearly empty bounce iteration cost
-// 200-400 us whatever little work it held).
+// Walks the set bits of a wave's share of a batch-mask array.  The words are fetched 64 at a
+// time, one per lane, so skipping the empty words of a sparse pool costs one load and a few
+// scalar bit operations per 64 batches instead of one dependent memory round trip per word
+// (which made every late, nearly empty bounce iteration cost 200-400 us whatever little work
+// it held).
 //
-// A wave's share of the mask array is INTERLEAVED, not contiguous: windows of `g` batches, wave w owning windows
-// w, w + n_waves, w + 2 n_waves, ...  Live slots are not spread evenly over a pool — a rolling sequence keeps one
-// render in each half of the main slots and all its old paths in the survivor area behind them (bf_wavefront.h) — and
-// with contiguous segments the few waves that own the busy region did all the work while the others idled.
+// A wave's share of the mask array is INTERLEAVED, not contiguous: wave w of W owns batches w, w + W, w + 2 W, ...
+// Live slots are not spread evenly over a pool — a rolling sequence keeps one render in each half of the main slots and
+// all its old paths in the survivor area behind them (bf_wavefront.h) — and with contiguous segments the few waves that
+// own the busy region did all the work while the others idled; batch-granular interleaving balances any distribution to
+// within one batch per wave.  The words are still fetched 64 at a time (lane l reads the wave's (64 k + l)-th batch: a
+// strided gather, one 8-byte word per cache line — the masks are a few MB per launch, the state rows GBs).
 struct MaskCursor {
     const unsigned long long *masks;
     uint32_t b, b_end;          // current batch / number of batches (wave-uniform)
     unsigned long long m;       // unconsumed bits of batch b (wave-uniform)
-    uint32_t win;               // first batch of the fetched window (wave-uniform)
-    uint32_t g, stride;         // window width in batches (<= 64, a power of two) / distance between this wave's windows
+    uint32_t base, stride;      // this wave's first batch / distance between its batches (the number of waves sharing the array)
+    uint32_t k;                 // chunk: lane l holds the word of batch base + (64 k + l) stride
     unsigned long long sub;     // slots of a batch this wave serves (all ones, or a 32- / 16-slot share: the tail's spreading)
-    unsigned long long w;       // this lane's word of the window: masks[win + lane] & sub (lanes >= g: 0)
-    unsigned long long nz;      // wave-uniform: window words that are non-zero and not consumed yet
+    unsigned long long w;       // this lane's word of the chunk, & sub
+    unsigned long long nz;      // wave-uniform: chunk words that are non-zero and not consumed yet
 };
 BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
     unsigned lo = (unsigned) __shfl((int) (unsigned) v, src), hi = (unsigned) __shfl((int) (unsigned) (v >> 32), src);
     return ((unsigned long long) hi << 32) | lo;
 }
-// position the cursor on the next non-empty batch at or after the window start (or at the end)
+BF_DEV void cursor_fetch(MaskCursor &c, int lane) {
+    const uint32_t idx = c.base + (c.k * 64u + (uint32_t) lane) * c.stride;
+    c.w = idx < c.b_end ? (c.masks[idx] & c.sub) : 0ull;
+    c.nz = __ballot(c.w != 0ull);
+}
+// position the cursor on the wave's next non-empty batch (or at the end)
 BF_DEV void cursor_seek(MaskCursor &c, int lane) {
     while (true) {
         if (c.nz) {
-            const int k = __ffsll((unsigned long long) c.nz) - 1;
+            const int j = __ffsll((unsigned long long) c.nz) - 1;
             c.nz &= c.nz - 1ull;
-            c.b = c.win + (uint32_t) k;
-            c.m = wave_read_u64(c.w, k);
+            c.b = c.base + (c.k * 64u + (uint32_t) j) * c.stride;
+            c.m = wave_read_u64(c.w, j);
             return;
         }
-        c.win += c.stride;
-        if (c.win >= c.b_end) {
+        ++c.k;
+        if (c.base + c.k * 64u * c.stride >= c.b_end) {
             c.b = c.b_end;
             c.m = 0ull;
             return;
         }
-        c.w = ((uint32_t) lane < c.g && c.win + (uint32_t) lane < c.b_end) ? (c.masks[c.win + (uint32_t) lane] & c.sub) : 0ull;
-        c.nz = __ballot(c.w != 0ull);
+        cursor_fetch(c, lane);
     }
 }
-// windows wide enough for one coalesced fetch each, narrow enough that every wave owns a few of them
-BF_DEV uint32_t cursor_window(uint32_t n_batches, uint32_t n_waves, uint32_t g_max) {
-    uint32_t g = g_max;
-    while (g > 1u && n_batches / g < 4u * n_waves) g >>= 1;
-    return g;
-}
-// `share` (1, 2 or 4): that many consecutive waves serve the same windows, each one its own 64 / share slots of every batch
+// `share` (1, 2 or 4): that many consecutive waves serve the same batches, each one its own 64 / share slots of every batch
 BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t wave_id, uint32_t n_waves, uint32_t n_batches, int lane,
-                        uint32_t g_max = 64u, uint32_t share = 1u) {
+                        uint32_t share = 1u) {
     c.sub = ~0ull;
     if (share > 1u) {
         const uint32_t width = 64u / share, q = wave_id % share;
@@ -178,19 +178,17 @@ BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t
     }
     c.masks = masks;
     c.b_end = n_batches;
-    c.g = cursor_window(n_batches, n_waves, g_max);
-    c.stride = c.g * n_waves;
-    c.win = c.g * wave_id;
-    c.b = c.win;
+    c.base = wave_id;
+    c.stride = n_waves;
+    c.k = 0u;
     c.m = 0ull;
     c.w = 0ull;
     c.nz = 0ull;
-    if (c.win >= n_batches) {
+    if (wave_id >= n_batches) {
         c.b = n_batches;
         return;
     }
-    c.w = ((uint32_t) lane < c.g && c.win + (uint32_t) lane < n_batches) ? (masks[c.win + (uint32_t) lane] & c.sub) : 0ull;
-    c.nz = __ballot(c.w != 0ull);
+    cursor_fetch(c, lane);
     cursor_seek(c, lane);
 }
 BF_DEV bool cursor_empty(const MaskCursor &c) { return c.b >= c.b_end; }
