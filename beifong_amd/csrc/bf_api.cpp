@@ -1473,6 +1473,12 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
     WfCtx c;
     if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
     lp.roll = scene->roll_ring;           // wf_setup may have (re)allocated the pool and the ring with it
+    {
+        // the slots due for this render's paths: global paths [k P, (k + 1) P) live in slots g mod n_main
+        const uint32_t n_main = scene->wf.n_main, lo = (uint32_t) (((uint64_t) k * lp.batch_paths) % n_main);
+        scene->wf.wake_b0 = lo / 64u;
+        scene->wf.wake_nb = (uint32_t) std::min<uint64_t>(n_main / 64u, ((uint64_t) (lo % 64u) + lp.batch_paths + 63u) / 64u);
+    }
     if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, sizeof(uint32_t), stream));
     {
         bfd::DRoll d;

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
     const int cur = it & 1, nxt = cur ^ 1;
     const bool receive = mode_receive<RX>(lp);
     // the first / wake launches start paths: main slots only (the survivor area never regenerates)
-    const uint32_t n_batches = (WALK ? wf.n_slots : wf.n_main) >> 6;
+    // (the wake launch: only the batches whose slots are due — the other half of the main slots holds the previous render)
+    const uint32_t n_batches = WALK ? wf.n_slots >> 6 : (FIRST == 2 ? wf.wake_nb : wf.n_main >> 6);
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
     SurvAlloc sv = {0ull, 0u, 0u};
 
@@ -180,7 +181,12 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         bool aligned;
         if (!WALK) {
             if (first_b >= n_batches) break;
-            slot = first_b * 64u + lane;
+            uint32_t fb = first_b;
+            if (FIRST == 2) {
+                fb += wf.wake_b0;
+                if (fb >= wf.n_main >> 6) fb -= wf.n_main >> 6;
+            }
+            slot = fb * 64u + lane;
             got = 64;
             aligned = true;
             first_b += n_waves;
