@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--pulses", type=int, default=64, help="c5: pulses per sweep")
     ap.add_argument("--cpu-paths", type=int, default=0, help="bounded sample for the CPU baseline; 0 = the config's")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-iso", action="store_true", help="skip the stand-alone latency probe (profiling runs: only the sequence's launches)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams (scene handles) the steps rotate over; 0 = the config's")
     ap.add_argument("--rolling", type=int, default=1, help="1: the steps of a handle form a rolling sequence (BF_FLAG_ROLLING), flushed at the "
                     "end of the timed region; 0: every step is a stand-alone render with its own tail (round 2's scheme)")
@@ -296,7 +297,7 @@ def main():
     # (C) a few stand-alone renders (their own tail each, nothing else on the GPU): the latency of ONE render, which is what
     #     an 8-GPU strong-scaled render of this config cannot go below
     iso = {}
-    if not w.sweep:
+    if not w.sweep and not args.no_iso:
         for i in range(min(args.steps, 5)):
             with torch.cuda.stream(streams[0]):
                 add_stats(iso, handles[0].render_device(w.launch(i, 0), hists[i].data_ptr(), stream=streams[0].cuda_stream, want_stats=True))
@@ -442,8 +443,9 @@ def main():
         if world == 1 and w.cfg in ("c3", "c4shard", "c4", "c2"):
             # what an 8-GPU strong-scaled render of this config would see: per-GPU time of 1/8 of the paths cannot drop
             # below the tail
-            out["config"]["isolated_step_ms"] = round(iso["kernel_ms"] / iso["n"], 3)
-            out["config"]["isolated_tail_ms"] = round(iso["tail_ms"] / iso["n"], 3)
+            if iso:
+                out["config"]["isolated_step_ms"] = round(iso["kernel_ms"] / iso["n"], 3)
+                out["config"]["isolated_tail_ms"] = round(iso["tail_ms"] / iso["n"], 3)
             out["config"]["tail_ms_per_step"] = round(tim["tail_ms"] / K, 3)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, args)

@@ -1,5 +1,6 @@
 """Per-kernel HBM traffic of the bench configs from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-tools/profile_r02.sh -> the JSON bench.py reads as `roofline.kernels[].traffic` (profiles/r02_pmc_traffic.json).
+tools/profile_r03.sh -> the JSON bench.py reads as `roofline.kernels[].traffic` (profiles/r03_pmc_traffic.json), stamped
+with a hash of beifong_amd/csrc (bench.py: csrc_hash) so that a kernel change makes it stale instead of silently wrong.
 Units and corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports half the
 bytes of wide (16 B per lane) loads -> x 2; WRITE_SIZE is exact."""
 import collections
@@ -10,9 +11,11 @@ import sqlite3
 import sys
 
 root = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 CLASS = (("wf_trace", "wf_trace"), ("wf_shade", "wf_shade"), ("bf_render_kernel", "tail"))
 out = {}
-for cfg in ("c2", "c3", "c4shard", "c5"):
+for cfg in ("c2", "c3", "c4shard", "c4", "c5"):
     per = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {}})
     found = False
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -32,9 +35,11 @@ for cfg in ("c2", "c3", "c4shard", "c5"):
         with open(os.path.join(root, "pmc_%s_FETCH_SIZE.json" % cfg)) as f:
             line = json.loads(f.read().strip().splitlines()[-1])
         paths = line["config"]["paths_per_gpu_per_step"] // (64 if cfg == "c5" else 1)
+        rolling = bool(line["config"].get("rolling"))
+        steps = int(line["steps"])
     except Exception:
-        paths = None
-    e = {"paths": paths, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --config %s --steps 2 --warmup 0 --no-cpu --streams 1" % cfg,
+        paths, rolling, steps = None, False, 0
+    e = {"paths": paths, "rolling": rolling, "steps": steps, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --config %s --steps 4 --warmup 0 --no-cpu --streams 1" % cfg,
          "fetch_correction": 2.0, "traffic_bytes_per_launch": {}, "dispatches": {}, "fetch_kib_sum": {}, "write_kib_sum": {}}
     for cls, d in per.items():
         nf, nw = len(d["n"].get("FETCH_SIZE", ())), len(d["n"].get("WRITE_SIZE", ()))
@@ -45,4 +50,5 @@ for cfg in ("c2", "c3", "c4shard", "c5"):
         e["fetch_kib_sum"][cls] = d["FETCH_SIZE"]
         e["write_kib_sum"][cls] = d["WRITE_SIZE"]
     out[cfg] = e
+out["csrc_sha16"] = bench.csrc_hash()
 print(json.dumps(out, indent=1))

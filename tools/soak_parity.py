@@ -133,6 +133,54 @@ if len(sys.argv) > 2 and sys.argv[2] == "batch":
     print("FAILED" if fails else "all cases bit-exact")
     sys.exit(1 if fails else 0)
 
+if len(sys.argv) > 2 and sys.argv[2] == "rolling":
+    # round 3: rolling sequences at full size — the bench step (C2, 2^24 paths), C3, a C4 shard and C2-recv I/Q, several
+    # renders per sequence with their own seeds, EVERY per-path record of every render against the oracle
+    import torch
+    from tests.test_gpu_rolling import _Sequence, _launch_like
+
+    def check_rolling(name, sd, lp, seeds, env=None):
+        global fails
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        g = capi.Scene(sd)
+        for k in (env or {}):
+            os.environ.pop(k)
+        seq = _Sequence(g, lp, seeds, extra_flags=capi.BF_FLAG_STATS)
+        seq.issue()
+        st = g.flush(want_stats=True)
+        h, recs = seq.results()
+        o = OracleScene(sd)
+        bad_total, rays = 0, 0
+        for k, seed in enumerate(seeds):
+            _, ro, so = o.render(_launch_like(lp, seed), records=True, threads=16)
+            rays += so.n_rays_closest + so.n_rays_shadow
+            bad_total += sum(int((recs[k][key].view(np.uint32) != ro[key].view(np.uint32)).sum()) for key in ("L", "aux"))
+            bad_total += int((recs[k]["n_rays"] != ro["n_rays"]).sum()) + int((recs[k]["valid"] != ro["valid"]).sum())
+        ok = bad_total == 0 and rays == st.n_rays_closest + st.n_rays_shadow and st.n_guard == 0
+        fails += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} {name:46s} {len(seeds)} renders x {lp.n_paths} paths, rays {st.n_rays_closest + st.n_rays_shadow} "
+              f"(oracle {rays}), tail rays {st.n_rays_tail}, iterations {st.n_bounce_iters}, mismatching records {bad_total}", flush=True)
+        g.close()
+        del seq
+        torch.cuda.empty_cache()
+
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(1000 + seed)
+        seeds = [int(x) for x in rng.integers(1, 1 << 40, 5)]
+        sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=1)
+        check_rolling(f"C2 bench step, soak seed {seed}", sd, lp, seeds[:3])
+        sd, lp = scenes.car_radar(n_tris=1_000_000, n_paths=1 << 20, bins=1024, dr=0.03, seed=2)
+        check_rolling(f"C3 car, soak seed {seed}", sd, lp, seeds)
+        check_rolling(f"C3 car, one iteration per call, soak seed {seed}", sd, lp, seeds, env={"BF_ROLL_ITERS": "1"})
+        sd, lp = scenes.multi_mesh_radar(n_paths=1 << 19)
+        check_rolling(f"C4 shard, soak seed {seed}", sd, lp, seeds)
+        sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 20, t_bins=1024, dr=0.03, seed=4, lambda_band_nm=(8.6e6 * 0.999, 8.6e6 * 1.001))
+        lp.mode = capi.BF_MODE_RECEIVE_IQ
+        check_rolling(f"C2-recv I/Q, soak seed {seed}", sd, lp, seeds[:4])
+    print("FAILED" if fails else "all cases bit-exact")
+    sys.exit(1 if fails else 0)
+
 for seed in range(n_seeds):
     sd, lp = scenes.bus_radar(n_tris=200_000, n_paths=1 << 24, seed=100 + seed)
     check(f"C2 range bus seed {100 + seed}", sd, lp)
