@@ -44,7 +44,7 @@ extern "C" hipError_t bfk_wf_trace(const bfd::DScene *sc, const bfd::WF *wf, uin
 extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch *lp, const bfd::WF *wf, uint32_t it,
                                       uint32_t n_slots, float *g_hist, bf_path_record *records, int stats, size_t lds_bytes,
                                       hipStream_t stream, int tail_waves, unsigned spread, unsigned block_cap);
-extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, uint32_t idx, const bfd::DRoll *d, hipStream_t stream);
+extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, float4 *offsets, uint32_t idx, const bfd::DRoll *d, const float *offset3, hipStream_t stream);
 
 namespace {
 
@@ -205,6 +205,9 @@ struct bf_scene {
         bfd::DLaunch lp;                         // device launch of the sequence (n_paths = supply so far)
         hipStream_t stream = nullptr;
         bool count_nodes = false, timed = false;
+        uint32_t per_call = 1;                   // renders every call adds (bf_render_batch_device: the batch size)
+        bool offsets = false;                    // the renders carry mesh offsets (batched calls with moving meshes)
+        float dmax = 0.f;                        // largest |offset component| so far (box slack of the SHIFT traversal)
         uint32_t window = 1;                     // renders of the LDS histogram window
         uint32_t iters = 0;                      // bounce iterations per call (adapted from the live counts)
         uint32_t flush_iters = 0;                // planned bounce iterations of a flush before its tail (learned)
@@ -214,6 +217,7 @@ struct bf_scene {
     };
     mutable Roll roll;
     mutable bfd::DRoll *roll_ring = nullptr;     // device [kRollRing]
+    mutable float4 *roll_offsets = nullptr;      // device [kRollRing]: mesh offset of every render of the sequence
     // Launch plan learned from the previous render of the same shape (wf_render): how many bounce
     // iterations precede the tail and how many slots are then alive.  With a plan the whole render is
     // enqueued without a host round trip; the live counts come back through a pinned buffer afterwards.
@@ -1106,6 +1110,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     scene->wf_owned.clear();
     std::memset(&wf, 0, sizeof(wf));
     scene->roll_ring = nullptr;
+    scene->roll_offsets = nullptr;
     auto alloc = [&](void **p, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) scene->wf_owned.push_back(*p);
@@ -1129,6 +1134,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     HIP_TRY(alloc((void **) &scene->roll_ring, bfd::kRollRing * sizeof(bfd::DRoll)));
+    HIP_TRY(alloc((void **) &scene->roll_offsets, bfd::kRollRing * sizeof(float4)));
     HIP_TRY(alloc((void **) &wf.surv_cursor, 64));
     wf.counters = scene->counters;
     wf.capacity = capacity;
@@ -1431,11 +1437,14 @@ static bool roll_same_shape(const bf_launch &a, const bf_launch &b) {
 
 static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool sync_timing);
 
-static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, const bfd::DLaunch &lp_in, float *hist_dev,
-                                bf_path_record *records_dev, hipStream_t stream) {
+static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, const bfd::DLaunch &lp_in,
+                                float *hist_dev, bf_path_record *records_dev, hipStream_t stream) {
     bf_scene::Roll &r = scene->roll;
     bf_status st;
-    if (r.open && (!roll_same_shape(r.shape, *launch) || r.count >= bfd::kRollRing || r.stream != stream)) {
+    const uint32_t K = batch ? batch->n_renders : 1u;          // renders this call adds to the sequence
+    const bool with_offsets = batch && batch->mesh_offsets && scene->d.n_tris != 0;
+    if (r.open && (!roll_same_shape(r.shape, *launch) || r.per_call != K || r.offsets != with_offsets ||
+                   r.count + K > bfd::kRollRing || r.stream != stream)) {
         if ((st = wf_roll_flush(scene, r.stream, false)) != BF_OK) return st;
         if (r.stream != stream) {
             // the flush ran on the old stream: the new sequence's first launches reuse the pool behind it
@@ -1448,7 +1457,13 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.shape = *launch;
         r.lp = lp_in;
         r.lp.batch = 1u;
-        r.lp.batch_paths = lp_in.n_paths;
+        r.lp.batch_paths = launch->n_paths;
+        r.lp.batch_seeds = nullptr;              // seeds, offsets and buffers of a rolling render live in its descriptor
+        r.lp.batch_offsets = nullptr;
+        r.lp.box_slack = 0.f;
+        r.per_call = K;
+        r.offsets = with_offsets;
+        r.dmax = 0.f;
         r.count = 0;
         r.it = 0;
         r.stream = stream;
@@ -1456,37 +1471,52 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.timed = (launch->flags & BF_FLAG_TIMING) != 0;
         // LDS window: the newest renders' histogram blocks, as many as fit
         r.window = 1;
-        if (lp_in.lds_hist) r.window = std::max<uint32_t>(1u, std::min<uint32_t>(bfd::kRollWindow, (uint32_t) bfd::kMaxLdsHist / std::max(1u, lp_in.n_chan)));
+        r.lp.lds_hist = (lp_in.n_chan <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
+        if (r.lp.lds_hist) r.window = std::max<uint32_t>(1u, std::min<uint32_t>(bfd::kRollWindow, (uint32_t) bfd::kMaxLdsHist / std::max(1u, lp_in.n_chan)));
         HIP_TRY(hipMemsetAsync(scene->counters, 0, sizeof(unsigned long long) * bfd::CTR_GUARD, stream));
         scene->wf_ev_kind.clear();
         scene->wf_iters = scene->wf_trace_launches = 0;
     }
     const bool fresh_pool = opening;
-    const uint32_t k = r.count;
+    const uint32_t k = r.count, newest = k + K - 1u;
     bfd::DLaunch &lp = r.lp;
-    lp.n_paths = (uint64_t) (k + 1u) * lp.batch_paths;
-    lp.roll_newest = k;
-    lp.roll_lo = k + 1u > r.window ? k + 1u - r.window : 0u;
+    lp.n_paths = (uint64_t) (k + K) * lp.batch_paths;
+    lp.roll_newest = newest;
+    lp.roll_lo = newest + 1u > r.window ? newest + 1u - r.window : 0u;
     lp.n_chan_all = (lp.roll_newest - lp.roll_lo + 1u) * lp.n_chan;
     lp.base_off = lp.lds_hist ? r.window * lp.n_chan : 0u;        // fixed for the sequence: behind the full window
     lp.lds_floats = lp.base_off + 5u * bfd::kRollBase;
     WfCtx c;
-    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
+    if (with_offsets) {
+        for (uint32_t j = 0; j < K; ++j)
+            for (int a = 0; a < 3; ++a) {
+                const float q = batch->mesh_offsets[3 * j + a];
+                if (!std::isfinite(q)) return fail(BF_ERR_INVALID, "bf_render_batch: non-finite mesh offset of render %u", j);
+                r.dmax = std::max(r.dmax, std::fabs(q));
+            }
+        // bf_device_core.h: Shift — slack for the largest offset of the sequence so far (older paths just get wider boxes)
+        lp.box_slack = 1e-6f * (scene->origin_scale_built + 2.f * r.dmax);
+    }
+    if ((st = wf_setup(scene, lp, (uint64_t) K * lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
     lp.roll = scene->roll_ring;           // wf_setup may have (re)allocated the pool and the ring with it
+    lp.batch_offsets = with_offsets ? scene->roll_offsets : nullptr;
+    scene->wf.offsets = lp.batch_offsets;
     {
-        // the slots due for this render's paths: global paths [k P, (k + 1) P) live in slots g mod n_main
+        // the slots due for this call's paths: global paths [k P, (k + K) P) live in slots g mod n_main
         const uint32_t n_main = scene->wf.n_main, lo = (uint32_t) (((uint64_t) k * lp.batch_paths) % n_main);
         scene->wf.wake_b0 = lo / 64u;
-        scene->wf.wake_nb = (uint32_t) std::min<uint64_t>(n_main / 64u, ((uint64_t) (lo % 64u) + lp.batch_paths + 63u) / 64u);
+        scene->wf.wake_nb = (uint32_t) std::min<uint64_t>(n_main / 64u, ((uint64_t) (lo % 64u) + (uint64_t) K * lp.batch_paths + 63u) / 64u);
     }
     if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, sizeof(uint32_t), stream));
-    {
+    const uint32_t n_chan1 = lp.n_chan;
+    for (uint32_t j = 0; j < K; ++j) {
         bfd::DRoll d;
-        d.seed = launch->seed;
+        d.seed = (batch && batch->seeds) ? batch->seeds[j] : launch->seed;
         d.path_offset = launch->path_offset;
-        d.hist = hist_dev;
-        d.records = records_dev;
-        HIP_TRY(bfk_roll_set(scene->roll_ring, k & (bfd::kRollRing - 1u), &d, stream));
+        d.hist = hist_dev + (size_t) j * n_chan1;
+        d.records = records_dev ? records_dev + (size_t) j * lp.batch_paths : nullptr;
+        HIP_TRY(bfk_roll_set(scene->roll_ring, scene->roll_offsets, (k + j) & (bfd::kRollRing - 1u), &d,
+                             with_offsets ? batch->mesh_offsets + 3 * j : nullptr, stream));
     }
     // ---- how many bounce iterations this call enqueues ------------------------------------------------
     // A launch that finds fewer live slots than fill the chip a few times over runs at its latency floor whatever it
@@ -1527,7 +1557,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.fb_is_flush = false;
     }
     r.open = true;
-    ++r.count;
+    r.count += K;
     return BF_OK;
 }
 
@@ -1545,7 +1575,7 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
     }
     bfd::DLaunch &lp = r.lp;
     WfCtx c;
-    if ((st = wf_setup(scene, lp, lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
+    if ((st = wf_setup(scene, lp, (uint64_t) r.per_call * lp.batch_paths, nullptr, nullptr, stream, r.count_nodes, r.timed, c, true)) != BF_OK) return st;
     bfd::WF &wf = scene->wf;
     volatile uint32_t *hq = scene->wf_host;
     const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
@@ -1723,10 +1753,11 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
                         (unsigned long long) (launch->path_offset + launch->n_paths), (unsigned long long) (px * launch->spp));
     }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    const bool rolling = (launch->flags & BF_FLAG_ROLLING) != 0u && launch->n_paths != 0u && launch->n_paths <= scene->tun.pool;
+    const bool rolling = (launch->flags & BF_FLAG_ROLLING) != 0u && launch->n_paths != 0u &&
+                         (uint64_t) n_renders * launch->n_paths <= scene->tun.pool && n_renders <= bfd::kRollRing;
     if (launch->flags & BF_FLAG_ROLLING) {
-        if (batch || multi_pixel || (launch->flags & BF_FLAG_MEGAKERNEL))
-            return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_ROLLING: batched launches, multi-pixel films and the one-kernel variant do not roll");
+        if (multi_pixel || (launch->flags & BF_FLAG_MEGAKERNEL))
+            return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_ROLLING: multi-pixel films and the one-kernel variant do not roll");
         if (stats_out)
             return fail(BF_ERR_INVALID, "BF_FLAG_ROLLING: a rolling render returns before its paths have ended, so it has no statistics "
                                         "of its own (pass stats_out = NULL; bf_scene_flush reports the sequence's)");
@@ -1764,7 +1795,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.lds_floats = lp.lds_hist ? lp.n_chan_all : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);
     lds = (lds + 15) & ~size_t(15);
-    if (batch) {
+    if (batch && !rolling) {
         // one launch sequence over n_renders * n_paths global path indices (DLaunch::batch); the per-render seeds and
         // mesh offsets travel through the scene's pinned staging ring, so the caller's arrays are free on return
         lp.batch = n_renders;
@@ -1810,7 +1841,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
 
     if (rolling) {
         // more paths than the pool has slots would need several paths per slot and render: not a rolling shape (above)
-        bf_status rst = wf_roll_render(scene, launch, lp, hist_dev, records_dev, stream);
+        bf_status rst = wf_roll_render(scene, launch, batch, lp, hist_dev, records_dev, stream);
         if (rst != BF_OK) return rst;
         return mark_last(scene, stream);
     }

@@ -596,12 +596,16 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
 
 namespace bfd {
 // one descriptor of a rolling sequence's ring (kernel arguments are captured at launch: no staging buffer to keep alive)
-__global__ void bf_roll_set_kernel(DRoll *ring, uint32_t idx, DRoll d) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ring[idx] = d;
+__global__ void bf_roll_set_kernel(DRoll *ring, float4 *offsets, uint32_t idx, DRoll d, float4 off) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ring[idx] = d;
+        offsets[idx] = off;
+    }
 }
 }  // namespace bfd
-extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, uint32_t idx, const bfd::DRoll *d, hipStream_t stream) {
-    hipLaunchKernelGGL(bfd::bf_roll_set_kernel, dim3(1), dim3(64), 0, stream, ring, idx, *d);
+extern "C" hipError_t bfk_roll_set(bfd::DRoll *ring, float4 *offsets, uint32_t idx, const bfd::DRoll *d, const float *offset3, hipStream_t stream) {
+    const float4 off = offset3 ? make_float4(offset3[0], offset3[1], offset3[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    hipLaunchKernelGGL(bfd::bf_roll_set_kernel, dim3(1), dim3(64), 0, stream, ring, offsets, idx, *d, off);
     return hipGetLastError();
 }
 

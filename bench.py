@@ -187,13 +187,13 @@ def main():
 
     w = Workload(args, rank, world, capi, scenes)
     n_streams = max(1, w.streams)
-    rolling = bool(args.rolling) and not w.sweep
+    rolling = bool(args.rolling)
     first = capi.Scene(w.sd, lib)                                  # ONE BVH build / upload ...
     handles = [first] + [first.clone() for _ in range(n_streams - 1)]   # ... shared by the stream handles
     info = first.info()
     n_chan = first.channels(w.lp)
     # one histogram PER STEP (a rolling render's histogram is complete only after the flush), one cube per sweep
-    n_rows = 1 if w.sweep else max(args.steps, args.warmup, n_streams)
+    n_rows = max(args.steps, args.warmup, n_streams if not w.sweep else 1, 2)
     hists = torch.zeros((n_rows, n_chan * (w.n_pulses if w.sweep else 1)), dtype=torch.float32, device=dev)
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     roll_flag = capi.BF_FLAG_ROLLING if rolling else 0
@@ -210,35 +210,32 @@ def main():
             if want:
                 add_stats(acc, st)
             return
-        # c5: one sweep = n_streams batches of pulses (one launch sequence each), cube accumulated in hists[0]
-        want = acc is not None
-        cube = hists[0]
-        for s in streams:
-            s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(streams[0]):
-            cube.zero_()
-        for s in streams[1:]:
-            s.wait_stream(streams[0])
-        bounds = [w.n_pulses * j // n_streams for j in range(n_streams + 1)]
-        for j in range(n_streams):
-            k0, k1 = bounds[j], bounds[j + 1]
+        # c5: one sweep = n_streams batches of pulses (one batched launch each: K pulses join the handle's rolling sequence
+        # per call, or — stand-alone — form one launch sequence with its own tail), cube of step i in hists[i]
+        want = acc is not None and not rolling
+        cube = hists[i]
+        # batches of at most 2^24 paths (a handle's pool), dealt round-robin to the handles
+        kmax = max(1, (1 << 24) // w.paths)
+        n_chunks = max(n_streams, (w.n_pulses + kmax - 1) // kmax)
+        bounds = [w.n_pulses * j // n_chunks for j in range(n_chunks + 1)]
+        for c in range(n_chunks):
+            k0, k1 = bounds[c], bounds[c + 1]
             if k1 == k0:
                 continue
+            j = c % n_streams if only is None else only
             with torch.cuda.stream(streams[j]):
                 st = handles[j].render_batch_device(l, k1 - k0, cube.data_ptr() + 4 * n_chan * k0, offsets=w.offsets[k0:k1],
                                                     stream=streams[j].cuda_stream, want_stats=want)
             if want:
                 add_stats(acc, st)
-        if world > 1:
-            for s in streams[1:]:
-                streams[0].wait_stream(s)
-            with torch.cuda.stream(streams[0]):
-                dist.all_reduce(cube)             # one all-reduce of the whole slow-time x fast-time cube
+        if world > 1 and not rolling:
+            cur = torch.cuda.current_stream(dev)
+            for s in streams:
+                cur.wait_stream(s)
+            dist.all_reduce(cube)             # one all-reduce of the whole slow-time x fast-time cube
 
     def begin(n):
         """Zero the histograms of the next n steps (stream-ordered before every handle's work)."""
-        if w.sweep:
-            return
         hists[:n].zero_()
         for s in streams:
             s.wait_stream(torch.cuda.current_stream(dev))
@@ -246,13 +243,11 @@ def main():
     def finish(n, acc=None):
         """End of a region of n steps: flush every handle's rolling sequence (the ONE tail per handle), then, for N > 1, one
         RCCL all-reduce of all n per-step range histograms over xGMI (they are complete only now)."""
-        if w.sweep:
-            return
-        for j in range(n_streams):
-            st = handles[j].flush(stream=streams[j].cuda_stream, want_stats=acc is not None and rolling)
+        for j in range(n_streams if rolling else 0):
+            st = handles[j].flush(stream=streams[j].cuda_stream, want_stats=acc is not None)
             if st is not None and st.n_paths:
                 add_stats(acc, st)
-        if world > 1:
+        if world > 1 and (rolling or not w.sweep):      # (stand-alone sweeps reduce their cube per step)
             cur = torch.cuda.current_stream(dev)
             for s in streams:
                 cur.wait_stream(s)
@@ -283,14 +278,19 @@ def main():
     #     K steps as ONE sequence on ONE handle (every launch alone on the GPU) and read the sequence's totals at its flush.
     cnt, tim = {}, {}
     one = 0 if rolling else None
+    per_step = w.sweep          # a sweep is dozens of renders: its sequence is read out (and flushed) sweep by sweep
     begin(args.steps)
     for i in range(args.steps):
         step(i, acc=cnt, flags=capi.BF_FLAG_STATS, only=one)
+        if per_step:
+            finish(args.steps, acc=cnt)
     finish(args.steps, acc=cnt)
     sync()
     begin(args.steps)
     for i in range(args.steps):
         step(i, acc=tim, flags=capi.BF_FLAG_TIMING if rolling else 0, only=one)
+        if per_step:
+            finish(args.steps, acc=tim)
     finish(args.steps, acc=tim)
     sync()
 

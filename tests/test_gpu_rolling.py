@@ -299,3 +299,45 @@ def test_renders_of_one_handle_on_two_streams_are_ordered(hiplib):
     for k in (0, 1, 5):
         _, rs, _ = g.render(_launch_like(lp, 40 + k), records=True)
         _same_records(np.ascontiguousarray(rr[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1), rs)
+
+
+@pytest.mark.parametrize("iq", [False, True])
+def test_rolling_batches_with_mesh_offsets(hiplib, iq):
+    """Batched calls join a rolling sequence (the pulses of a sweep, K per call, each with its own seed and mesh offset:
+    BASELINE configs[4]): every path equals the plain batched launch's, which test_gpu_batch.py pins to the oracle on
+    scenes BUILT from the shifted vertices."""
+    import torch
+    sd, lp = scenes.bus_receive(n_tris=20000, n_paths=20000, t_bins=256, dr=0.1)
+    if iq:
+        lp.mode = capi.BF_MODE_RECEIVE_IQ
+    K, calls = 4, 3
+    rng = np.random.default_rng(3)
+    offsets = np.concatenate([np.zeros((1, 3)), rng.uniform(-0.02, 0.02, (5, 3)), rng.uniform(-2.5, 2.5, (6, 3))]).astype(np.float32)
+    seeds = [int(x) for x in rng.integers(1, 1 << 40, K * calls)]
+    g = capi.Scene(sd)
+    n = g.channels(lp)
+    hist = torch.zeros((K * calls, n), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((K * calls, int(lp.n_paths), 4), dtype=torch.int32, device="cuda")
+    lr = _launch_like(lp, lp.seed, flags=capi.BF_FLAG_ROLLING)
+    for c in range(calls):
+        k0 = c * K
+        g.render_batch_device(lr, K, hist[k0].data_ptr(), seeds=seeds[k0:k0 + K], offsets=offsets[k0:k0 + K],
+                              records_ptr=rec[k0].data_ptr())
+    g.flush()
+    g.sync()
+    h = hist.cpu().numpy()
+    rr = rec.cpu().numpy().view(np.uint32)
+    g2 = capi.Scene(sd)
+    hb, rb, _ = g2.render_batch(lp, K * calls, seeds=seeds, offsets=offsets, records=True)
+    for k in range(K * calls):
+        got = np.ascontiguousarray(rr[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+        _same_records(got, rb[k])
+        _close_hist(h[k], hb[k], lp.n_paths, float(np.abs(rb[k]["L"]).max()))
+    assert not np.array_equal(rb[0]["L"], rb[7]["L"])
+    # a rolling batch without offsets after one with offsets opens a new sequence (the shape differs) and is correct too
+    g.render_batch_device(lr, K, hist[0].data_ptr(), seeds=seeds[:K], records_ptr=rec[0].data_ptr())
+    g.flush()
+    g.sync()
+    hb0, rb0, _ = g2.render_batch(lp, K, seeds=seeds[:K], records=True)
+    got = np.ascontiguousarray(rec.cpu().numpy().view(np.uint32)[2]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+    _same_records(got, rb0[2])
