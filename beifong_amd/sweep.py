@@ -85,6 +85,8 @@ class PulseSweeper:
     batches' tails overlap each other's heads.  See render_pulse_sweep."""
 
     def __init__(self, sd, launch, n_streams=2, lib=None, device=None):
+        from . import configure_runtime
+        configure_runtime()          # more hardware queues than the default 4 (no effect once HIP has started)
         import torch
         self.lib = lib or capi.load_library()
         self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)

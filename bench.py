@@ -39,6 +39,7 @@ import argparse
 import os
 
 # before anything loads the HIP runtime: hardware queues per process (default 4), see the note on streams above
+# (= beifong_amd.configure_runtime(), spelled out here because nothing of the package is imported yet)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import hashlib
 import json
@@ -352,9 +353,9 @@ def main():
                     "tail": max(tim["n_tail_launches"], 1)}
         bytes_ = {"wf_trace": b_trace, "wf_shade": b_shade, "tail": b_tail}
         # the symbols rocprofv3 prints (template arguments: wf_trace<STATS, W, SHIFT, QUANT>, wf_shade<FIRST, W, RX> with
-        # FIRST = 0 alive masks / 1 first bounce / 2 wake launch, bf_render_kernel<STATS, RESUME, SPILL, TW>)
+        # FIRST = 0 alive masks / 1 first bounce / 2 wake launch / 3 alive masks + eviction, bf_render_kernel<STATS, RESUME, SPILL, TW>)
         names = {"wf_trace": "bfd::wf_trace<false, 5, %s, false>" % ("true" if w.sweep else "false"),
-                 "wf_shade": "bfd::wf_shade<0|1|2, 3, %d>" % (1 if w.receive else 0),
+                 "wf_shade": "bfd::wf_shade<0|1|2|3, 3, %d>" % (1 if w.receive else 0),
                  "tail": "bfd::bf_render_kernel<false, true, %s, 3> (tail)" % ("true" if info.bvh_stack_need > 32 else "false")}
         traffic = pmc_traffic(w, args, rolling, n_streams)
         total_ms = sum(ms.values()) or 1.0

@@ -4,6 +4,8 @@ cube [64, 1024, (I, Q, W)] -> slow-time FFT -> range-Doppler map.  Prints the ti
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import beifong_amd
+beifong_amd.configure_runtime()
 from beifong_amd import capi, scenes, sweep
 
 speed = float(os.environ.get("SPEED", 5.0))      # m/s towards the radar; 5 m/s walks 10 range bins in the 64 pulses,

@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import beifong_amd
+beifong_amd.configure_runtime()
 from beifong_amd import capi, scenes
 
 n_paths = int(os.environ.get("PATHS", 1 << 24))
