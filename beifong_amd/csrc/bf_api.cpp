@@ -1454,6 +1454,8 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
     }
     const bool opening = !r.open;
     if (opening) {
+        // what the previous sequence of this handle learned (iterations per call, the flush's plan) only fits its shape
+        if (!roll_same_shape(r.shape, *launch) || r.per_call != K) r.iters = r.flush_iters = r.flush_live = 0;
         r.shape = *launch;
         r.lp = lp_in;
         r.lp.batch = 1u;
