@@ -119,6 +119,7 @@ struct bf_tunables {
     uint32_t shade_chain = bfd::kShadeChain, row_jobs = bfd::kTailRowJobs;
     int shade_waves = 3, trace_waves = 5, tail_waves = 3;
     unsigned tail_spread = 1, tail_blocks = 0;
+    int tail_share = -1;                     // BF_TAIL_SHARE: waves per batch in a stand-alone render's tail (-1: by pool size)
     bool allow_plan = true;                  // BF_WF_SYNC=1 turns launch plans off
     uint32_t roll_iters = 0;                 // BF_ROLL_ITERS: bounce iterations per call of a rolling sequence (0: adaptive)
     uint32_t roll_live = 1u << 20;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
@@ -145,6 +146,7 @@ static bf_tunables read_tunables() {
     t.tail_waves = num("BF_TAIL_WAVES", 3) == 2 ? 2 : 3;
     t.tail_spread = (unsigned) std::max<long long>(1, num("BF_TAIL_SPREAD", 1));
     t.tail_blocks = (unsigned) std::max<long long>(0, num("BF_TAIL_BLOCKS", 0));
+    t.tail_share = (int) num("BF_TAIL_SHARE", -1);
     t.allow_plan = num("BF_WF_SYNC", 0) == 0;
     t.roll_iters = (uint32_t) std::max<long long>(0, std::min<long long>(32, num("BF_ROLL_ITERS", 0)));
     t.roll_live = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_ROLL_LIVE", 1ll << 20), 1ll << 30));
@@ -1295,6 +1297,10 @@ static bf_status wf_tail_launch(const WfCtx &c, uint32_t it, uint32_t est_live, 
     // share a batch, so a wave starts with <= 16 paths and walks four lanes per ray from its first bounce instead of
     // waiting for the longest of 64 lane-per-ray walks (half of a tail's cycles are those dense iterations)
     uint32_t share = 1;
+    if (!alone && scene->tun.tail_share > 1) {
+        share = scene->tun.tail_share >= 4 ? 4u : 2u;
+        est_live = (uint32_t) std::min<uint64_t>((uint64_t) est_live * share, 1u << 30);
+    }
     if (alone) {
         const uint32_t resident = (uint32_t) scene->n_cus * 4u * 3u;          // waves at 3 per SIMD
         while (share < 4u && (uint64_t) est_live * (share * 2u) / 64u <= resident) share *= 2u;
