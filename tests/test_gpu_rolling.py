@@ -341,3 +341,34 @@ def test_rolling_batches_with_mesh_offsets(hiplib, iq):
     hb0, rb0, _ = g2.render_batch(lp, K, seeds=seeds[:K], records=True)
     got = np.ascontiguousarray(rec.cpu().numpy().view(np.uint32)[2]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
     _same_records(got, rb0[2])
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("receive", [False, True])
+def test_rolling_fuzz_scenes(hiplib, seed, receive):
+    """The random scenes of test_gpu_parity (every integrator mode, depth and roulette limits, several emitters, phase
+    bins, the Doppler hook / mix_resample on odd receive seeds) as rolling sequences of five renders: records and
+    histograms of every render against the stand-alone render (which the fuzz tests hold to the oracle), and the first and
+    last against the oracle directly."""
+    from tests.test_gpu_parity import _fuzz_scene
+    sd, lp = _fuzz_scene(seed, receive=receive)
+    if lp.spp:
+        pytest.skip("multi-pixel films do not roll")
+    if receive and seed % 2:
+        lp.flags = capi.BF_FLAG_DOPPLER | (capi.BF_FLAG_MIX_RESAMPLE if sd.sensor.type == capi.BF_RECEIVER_OMNI else 0)
+    g = capi.Scene(sd)
+    seeds = [int(lp.seed) + 1000 * k for k in range(5)]
+    seq = _Sequence(g, lp, seeds)
+    seq.issue()
+    g.flush()
+    h, recs = seq.results()
+    o = OracleScene(sd)
+    for k, s in enumerate(seeds):
+        l1 = _launch_like(lp, s, flags=lp.flags)
+        hs, rs, _ = g.render(l1, records=True)
+        _same_records(recs[k], rs)
+        amax = float(np.nanmax(np.abs(rs["L"]))) if len(rs) else 0.0
+        assert np.allclose(h[k], hs, rtol=2e-5, atol=lp.n_paths * 2.0 ** -24 * max(amax, 1.0) * 4, equal_nan=True), (seed, k)
+        if k in (0, 4):
+            _, ro, _ = o.render(l1, records=True, threads=8)
+            _same_records(recs[k], ro)
