@@ -230,8 +230,6 @@ struct bf_scene {
         uint32_t iters = 0, tail_live = 0;
     };
     mutable WfPlan wf_plan;
-    mutable float *wf_dop_buf = nullptr;         // per-slot wavelength shift (WF::dop when BF_FLAG_DOPPLER is set)
-    mutable uint32_t *wf_render_buf = nullptr;   // per-slot render index of batched launches (WF::render when a batch runs)
     // Pinned staging for small host tables that travel with a launch (batch seeds / mesh offsets, endpoint records):
     // a ring of slots, each with its own device mirror and an event recorded behind the copy, so the caller's arrays
     // and our stack locals are free again when the call returns and nothing blocks unless kStageSlots launches are in
@@ -1119,20 +1117,26 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
         return e;
     };
     size_t n = capacity, nb = capacity / 64;
-    HIP_TRY(alloc((void **) &wf.ray0, n * 16));
-    HIP_TRY(alloc((void **) &wf.ray1, n * 16));
-    HIP_TRY(alloc((void **) &wf.sa, n * 16));
-    HIP_TRY(alloc((void **) &wf.sb, n * 16));
-    HIP_TRY(alloc((void **) &wf.sd, n * 16));
-    HIP_TRY(alloc((void **) &wf.se, n * 16));
-    HIP_TRY(alloc((void **) &wf.hit, n * 16));
-    HIP_TRY(alloc((void **) &wf.hit_prim, n * 4));
-    HIP_TRY(alloc((void **) &wf.sh0, n * 16));
-    HIP_TRY(alloc((void **) &wf.sh1, n * 16));
-    HIP_TRY(alloc((void **) &wf.sh2, n * 4));
-    HIP_TRY(alloc((void **) &wf.sh3, n * 4));
-    HIP_TRY(alloc((void **) &scene->wf_render_buf, n * 4));
-    HIP_TRY(alloc((void **) &scene->wf_dop_buf, n * 4));
+#if BF_STATE_AOS
+    HIP_TRY(alloc((void **) &wf.recA, n * 64));
+    HIP_TRY(alloc((void **) &wf.recB, n * 64));
+    HIP_TRY(alloc((void **) &wf.recC, n * 64));
+#else
+    HIP_TRY(alloc((void **) &wf.ray0_, n * 16));
+    HIP_TRY(alloc((void **) &wf.ray1_, n * 16));
+    HIP_TRY(alloc((void **) &wf.sa_, n * 16));
+    HIP_TRY(alloc((void **) &wf.sb_, n * 16));
+    HIP_TRY(alloc((void **) &wf.sd_, n * 16));
+    HIP_TRY(alloc((void **) &wf.se_, n * 16));
+    HIP_TRY(alloc((void **) &wf.hit_, n * 16));
+    HIP_TRY(alloc((void **) &wf.hit_prim_, n * 4));
+    HIP_TRY(alloc((void **) &wf.sh0_, n * 16));
+    HIP_TRY(alloc((void **) &wf.sh1_, n * 16));
+    HIP_TRY(alloc((void **) &wf.sh2_, n * 4));
+    HIP_TRY(alloc((void **) &wf.sh3_, n * 4));
+    HIP_TRY(alloc((void **) &wf.render_, n * 4));
+    HIP_TRY(alloc((void **) &wf.dop_, n * 4));
+#endif
     HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     HIP_TRY(alloc((void **) &scene->roll_ring, bfd::kRollRing * sizeof(bfd::DRoll)));
@@ -1234,9 +1238,9 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     wf.shade_chain = scene->tun.shade_chain;
     wf.row_jobs = scene->tun.row_jobs;
     wf.iq = lp.iq;
-    wf.render = lp.batch != 0u ? scene->wf_render_buf : nullptr;
+    wf.has_render = lp.batch != 0u ? 1u : 0u;
     wf.offsets = lp.batch_offsets;
-    wf.dop = lp.doppler ? scene->wf_dop_buf : nullptr;
+    wf.has_dop = lp.doppler ? 1u : 0u;
     wf.box_slack = lp.box_slack;
     const size_t nb = wf.n_slots / 64;
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
                     need_closest = false;          // traced (and counted) by wf_trace already
                     film = false;
                     if (!(s.flags & kFlagTermPending)) {
-                        float4 hq = wf.hit[slot];
+                        float4 hq = wf.hit(slot);
                         hit.t = hq.x;
                         hit.u = hq.y;
                         hit.v = hq.z;

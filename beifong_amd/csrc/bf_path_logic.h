@@ -46,8 +46,8 @@ struct PathState {
 };
 
 BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
-    float4 r0 = wf.ray0[i], r1 = wf.ray1[i], a = wf.sa[i], bb = wf.sb[i];
-    uint4 d = wf.sd[i];
+    float4 r0 = wf.ray0(i), r1 = wf.ray1(i), a = wf.sa(i), bb = wf.sb(i);
+    uint4 d = wf.sd(i);
     s.ro = mk(r0.x, r0.y, r0.z);
     s.rmint = r0.w;
     s.rd = mk(r1.x, r1.y, r1.z);
@@ -64,10 +64,10 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     s.rng.state = ((uint64_t) d.y << 32) | d.x;
     s.path_i = ((uint64_t) d.w << 32) | d.z;
     s.time = s.t_rx = s.lambda0 = s.phase = 0.f;
-    s.render = wf.render ? wf.render[i] : 0u;
-    s.dlambda = wf.dop ? wf.dop[i] : 0.f;
+    s.render = wf.has_render ? wf.render(i) : 0u;
+    s.dlambda = wf.has_dop ? wf.dop(i) : 0.f;
     if (receive) {
-        float4 e = wf.se[i];
+        float4 e = wf.se(i);
         s.time = e.x;
         s.t_rx = e.y;
         s.lambda0 = e.z;
@@ -75,15 +75,15 @@ BF_DEV void load_state(const WF &wf, uint32_t i, bool receive, PathState &s) {
     }
 }
 BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState &s) {
-    wf.ray0[j] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
-    wf.ray1[j] = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
-    wf.sa[j] = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
-    wf.sb[j] = make_float4(s.aux, s.bs_pdf, __uint_as_float(s.flags), __uint_as_float(s.n_rays));
-    wf.sd[j] = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
+    wf.ray0(j) = make_float4(s.ro.x, s.ro.y, s.ro.z, s.rmint);
+    wf.ray1(j) = make_float4(s.rd.x, s.rd.y, s.rd.z, s.rmaxt);
+    wf.sa(j) = make_float4(s.throughput, s.eta, s.emission_weight, s.result);
+    wf.sb(j) = make_float4(s.aux, s.bs_pdf, __uint_as_float(s.flags), __uint_as_float(s.n_rays));
+    wf.sd(j) = make_uint4((uint32_t) s.rng.state, (uint32_t) (s.rng.state >> 32), (uint32_t) s.path_i,
                           (uint32_t) (s.path_i >> 32));
-    if (receive) wf.se[j] = make_float4(s.time, s.t_rx, s.lambda0, s.phase);
-    if (wf.render) wf.render[j] = s.render;
-    if (wf.dop) wf.dop[j] = s.dlambda;
+    if (receive) wf.se(j) = make_float4(s.time, s.t_rx, s.lambda0, s.phase);
+    if (wf.has_render) wf.render(j) = s.render;
+    if (wf.has_dop) wf.dop(j) = s.dlambda;
 }
 // Shape::doppler — src/librender/shape.cpp:375-389 (call sites commented out at the reference's HEAD:
 // pathtimefrequency.cpp:141-144, 180-183): 2 dot(si.wi, m_velocity * Point3f(si.to_local(si.p))) / MTS_C * wavelength

@@ -28,23 +28,58 @@ constexpr uint32_t kTraceBlocksPerCU = 8;
 constexpr uint32_t kTailSmallPool = 1u << 22;   // pools below this never fill the chip: earlier hand-over to the tail (bf_api.cpp: wf_tail_threshold)
 constexpr uint32_t kTailRowJobs = 12;      // tail: up to three passes of four row-traversed rays beat one quad pass of sixteen
 
+// Per-slot state layout.  BF_STATE_AOS = 1 (default since round 3): three 64-byte RECORDS per slot,
+//   A = ray0, ray1, hit, (hit_prim, render, dop, -)      what wf_trace reads / writes for a closest-hit ray: ONE line
+//   B = sa, sb, sd, se                                   the rest of the path state (wf_shade; wf_trace adds a released
+//                                                        NEE contribution to sa.w / se.w)
+//   C = sh0, sh1, (sh2, sh3, -, -), -                    the NEE shadow request
+// Most launches GATHER sparse slots through the mask cursor (a few per cent to a third of a batch alive): with one
+// array per row (BF_STATE_AOS = 0, rounds 1-2: "a wave touching one dense batch reads 1 KiB contiguous per array") a
+// gathered lane touches seven cache lines for its state and six more to write it back; with records, two and two.
+#ifndef BF_STATE_AOS
+#define BF_STATE_AOS 1
+#endif
+#define BF_HD __host__ __device__ __forceinline__
+
 struct WF {
-    // path state [n_slots]
-    float4 *ray0;       // o.xyz, mint
-    float4 *ray1;       // d.xyz, maxt
-    float4 *sa;         // throughput, eta, emission_weight, result
-    float4 *sb;         // aux, bs_pdf, depth|flags (bits), n_rays (bits)
-    uint4 *sd;          // rng state lo/hi, path index lo/hi
-    float4 *se;         // receive mode only: ray.time, t_rx, lambda0, -
-    float4 *hit;        // t, u, v, triangle slot
-    uint32_t *hit_prim; // global primitive index of `hit` (tie rule) while a ray is in flight
-    // NEE shadow ray of the slot (valid iff its shadow bit is set)
-    float4 *sh0;        // o.xyz, mint
-    float4 *sh1;        // d.xyz, maxt
-    float *sh2;         // contribution released when unoccluded
-    float *sh3;         // BF_MODE_RECEIVE_IQ: its imaginary part
-    float *dop;         // BF_FLAG_DOPPLER: wavelength shift accumulated by the slot's path (nm); nullptr when the hook is off
-    uint32_t *render;   // batched launches: render index of the slot's current path (selects the mesh offset)
+#if BF_STATE_AOS
+    float4 *recA, *recB, *recC;     // [n_slots][4] float4 each
+    BF_HD float4 &ray0(uint32_t i) const { return recA[4 * (size_t) i + 0]; }       // o.xyz, mint
+    BF_HD float4 &ray1(uint32_t i) const { return recA[4 * (size_t) i + 1]; }       // d.xyz, maxt
+    BF_HD float4 &hit(uint32_t i) const { return recA[4 * (size_t) i + 2]; }        // t, u, v, triangle slot
+    BF_HD uint32_t &hit_prim(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + 4 * (size_t) i + 3)[0]; }
+    BF_HD uint32_t &render(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + 4 * (size_t) i + 3)[1]; }
+    BF_HD float &dop(uint32_t i) const { return reinterpret_cast<float *>(recA + 4 * (size_t) i + 3)[2]; }
+    BF_HD float4 &sa(uint32_t i) const { return recB[4 * (size_t) i + 0]; }         // throughput, eta, emission_weight, result
+    BF_HD float4 &sb(uint32_t i) const { return recB[4 * (size_t) i + 1]; }         // aux, bs_pdf, depth|flags (bits), n_rays (bits)
+    BF_HD uint4 &sd(uint32_t i) const { return reinterpret_cast<uint4 *>(recB)[4 * (size_t) i + 2]; }   // rng state lo/hi, path index lo/hi
+    BF_HD float4 &se(uint32_t i) const { return recB[4 * (size_t) i + 3]; }         // receive mode: ray.time, t_rx, lambda0, phase / Q
+    BF_HD float4 &sh0(uint32_t i) const { return recC[4 * (size_t) i + 0]; }        // shadow ray o.xyz, mint
+    BF_HD float4 &sh1(uint32_t i) const { return recC[4 * (size_t) i + 1]; }        // d.xyz, maxt
+    BF_HD float &sh2(uint32_t i) const { return reinterpret_cast<float *>(recC + 4 * (size_t) i + 2)[0]; }   // contribution released when unoccluded
+    BF_HD float &sh3(uint32_t i) const { return reinterpret_cast<float *>(recC + 4 * (size_t) i + 2)[1]; }   // BF_MODE_RECEIVE_IQ: its imaginary part
+#else
+    float4 *ray0_, *ray1_, *sa_, *sb_, *se_, *hit_, *sh0_, *sh1_;
+    uint4 *sd_;
+    uint32_t *hit_prim_, *render_;
+    float *sh2_, *sh3_, *dop_;
+    BF_HD float4 &ray0(uint32_t i) const { return ray0_[i]; }
+    BF_HD float4 &ray1(uint32_t i) const { return ray1_[i]; }
+    BF_HD float4 &hit(uint32_t i) const { return hit_[i]; }
+    BF_HD uint32_t &hit_prim(uint32_t i) const { return hit_prim_[i]; }
+    BF_HD uint32_t &render(uint32_t i) const { return render_[i]; }
+    BF_HD float &dop(uint32_t i) const { return dop_[i]; }
+    BF_HD float4 &sa(uint32_t i) const { return sa_[i]; }
+    BF_HD float4 &sb(uint32_t i) const { return sb_[i]; }
+    BF_HD uint4 &sd(uint32_t i) const { return sd_[i]; }
+    BF_HD float4 &se(uint32_t i) const { return se_[i]; }
+    BF_HD float4 &sh0(uint32_t i) const { return sh0_[i]; }
+    BF_HD float4 &sh1(uint32_t i) const { return sh1_[i]; }
+    BF_HD float &sh2(uint32_t i) const { return sh2_[i]; }
+    BF_HD float &sh3(uint32_t i) const { return sh3_[i]; }
+#endif
+    uint32_t has_render;     // batched / rolling launches: render(i) = render index of the slot's current path (selects seed, histogram, mesh offset)
+    uint32_t has_dop;        // BF_FLAG_DOPPLER: dop(i) = wavelength shift accumulated by the slot's path (nm)
     const float4 *offsets;   // batched launches with moving meshes: DLaunch::batch_offsets (wf_trace has no DLaunch)
     float box_slack;
     // batch masks, double buffered by bounce parity: [2][n_slots / 64]

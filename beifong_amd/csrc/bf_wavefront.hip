@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                 // the slot's last finished path in a wake launch
                 s.path_i = (uint64_t) slot - (uint64_t) wf.n_main;
                 if (FIRST == 2) {
-                    const uint4 d = wf.sd[slot];
+                    const uint4 d = wf.sd(slot);
                     s.path_i = ((uint64_t) d.w << 32) | d.z;
                 }
             } else {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
                     film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
                     need_gen = true;
                 } else {
-                    float4 hq = wf.hit[slot];
+                    float4 hq = wf.hit(slot);
                     hit.t = hq.x;
                     hit.u = hq.y;
                     hit.v = hq.z;
@@ -358,21 +358,21 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         if (has && cont) {
             if (!(s.flags & kFlagTermPending)) {
                 // resolved rays carry their final hit; the others start wf_trace from the rectangle hit
-                wf.hit[dst] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
-                wf.hit_prim[dst] = hit.prim;
+                wf.hit(dst) = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
+                wf.hit_prim(dst) = hit.prim;
             }
             store_state(wf, dst, receive, s);
             ++c_live;
             if (shadowing) {
-                wf.sh0[dst] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
-                wf.sh1[dst] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
-                wf.sh2[dst] = sh.c;
-                if (receive && lp.iq) wf.sh3[dst] = sh.c_im;
+                wf.sh0(dst) = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
+                wf.sh1(dst) = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
+                wf.sh2(dst) = sh.c;
+                if (receive && lp.iq) wf.sh3(dst) = sh.c_im;
             }
         } else if (has && rolling && touched) {
             // the slot has run out of paths for now: remember the last one it rendered, so that the wake launch of the
             // sequence's next call continues from there (a path that started and ended within this visit was never stored)
-            wf.sd[slot] = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
+            wf.sd(slot) = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
         }
         cont = has && cont;
         tracing = cont && tracing;
@@ -497,12 +497,12 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                     job = slot;
                     float4 r0, r1;
                     if (phase_shadow) {
-                        r0 = wf.sh0[slot];
-                        r1 = wf.sh1[slot];
+                        r0 = wf.sh0(slot);
+                        r1 = wf.sh1(slot);
                         any = true;
                     } else {
-                        r0 = wf.ray0[slot];
-                        r1 = wf.ray1[slot];
+                        r0 = wf.ray0(slot);
+                        r1 = wf.ray1(slot);
                         any = false;
                     }
                     o = mk(r0.x, r0.y, r0.z);
@@ -517,15 +517,15 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                     best.slot = 0;
                     if (!phase_shadow) {
                         // closest-hit rays continue from the rectangle hit wf_shade found (presolve_ray)
-                        float4 hq = wf.hit[slot];
+                        float4 hq = wf.hit(slot);
                         best.t = hq.x;
                         best.u = hq.y;
                         best.v = hq.z;
                         best.slot = __float_as_int(hq.w);
-                        best.prim = wf.hit_prim[slot];
+                        best.prim = wf.hit_prim(slot);
                     }
                     if (SHIFT) {
-                        shf = make_shift(wf.offsets, wf.render[slot], wf.box_slack);
+                        shf = make_shift(wf.offsets, wf.render(slot), wf.box_slack);
                         ray_inverse_shift(o, d, shf, id, oid, ohi);
                     } else {
                         ray_inverse(o, d, id, oid);
@@ -588,22 +588,22 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 if (any) {
                     // Scene::ray_test resolved: an unoccluded shadow ray releases its NEE contribution
                     // (an occluded sample contributes c * 0, scene.cpp:220-224: only a non-finite c leaves a trace)
-                    const float c = wf.sh2[job];
+                    const float c = wf.sh2(job);
                     if (!found || !__builtin_isfinite(c)) {
-                        float4 a = wf.sa[job];
+                        float4 a = wf.sa(job);
                         a.w += found ? c * 0.f : c;
-                        wf.sa[job] = a;
+                        wf.sa(job) = a;
                     }
                     if (wf.iq) {                     // BF_MODE_RECEIVE_IQ: imaginary accumulator lives in se.w
-                        const float ci = wf.sh3[job];
+                        const float ci = wf.sh3(job);
                         if (!found || !__builtin_isfinite(ci)) {
-                            float4 e = wf.se[job];
+                            float4 e = wf.se(job);
                             e.w += found ? ci * 0.f : ci;
-                            wf.se[job] = e;
+                            wf.se(job) = e;
                         }
                     }
                 } else {
-                    wf.hit[job] = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
+                    wf.hit(job) = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
                 }
                 has = false;
             }
