@@ -697,7 +697,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     if (sc->tun.wide_rows_log >= 0) wide_rlog = std::min<uint32_t>(wide_rlog, (uint32_t) sc->tun.wide_rows_log);
     for (int k = 0; k < 3 && !btris.empty(); ++k)
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
-    std::vector<float4> tri_data(3 * btris.size()), nrm_data;
+    std::vector<float4> tri_data(bfd::kTriStride * btris.size(), make_float4(0, 0, 0, 0)), nrm_data;
     if (any_normals) nrm_data.resize(3 * btris.size());
     std::vector<float4> uv_data;
     if (flat.any_uvs) uv_data.assign(btris.size(), make_float4(0, 0, 0, 0));
@@ -719,9 +719,9 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         std::memcpy(&w0, &m.prim, 4);
         std::memcpy(&w1, &m.shape, 4);
         std::memcpy(&w2, &has_n, 4);
-        tri_data[3 * slot + 0] = make_float4(t.p0[0], t.p0[1], t.p0[2], w0);
-        tri_data[3 * slot + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], w1);
-        tri_data[3 * slot + 2] = make_float4(t.p2[0], t.p2[1], t.p2[2], w2);
+        tri_data[bfd::kTriStride * slot + 0] = make_float4(t.p0[0], t.p0[1], t.p0[2], w0);
+        tri_data[bfd::kTriStride * slot + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], w1);
+        tri_data[bfd::kTriStride * slot + 2] = make_float4(t.p2[0], t.p2[1], t.p2[2], w2);
         if (any_normals) {
             if (m.n0) {
                 nrm_data[3 * slot + 0] = make_float4(m.n0[0], m.n0[1], m.n0[2], 0.f);
@@ -829,7 +829,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     inf.n_bvh_nodes = sc->d.n_nodes;
     inf.node_bytes = (uint32_t) sizeof(bf::Node4);
     inf.trace_node_bytes = sc->d.qnodes ? (uint32_t) sizeof(bf::Node4Q) : (uint32_t) sizeof(bf::Node4);
-    inf.tri_bytes = 48;
+    inf.tri_bytes = 16 * bfd::kTriStride;
     inf.bvh_depth = bvh4.max_depth;
     inf.bvh_stack_need = bvh4.stack_need;
     inf.device_bytes = bytes;
@@ -923,7 +923,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         if (ost == BF_OK) ost = close_sequence(scene, stream);
         if (ost != BF_OK) return ost;
     }
-    const size_t tri_bytes = (size_t) scene->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
+    const size_t tri_bytes = (size_t) scene->d.n_tris * bfd::kTriStride * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
     const size_t wnode_bytes = scene->d.wnodes ? (size_t) scene->d.n_wnodes * 32 * sizeof(float4) : 0;
     const bool shared = scene->geom_token.use_count() > 1 && !scene->geom_private;
     // all-or-nothing allocation: the handle's pointers change only once every copy exists (a failed hipMalloc half way
@@ -976,7 +976,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         scene->nodes0 = cp.p[1];
         scene->wnodes0 = cp.p[2];
     }
-    HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * 3, scene->nodes0,
+    HIP_TRY(bfk_launch_translate(scene->tris0, const_cast<float4 *>(scene->d.tris), scene->d.n_tris * bfd::kTriStride, scene->nodes0,
                                  const_cast<float4 *>(scene->d.nodes), const_cast<float4 *>(scene->d.qnodes), scene->d.n_nodes, scene->wnodes0,
                                  const_cast<float4 *>(scene->d.wnodes), wnode_bytes ? scene->d.n_wnodes * 16u : 0u, offset, stream));
     return mark_last(scene, stream);
@@ -1034,7 +1034,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     if (src->tris0 || src->geom_private) {
         // `src` has been translated (in place, or into its own copies): the clone takes a snapshot of the geometry
         // src renders now as ITS geometry "as created"; normals / texture coordinates stay shared
-        const size_t tri_bytes = (size_t) src->d.n_tris * 3 * sizeof(float4), node_bytes = (size_t) src->d.n_nodes * 8 * sizeof(float4);
+        const size_t tri_bytes = (size_t) src->d.n_tris * bfd::kTriStride * sizeof(float4), node_bytes = (size_t) src->d.n_nodes * 8 * sizeof(float4);
         const size_t wnode_bytes = src->d.wnodes ? (size_t) src->d.n_wnodes * 32 * sizeof(float4) : 0;
         if ((st = dup(src->d.tris, tri_bytes, (const void **) &sc->d.tris)) != BF_OK) return fail_out(st);
         if ((st = dup(src->d.nodes, node_bytes, (const void **) &sc->d.nodes)) != BF_OK) return fail_out(st);

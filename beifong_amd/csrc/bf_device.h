@@ -3,10 +3,12 @@
 //
 // HBM layout (DESIGN.md "Data layout"):
 //   nodes   : bf::Node4[n_nodes]     128 B each, four child boxes (SoA) + four child references
-//   tris    : float4[3 * n_tris]     48 B per triangle, BVH leaf order:
+//   tris    : float4[kTriStride * n_tris]   48 B per triangle (kTriStride = 3), BVH leaf order:
 //               q0 = (p0.xyz, bits(global prim index))
 //               q1 = (p1.xyz, bits(shape index))
 //               q2 = (p2.xyz, tag: normals / texcoords bits, material, emitter)
+//             (-DBF_TRI_STRIDE=4 pads every record to 64 bytes so that none straddles a sector: measured, no difference
+//              on any config — profiles/r03_tri_record_ab.txt — so the 48-byte records of SURVEY 8d stay)
 //   normals : float4[3 * n_tris]     only if some mesh carries vertex normals
 //   uvs     : float4[n_tris]         (uv1 - uv0, uv2 - uv0), only if some mesh carries texture coordinates
 //   rects, shapes, materials, emitters : small tables (scenes hold a handful)
@@ -18,6 +20,10 @@
 
 namespace bfd {
 
+#ifndef BF_TRI_STRIDE
+#define BF_TRI_STRIDE 3
+#endif
+constexpr uint32_t kTriStride = BF_TRI_STRIDE;      // float4 per triangle record
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kStackDepth = 32;      // per-lane traversal stack entries in LDS
 constexpr int kMaxLdsHist = 12288;   // floats of LDS-privatised histogram (48 KiB)

@@ -309,7 +309,7 @@ BF_DEV bool leaf_intersect(const DScene &sc, int node, bool any, V3 o, V3 d, flo
     const uint32_t enc = ~(uint32_t) node;
     const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
-        const float4 *tp = sc.tris + 3u * (first + i);
+        const float4 *tp = sc.tris + kTriStride * (first + i);
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) ++n_tris;
         float t, u, v;
@@ -459,7 +459,7 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
             const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
             bool tri_hit = false;
             for (uint32_t i = (uint32_t) q; i < cnt; i += 4u) {
-                const float4 *tp = sc.tris + 3u * (first + i);
+                const float4 *tp = sc.tris + kTriStride * (first + i);
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 if (STATS) ++n_tris;
                 float t, u, v;
@@ -594,7 +594,7 @@ BF_DEV void traverse_row16(const DScene &sc, uint32_t rlog, bool active, bool an
             ptr = sc.wnodes + (32u * (uint32_t) node + 2u * j);
             ld = true;
         } else if (is_leaf) {
-            ptr = sc.tris + 3u * (first + j);
+            ptr = sc.tris + kTriStride * (first + j);
             ld = j < cnt;
         }
         float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa, qc = qa;
@@ -716,7 +716,7 @@ template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, c
             geom->dp_dv = mk(rc.t[0], rc.t[1], rc.t[2]);
         }
     } else {
-        const float4 *tp = sc.tris + 3 * (size_t) h.slot;
+        const float4 *tp = sc.tris + kTriStride * (size_t) h.slot;
         float4 a = tp[0], b = tp[1], c = tp[2];
         // the vertex normals are fetched together with the positions, not after the tag has arrived (one dependent
         // memory round trip less per shaded vertex); scenes without any normals skip the load
