@@ -1118,8 +1118,13 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     };
     size_t n = capacity, nb = capacity / 64;
 #if BF_STATE_AOS
+#if BF_STATE_AOS == 2
+    HIP_TRY(alloc((void **) &wf.recA, n * 128));
+    wf.recB = wf.recA + 4;
+#else
     HIP_TRY(alloc((void **) &wf.recA, n * 64));
     HIP_TRY(alloc((void **) &wf.recB, n * 64));
+#endif
     HIP_TRY(alloc((void **) &wf.recC, n * 64));
 #else
     HIP_TRY(alloc((void **) &wf.ray0_, n * 16));

@@ -43,17 +43,19 @@ constexpr uint32_t kTailRowJobs = 12;      // tail: up to three passes of four r
 
 struct WF {
 #if BF_STATE_AOS
+    // BF_STATE_AOS = 2: records A and B of a slot are the two halves of ONE 128-byte line (recB = recA + 4, stride 8)
+    static constexpr size_t kAB = BF_STATE_AOS == 2 ? 8 : 4;
     float4 *recA, *recB, *recC;     // [n_slots][4] float4 each
-    BF_HD float4 &ray0(uint32_t i) const { return recA[4 * (size_t) i + 0]; }       // o.xyz, mint
-    BF_HD float4 &ray1(uint32_t i) const { return recA[4 * (size_t) i + 1]; }       // d.xyz, maxt
-    BF_HD float4 &hit(uint32_t i) const { return recA[4 * (size_t) i + 2]; }        // t, u, v, triangle slot
-    BF_HD uint32_t &hit_prim(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + 4 * (size_t) i + 3)[0]; }
-    BF_HD uint32_t &render(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + 4 * (size_t) i + 3)[1]; }
-    BF_HD float &dop(uint32_t i) const { return reinterpret_cast<float *>(recA + 4 * (size_t) i + 3)[2]; }
-    BF_HD float4 &sa(uint32_t i) const { return recB[4 * (size_t) i + 0]; }         // throughput, eta, emission_weight, result
-    BF_HD float4 &sb(uint32_t i) const { return recB[4 * (size_t) i + 1]; }         // aux, bs_pdf, depth|flags (bits), n_rays (bits)
-    BF_HD uint4 &sd(uint32_t i) const { return reinterpret_cast<uint4 *>(recB)[4 * (size_t) i + 2]; }   // rng state lo/hi, path index lo/hi
-    BF_HD float4 &se(uint32_t i) const { return recB[4 * (size_t) i + 3]; }         // receive mode: ray.time, t_rx, lambda0, phase / Q
+    BF_HD float4 &ray0(uint32_t i) const { return recA[kAB * (size_t) i + 0]; }       // o.xyz, mint
+    BF_HD float4 &ray1(uint32_t i) const { return recA[kAB * (size_t) i + 1]; }       // d.xyz, maxt
+    BF_HD float4 &hit(uint32_t i) const { return recA[kAB * (size_t) i + 2]; }        // t, u, v, triangle slot
+    BF_HD uint32_t &hit_prim(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + kAB * (size_t) i + 3)[0]; }
+    BF_HD uint32_t &render(uint32_t i) const { return reinterpret_cast<uint32_t *>(recA + kAB * (size_t) i + 3)[1]; }
+    BF_HD float &dop(uint32_t i) const { return reinterpret_cast<float *>(recA + kAB * (size_t) i + 3)[2]; }
+    BF_HD float4 &sa(uint32_t i) const { return recB[kAB * (size_t) i + 0]; }         // throughput, eta, emission_weight, result
+    BF_HD float4 &sb(uint32_t i) const { return recB[kAB * (size_t) i + 1]; }         // aux, bs_pdf, depth|flags (bits), n_rays (bits)
+    BF_HD uint4 &sd(uint32_t i) const { return reinterpret_cast<uint4 *>(recB)[kAB * (size_t) i + 2]; }   // rng state lo/hi, path index lo/hi
+    BF_HD float4 &se(uint32_t i) const { return recB[kAB * (size_t) i + 3]; }         // receive mode: ray.time, t_rx, lambda0, phase / Q
     BF_HD float4 &sh0(uint32_t i) const { return recC[4 * (size_t) i + 0]; }        // shadow ray o.xyz, mint
     BF_HD float4 &sh1(uint32_t i) const { return recC[4 * (size_t) i + 1]; }        // d.xyz, maxt
     BF_HD float &sh2(uint32_t i) const { return reinterpret_cast<float *>(recC + 4 * (size_t) i + 2)[0]; }   // contribution released when unoccluded
