@@ -122,7 +122,7 @@ struct bf_tunables {
     int tail_share = -1;                     // BF_TAIL_SHARE: waves per batch in a stand-alone render's tail (-1: by pool size)
     bool allow_plan = true;                  // BF_WF_SYNC=1 turns launch plans off
     uint32_t roll_iters = 0;                 // BF_ROLL_ITERS: bounce iterations per call of a rolling sequence (0: adaptive)
-    uint32_t roll_live = 1u << 20;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
+    uint32_t roll_live = 3u << 19;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
     bool no_wide = false, quant = false;
     int wide_rows_log = -1;
 };
@@ -149,7 +149,7 @@ static bf_tunables read_tunables() {
     t.tail_share = (int) num("BF_TAIL_SHARE", -1);
     t.allow_plan = num("BF_WF_SYNC", 0) == 0;
     t.roll_iters = (uint32_t) std::max<long long>(0, std::min<long long>(32, num("BF_ROLL_ITERS", 0)));
-    t.roll_live = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_ROLL_LIVE", 1ll << 20), 1ll << 30));
+    t.roll_live = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_ROLL_LIVE", 3ll << 19), 1ll << 30));
     t.no_wide = getenv("BF_NO_WIDE_BVH") != nullptr;
     t.quant = num("BF_QUANT_BVH", 0) != 0;
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
@@ -1537,7 +1537,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
     }
     // ---- how many bounce iterations this call enqueues ------------------------------------------------
     // A launch that finds fewer live slots than fill the chip a few times over runs at its latency floor whatever it
-    // holds, so a call stops iterating once that few are left (roll_live, 2^20 by default) and leaves them to the next
+    // holds, so a call stops iterating once that few are left (roll_live, 1.5 x 2^20 by default: tools/r03_probe9.sh) and leaves them to the next
     // call's launches: too few iterations and too many paths have to move to the survivor area, too many and the late ones
     // run over a nearly empty pool.  Steered by the live counts that come back (without ever waiting for them).
     const bool fb_ready = scene->wf_fb_pending && hipEventQuery(scene->wf_fb_event) == hipSuccess;
