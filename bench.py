@@ -303,6 +303,14 @@ def main():
             with torch.cuda.stream(streams[0]):
                 add_stats(iso, handles[0].render_device(w.launch(i, 0), hists[i].data_ptr(), stream=streams[0].cuda_stream, want_stats=True))
         iso["n"] = min(args.steps, 5)
+        # a stand-alone render closes handle 0's rolling sequence and resets what the handle had learnt about it (iterations per
+        # call, flush plan): learn it again, untimed, as before the warm-up steps
+        for rep in range(2 if rolling else 0):
+            begin(n_streams)
+            for j in range(n_streams):
+                step(j)
+            finish(n_streams)
+            sync()
 
     # timed region: EXACTLY `steps` steps, no instrumentation, barrier + synchronize on both sides; every histogram of the
     # region is complete (flushed, and reduced for N > 1) when the clock stops
