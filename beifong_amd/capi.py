@@ -56,6 +56,14 @@ class bf_emitter(C.Structure):
                 ("resample_freq", C.c_uint32), ("array", bf_phased_array)]
 
 
+BF_FILTER_RESOLUTION = 31
+
+
+class bf_rfilter(C.Structure):
+    _fields_ = [("radius", C.c_float), ("scale", C.c_float), ("border", C.c_uint32), ("block_size", C.c_uint32),
+                ("values", C.c_float * (BF_FILTER_RESOLUTION + 1))]
+
+
 class bf_sensor(C.Structure):
     _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("to_world", M16), ("sample_to_camera", M16),
                 ("fov_x_deg", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
@@ -65,7 +73,7 @@ class bf_sensor(C.Structure):
                 ("t_bins", C.c_uint32), ("f_bins", C.c_uint32),
                 ("t_bandwidth", C.c_float), ("f_bandwidth", C.c_float),
                 ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32),
-                ("array", bf_phased_array)]
+                ("array", bf_phased_array), ("rfilter", bf_rfilter)]
 
 
 class bf_physics(C.Structure):

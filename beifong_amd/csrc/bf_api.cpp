@@ -619,6 +619,21 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
     } else {
         return fail(BF_ERR_UNSUPPORTED, "sensor type %u not supported by this build", desc->sensor.type);
     }
+    {
+        // ImageBlock::put / SignalBlock::put take the filtered branch iff radius > 0.5 + RayEpsilon (imageblock.cpp:115)
+        const bf_rfilter &rf = desc->sensor.rfilter;
+        const float ray_eps = 1500.f * 5.9604644775390625e-8f;          // math::RayEpsilon<float> = Epsilon * 1500
+        if (!(rf.radius >= 0.f) || !std::isfinite(rf.radius) || rf.radius > 64.f) return fail(BF_ERR_INVALID, "reconstruction filter radius %g", rf.radius);
+        if (rf.radius > .5f + ray_eps) {
+            sen.filt_n = (uint32_t) std::ceil((rf.radius - 2.f * ray_eps) * 2.f);
+            sen.filt_border = rf.border;
+            sen.filt_block = rf.block_size;
+            sen.filt_radius = rf.radius;
+            sen.filt_scale = rf.scale;
+            for (int k = 0; k <= BF_FILTER_RESOLUTION; ++k) sen.filt_tab[k] = rf.values[k];
+            if (rf.border > 64u || !(rf.scale > 0.f)) return fail(BF_ERR_INVALID, "reconstruction filter: border %u, scale %g", rf.border, rf.scale);
+        }
+    }
     sen.near_clip = desc->sensor.near_clip;
     sen.far_clip = desc->sensor.far_clip;
     sen.shutter_open = desc->sensor.shutter_open;
@@ -1805,6 +1820,7 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);
     lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
+    lp.wide = scene->sensor_host.filt_n != 0u ? 1u : 0u;      // reconstruction filter wider than a pixel: the kernels' kWide variants
     lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
     lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;

@@ -78,6 +78,11 @@ struct DSensor {
     const float *velems;      // BF_RECEIVER_PHASED (phasedreceiver.cpp:115-172)
     uint32_t n_velems;
     float wid[3];
+    // reconstruction filter of the film / ADC (bf_rfilter); filt_n = 0: put()'s box branch
+    uint32_t filt_n;          // ceil((radius - 2 RayEpsilon) * 2): weights per axis (imageblock.cpp:121)
+    uint32_t filt_border, filt_block;
+    float filt_radius, filt_scale;
+    float filt_tab[32];
 };
 
 struct DScene {
@@ -151,6 +156,7 @@ struct DLaunch {
     uint32_t lds_floats;            // floats of dynamic LDS the histogram code zeroes: the privatised histogram (n_chan_all, if lds_hist)
                                     // followed, in a rolling launch, by the base-channel table [kRollBase][5] at float offset base_off
     uint32_t base_off;
+    uint32_t wide;                  // 1: the sensor's reconstruction filter is wider than a pixel (DSensor::filt_n != 0): the kernels' kWide variants
 };
 
 // device counters (uint64 each)

@@ -44,10 +44,11 @@ __device__ unsigned long long g_tail_prof[8192 * 24];
 #else
 #define BF_PROF_STAMP(var)
 #endif
-template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES>
+template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
+    constexpr int kRX = 2 | (WIDE ? kWide : 0);       // mode decided at run time; WIDE: the filtered put (bf_path_logic.h: kWide)
     extern __shared__ __align__(16) unsigned char s_raw[];
     int *s_stack = reinterpret_cast<int *>(s_raw);                         // [kStackDepth][kBlock]
     float *s_hist = reinterpret_cast<float *>(s_raw + sizeof(int) * kStackDepth * kBlock);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
                 if (path_i >= lp.n_paths) {
                     done = true;
                 } else {
-                    generate_path(sc, lp, path_i, s);
+                    generate_path<kRX>(sc, lp, path_i, s);
                     alive = true;
                     need_closest = true;
                     film = false;
@@ -344,14 +345,14 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         // ---- 3. film: paths that ended at the vertex shaded last iteration (their last shadow ray
         //         has resolved by now) ---------------------------------------------------------------
         if (alive && (film || term_pending)) {
-            film_put(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+            film_put<kRX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
             alive = false;
             film = false;
             if (RESUME) {
                 // the slot's static path sequence: i, i + n_slots, i + 2 n_slots, ...
                 uint64_t next_path = s.path_i + resume_slots;
                 if (regen_ok && next_path < lp.n_paths) {
-                    generate_path(sc, lp, next_path, s);
+                    generate_path<kRX>(sc, lp, next_path, s);
                     alive = true;
                     need_closest = true;
                 }
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         BF_PROF_STAMP(pf_t3);
         // ---- 4. vertex logic for the lanes that hold a fresh hit ---------------------------------
         if (alive && !need_closest) {
-            if (!shade_vertex(sc, lp, s, hit, sh, c_bounces
+            if (!shade_vertex<kRX>(sc, lp, s, hit, sh, c_bounces
 #ifdef BF_TAIL_PROF
                               , &pf_sp
 #endif
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     }
 #endif
 
-    film_flush(lp, acc, s_hist, g_hist, lds_hist, tid);
+    film_flush<kRX>(lp, acc, s_hist, g_hist, lds_hist, tid);
     // statistics: wave-reduce then one atomic per counter per wave
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_nodes = c_nodes, v_tris = c_tris,
                        v_invalid = acc.invalid, v_bounces = c_bounces, v_wnodes = c_wnodes;
@@ -539,15 +540,19 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
     bfd::WF none;
     memset(&none, 0, sizeof(none));
     const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
-#define BF_RENDER_LAUNCH(S, R, P, WF_, IT_)                                                                                  \
-    hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
-                       records, counters, WF_, IT_)
+#define BF_RENDER_LAUNCH(S, R, P, WF_, IT_)                                                                                              \
+    if (lp->wide)                                                                                                                        \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P, BF_TAIL_WAVES, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, \
+                           *lp, g_hist, records, counters, WF_, IT_);                                                                    \
+    else                                                                                                                                 \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist,         \
+                           records, counters, WF_, IT_)
     if (stats) {
-        if (spill) BF_RENDER_LAUNCH(true, false, true, none, 0u);
-        else BF_RENDER_LAUNCH(true, false, false, none, 0u);
+        if (spill) { BF_RENDER_LAUNCH(true, false, true, none, 0u); }
+        else { BF_RENDER_LAUNCH(true, false, false, none, 0u); }
     } else {
-        if (spill) BF_RENDER_LAUNCH(false, false, true, none, 0u);
-        else BF_RENDER_LAUNCH(false, false, false, none, 0u);
+        if (spill) { BF_RENDER_LAUNCH(false, false, true, none, 0u); }
+        else { BF_RENDER_LAUNCH(false, false, false, none, 0u); }
     }
     return hipGetLastError();
 }
@@ -577,7 +582,10 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     unsigned long long *counters = wf->counters;
     const bool two = tail_waves == 2;
 #define BF_TAIL_LAUNCH(S, P)                                                                                                           \
-    if (two)                                                                                                                           \
+    if (lp->wide)                                                                                                                      \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,   \
+                           g_hist, records, counters, *wf, it);                                                                       \
+    else if (two)                                                                                                                      \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 2>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
                            records, counters, *wf, it);                                                                               \
     else                                                                                                                               \

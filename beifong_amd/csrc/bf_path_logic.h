@@ -406,7 +406,11 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
 // Mode specialisation: RX = 0 compiles the render modes only (path / range / time), RX = 1 the receive modes only,
 // RX = 2 decides at run time (the one-kernel variant and the tail).  The receive branches carry the Wigner / phased-array
 // / signal-model code; a shading kernel that cannot reach them allocates fewer registers.
-template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return RX == 2 ? lp.mode == BF_MODE_RECEIVE_RAW : RX == 1; }
+template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return (RX & 3) == 2 ? lp.mode == BF_MODE_RECEIVE_RAW : (RX & 3) == 1; }
+// RX | kWide: the kernel variant for films / ADCs whose reconstruction filter is wider than a pixel (DLaunch::wide).  A variant
+// of its own, not a branch: the filtered put's live values cost the box-filter kernels 3 % of wf_shade when both were compiled
+// into one (profiles/r03_wide_filter_ab.txt), and every radar scene of the reference uses the box filter.
+constexpr int kWide = 4;
 
 // ---------------------------------------------------------------------------
 // path generation
@@ -751,6 +755,99 @@ struct FilmAcc {
     uint32_t invalid;
 };
 
+// ImageBlock::put / SignalBlock::put, the branch for reconstruction filters wider than a pixel (imageblock.cpp:115-165,
+// signalblock.cpp:117-161): every channel of the sample goes, times wy * wx, to the cells within `radius` of its position;
+// the weights are the host's discretised filter (bf_rfilter), looked up as eval_discretized does (rfilter.h:62-65).
+// The sample sits in the block that rendered it: offset `off` (a multiple of bf_rfilter.block_size, integrator.cpp:139-142;
+// the ADC is one block), size `bsz`, a border of filt_border cells around it; what lands in the border or outside the
+// storage is dropped when the block is added to the film (imageblock.cpp:56-74 put(block): accumulate_2d clips).
+struct WideSample {
+    float posx, posy;         // pos_ as put() receives it
+    int offx, offy;           // block offset
+    int bw, bh;               // block size (without border)
+    int W, H;                 // storage extent in cells
+    uint32_t C;               // channels per cell
+    float v0, v1, v2, v3, v4; // base channels (scalars, no indexed array: the hot kernels must stay free of scratch)
+    bool five;                // five base channels (render modes) or three (receive modes)
+    int ech;                  // channel of the first candidate extra bin (may be negative: that candidate is masked out)
+    uint32_t emask;           // candidates that take the sample (bit i: bin i of the three)
+    bool e3;                  // three values per bin (time mode) or one
+    float e0, e1, e2;
+};
+BF_DEV float filt_eval(const DSensor &se, float x) {
+    const int idx = min((int) __builtin_fabsf(x * se.filt_scale), 31);
+    return se.filt_tab[idx];
+}
+BF_DEV void put_wide_add(const HistDst &hd, uint32_t idx, float v, float w) {
+    const float a = v * w;          // value[k] * weight (imageblock.cpp:160)
+    if (a != 0.f) hist_add(hd.s, hd.g, hd.lds, idx, a);
+}
+BF_DEV void put_wide(const DSensor &se, const WideSample &ws, const HistDst &hd) {
+    const int border = (int) se.filt_border, n = (int) se.filt_n;
+    const float r = se.filt_radius;
+    // pos = pos_ - (m_offset - m_border_size + .5f)
+    const float px = ws.posx - ((float) (ws.offx - border) + .5f), py = ws.posy - ((float) (ws.offy - border) + .5f);
+    const int sx = ws.bw + 2 * border, sy = ws.bh + 2 * border;
+    const int lox = max((int) __builtin_ceilf(px - r), 0), loy = max((int) __builtin_ceilf(py - r), 0);
+    const int hix = min((int) __builtin_floorf(px + r), sx - 1), hiy = min((int) __builtin_floorf(py + r), sy - 1);
+    const float basex = (float) lox - px, basey = (float) loy - py;
+    const int estep = ws.e3 ? 3 : 1;
+    for (int yr = 0; yr < n; ++yr) {
+        const int y = loy + yr;
+        if (y > hiy) break;
+        const float wy = filt_eval(se, basey + (float) yr);
+        const int gy = ws.offy + y - border;
+        for (int xr = 0; xr < n; ++xr) {
+            const int x = lox + xr;
+            if (x > hix) break;
+            const float w = wy * filt_eval(se, basex + (float) xr);
+            const int gx = ws.offx + x - border;
+            if (gx < 0 || gx >= ws.W || gy < 0 || gy >= ws.H) continue;
+            const uint32_t cell = ws.C * ((uint32_t) gy * (uint32_t) ws.W + (uint32_t) gx);
+            put_wide_add(hd, cell + 0u, ws.v0, w);
+            put_wide_add(hd, cell + 1u, ws.v1, w);
+            put_wide_add(hd, cell + 2u, ws.v2, w);
+            if (ws.five) {
+                put_wide_add(hd, cell + 3u, ws.v3, w);
+                put_wide_add(hd, cell + 4u, ws.v4, w);
+            }
+            for (int i = 0; i < 3; ++i) {
+                if (!(ws.emask >> i & 1u)) continue;
+                const uint32_t c = cell + (uint32_t) (ws.ech + i * estep);
+                put_wide_add(hd, c, ws.e0, w);
+                if (ws.e3) {
+                    put_wide_add(hd, c + 1u, ws.e1, w);
+                    put_wide_add(hd, c + 2u, ws.e2, w);
+                }
+            }
+        }
+    }
+}
+// position_sample of a path's render_sample (integrator.cpp:263): the pixel it was drawn for and the first next_2d of its stream
+BF_DEV void film_position(const DLaunch &lp, const PathState &s, uint32_t &px, uint32_t &py, float &fx, float &fy) {
+    uint64_t seed = lp.seed, path_offset = lp.path_offset, path_i = s.path_i;
+    if (lp.batch != 0u) {
+        path_i -= (uint64_t) s.render * lp.batch_paths;
+        if (lp.roll) {
+            const DRoll &rr = lp.roll[s.render & (kRollRing - 1u)];
+            seed = rr.seed;
+            path_offset = rr.path_offset;
+        } else if (lp.batch_seeds) {
+            seed = lp.batch_seeds[s.render];
+        }
+    }
+    Rng rng;
+    pcg_seed(rng, seed + path_offset + path_i);
+    fx = next_1d(rng);
+    fy = next_1d(rng);
+    px = py = 0u;
+    if (lp.spp) {
+        const uint64_t q = (lp.path_offset + path_i) / lp.spp;
+        px = (uint32_t) (q % lp.film_w);
+        py = (uint32_t) (q / lp.film_w);
+    }
+}
+
 template <int RX = 2>
 BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
                      FilmAcc &acc, bf_path_record *records) {
@@ -761,6 +858,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
     s_hist = hd.s;
     g_hist = hd.g;
     lds_hist = hd.lds;
+    constexpr bool wide = (RX & kWide) != 0;       // reconstruction filter wider than a pixel (uniform; the radar scenes use box)
     if (mode_receive<RX>(lp)) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
@@ -797,8 +895,30 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
             ok = ok && __builtin_isfinite(pv);
         }
         float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
-        ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
-        if (ok) {
+        if (wide) {
+            if (ok) {
+                WideSample ws;
+                ws.posx = tf0;
+                ws.posy = tf1;
+                ws.offx = ws.offy = 0;                       // receive(): ONE block of the ADC's size (integrator.cpp:624-627)
+                ws.bw = ws.W = (int) lp.bins;
+                ws.bh = ws.H = (int) lp.bins_y;
+                ws.C = 3u + P;
+                ws.v0 = a0;
+                ws.v1 = a1;
+                ws.v2 = 1.f;
+                ws.v3 = ws.v4 = 0.f;
+                ws.five = false;
+                ws.ech = 3 + pk0 - 1;
+                ws.emask = pmask;
+                ws.e3 = false;
+                ws.e0 = pv;
+                ws.e1 = ws.e2 = 0.f;
+                put_wide(se, ws, hd);
+            } else {
+                ++acc.invalid;
+            }
+        } else if ((ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y)) {
             uint32_t off = (3u + P) * ((uint32_t) ly * lp.bins + (uint32_t) lx);
             if (a0 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 0u, a0);
             if (a1 != 0.f) hist_add(s_hist, g_hist, lds_hist, off + 1u, a1);
@@ -840,7 +960,52 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
             const uint32_t py = (uint32_t) (q / lp.film_w) - ((s.flags & kFlagFilmUp) ? 1u : 0u);
             pix = (py * lp.film_w + px) * lp.chan_px;          // only used when kFlagFilmOk
         }
-        if (ok) {
+        if (wide) {
+            // the filtered branch takes every finite sample (where it lands is decided cell by cell)
+            bool fin = __builtin_isfinite(X) && __builtin_isfinite(Y) && __builtin_isfinite(Z);
+            if (is_range || is_time) fin = fin && __builtin_isfinite(a0) && __builtin_isfinite(a1) && __builtin_isfinite(a2);
+            if (fin) {
+                WideSample ws;
+                uint32_t qx, qy;
+                float fx, fy;
+                film_position(lp, s, qx, qy, fx, fy);
+                ws.posx = (float) qx + fx;
+                ws.posy = (float) qy + fy;
+                const uint32_t B = sc.sensor->filt_block;
+                ws.offx = B ? (int) (qx / B * B) : 0;
+                ws.offy = B ? (int) (qy / B * B) : 0;
+                ws.W = (int) lp.film_w;
+                ws.H = (int) lp.film_h;
+                ws.bw = B ? min((int) B, ws.W - ws.offx) : ws.W;
+                ws.bh = B ? min((int) B, ws.H - ws.offy) : ws.H;
+                ws.C = lp.chan_px;
+                ws.v0 = X;
+                ws.v1 = Y;
+                ws.v2 = Z;
+                ws.v3 = valid ? 1.f : 0.f;
+                ws.v4 = 1.f;
+                ws.five = true;
+                ws.emask = 0u;
+                ws.e3 = is_time;
+                ws.ech = 5;
+                ws.e0 = a0;
+                ws.e1 = a1;
+                ws.e2 = a2;
+                if (is_range || is_time) {
+                    float w = lp.bin_width;
+                    int k = (int) __builtin_floorf(s.aux / w);
+                    ws.ech = 5 + (k - 1) * (is_time ? 3 : 1);
+                    for (int i = k - 1; i <= k + 1; ++i) {
+                        if (i < 0 || i >= (int) lp.bins) continue;
+                        float lo = (float) i * w, hi = (float) i * w + w;
+                        if (s.aux >= lo && s.aux < hi) ws.emask |= 1u << (i - (k - 1));
+                    }
+                }
+                put_wide(*sc.sensor, ws, hd);
+            } else {
+                ++acc.invalid;
+            }
+        } else if (ok) {
             if (lp.spp) {
                 if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 0u, X);
                 if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 1u, Y);

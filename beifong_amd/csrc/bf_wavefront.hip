@@ -649,14 +649,21 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
                                    hipStream_t stream, int waves) {
     // `waves`: register budget of the shading kernel (waves per SIMD); 3 is the sweet spot (168 VGPRs)
     const bool rx = lp->mode == BF_MODE_RECEIVE_RAW;
-#define BF_SHADE_LAUNCH(F, W)                                                                                                    \
-    if (rx)                                                                                                                      \
-        hipLaunchKernelGGL((bfd::wf_shade<F, W, 1>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
-                           records);                                                                                             \
-    else                                                                                                                         \
-        hipLaunchKernelGGL((bfd::wf_shade<F, W, 0>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, \
-                           records)
-    if (first == 3) {
+#define BF_SHADE_LAUNCH_RX(F, W, RX_)                                                                                              \
+    hipLaunchKernelGGL((bfd::wf_shade<F, W, RX_>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, *wf, it, g_hist, records)
+#define BF_SHADE_LAUNCH(F, W)            \
+    if (rx) BF_SHADE_LAUNCH_RX(F, W, 1); \
+    else BF_SHADE_LAUNCH_RX(F, W, 0)
+#define BF_SHADE_LAUNCH_WIDE(F)                          \
+    if (rx) BF_SHADE_LAUNCH_RX(F, 3, 1 | bfd::kWide);    \
+    else BF_SHADE_LAUNCH_RX(F, 3, 0 | bfd::kWide)
+    if (lp->wide) {
+        // reconstruction filter wider than a pixel: the kWide variants (three waves per SIMD only)
+        if (first == 3) { BF_SHADE_LAUNCH_WIDE(3); }
+        else if (first == 2) { BF_SHADE_LAUNCH_WIDE(2); }
+        else if (first) { BF_SHADE_LAUNCH_WIDE(1); }
+        else { BF_SHADE_LAUNCH_WIDE(0); }
+    } else if (first == 3) {
         BF_SHADE_LAUNCH(3, 3);
     } else if (first == 2) {
         BF_SHADE_LAUNCH(2, 3);
@@ -671,6 +678,8 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
         }
     }
 #undef BF_SHADE_LAUNCH
+#undef BF_SHADE_LAUNCH_WIDE
+#undef BF_SHADE_LAUNCH_RX
     return hipGetLastError();
 }
 

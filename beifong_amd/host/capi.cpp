@@ -54,6 +54,17 @@ void bfh_release(void *obj) {
 }
 const char *bfh_class_name(void *obj) { return ((Object *) obj)->class_()->name().c_str(); }
 
+/* ReconstructionFilter objects (load_string("<rfilter type='gaussian'/>")): the Python face of src/libcore/python/rfilter.cpp */
+static ReconstructionFilter *as_rfilter(void *o) {
+    auto *f = dynamic_cast<ReconstructionFilter *>((Object *) o);
+    if (!f) Throw("object is not a ReconstructionFilter");
+    return f;
+}
+int bfh_rfilter_eval(void *obj, float x, int discretized, float *out) {
+    BFH_TRY(*out = discretized ? as_rfilter(obj)->eval_discretized(x) : as_rfilter(obj)->eval(x))
+}
+int bfh_rfilter_flatten(void *obj, unsigned block_size, bf_rfilter *out) { BFH_TRY(*out = as_rfilter(obj)->flatten(block_size)) }
+
 static Scene *as_scene(void *o) {
     auto *s = dynamic_cast<Scene *>((Object *) o);
     if (!s) Throw("object is not a Scene");

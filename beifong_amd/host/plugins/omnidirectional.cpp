@@ -8,7 +8,7 @@ public:
             Throw("Found a 'to_world' transformation -- this is not allowed. The omnidirectional receiver inherits "
                   "this transformation from its parent shape.");
         if (m_adc->reconstruction_filter()->radius() > 0.5f + 1500 * 5.9604644775390625e-8f)
-            Throw("omnidirectional: only the box reconstruction filter is supported (adc rfilter radius <= 0.5)");
+            Log(Warn, "This sensor should only be used with a reconstruction filter of radius 0.5 or lower(e.g. default box)");
     }
     void flatten(bf_sensor &s, int32_t shape) const override {
         if (shape < 0) Throw("receiver must be the child of a shape");

@@ -13,7 +13,7 @@ public:
         if (m_receive_type == "mix_resample")
             Throw("phasedreceiver: receive_type \"mix_resample\" is not supported (\"raw\" and \"raw_resample\" are)");
         if (m_adc->reconstruction_filter()->radius() > 0.5f + 1500 * 5.9604644775390625e-8f)
-            Throw("phasedreceiver: only the box reconstruction filter is supported (adc rfilter radius <= 0.5)");
+            Log(Warn, "This sensor should only be used with a reconstruction filter of radius 0.5 or lower(e.g. default box)");
         m_f_centre = props.float_("freq_centre", 1.f);
         m_f_ext = props.float_("freq_ext", 1.f);
         m_gain = props.float_("gain", 1.f);

@@ -62,6 +62,29 @@ Sampler::Sampler(const Properties &props) {
     m_base_seed = (uint64_t) props.int_("seed", 0);
 }
 
+static constexpr float kRayEpsilon = 1500 * 5.9604644775390625e-8f;      // math::RayEpsilon<float>
+void ReconstructionFilter::init_discretization() {                        // rfilter.cpp:9-21
+    if (!(m_radius > 0.f)) Throw("ReconstructionFilter: radius must be positive");
+    for (size_t i = 0; i < BF_FILTER_RESOLUTION; ++i) m_values[i] = eval((m_radius * i) / BF_FILTER_RESOLUTION);
+    m_values[BF_FILTER_RESOLUTION] = 0;
+    m_scale_factor = BF_FILTER_RESOLUTION / m_radius;
+    m_border_size = (uint32_t) (int) std::ceil(m_radius - .5f - 2.f * kRayEpsilon);
+}
+float ReconstructionFilter::eval_discretized(float x) const {
+    const int index = std::min((int) std::fabs(x * m_scale_factor), BF_FILTER_RESOLUTION);
+    return m_values[index];
+}
+bf_rfilter ReconstructionFilter::flatten(uint32_t block_size) const {
+    bf_rfilter f;
+    std::memset(&f, 0, sizeof(f));
+    f.radius = m_radius;
+    f.scale = m_scale_factor;
+    f.border = m_border_size;
+    f.block_size = block_size;
+    std::memcpy(f.values, m_values, sizeof(f.values));
+    return f;
+}
+
 static ref<ReconstructionFilter> find_filter(const Properties &props, const char *def_plugin) {
     for (auto &kv : props.objects(false)) {
         auto *f = dynamic_cast<ReconstructionFilter *>(kv.second.get());
@@ -456,9 +479,13 @@ void Scene::flatten(const Endpoint *endpoint) {
     }
     if (auto *se = dynamic_cast<const Sensor *>(endpoint)) {
         se->flatten(sen, sen.shape);
+        // render() walks the film in blocks of MTS_BLOCK_SIZE (spiral.h:10; integrator.cpp:101-114 halves it while there are
+        // fewer blocks than threads — a choice of the machine, not of the scene: the default is what is flattened)
+        sen.rfilter = se->film()->reconstruction_filter()->flatten(32);
         endpoint_found = true;
     } else if (auto *re = dynamic_cast<const Receiver *>(endpoint)) {
         re->flatten(sen, sen.shape);
+        sen.rfilter = re->adc()->reconstruction_filter()->flatten(0);      // receive(): one block of the ADC's size
     }
     if (!endpoint_found) Throw("Scene: the given sensor / receiver does not belong to this scene");
     // physics constants of the fork at HEAD (spectrum.h:15-40, math.h:40-41)

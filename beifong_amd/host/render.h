@@ -27,10 +27,23 @@ private:
     float m_value;
 };
 
+/// include/mitsuba/core/rfilter.h:48-82, src/libcore/rfilter.cpp:9-21
 class ReconstructionFilter : public Object {
 public:
-    virtual float radius() const = 0;
+    float radius() const { return m_radius; }
+    uint32_t border_size() const { return m_border_size; }
+    virtual float eval(float x) const = 0;
+    /// rfilter.h:62-65
+    float eval_discretized(float x) const;
+    /// the discretised filter as the C ABI carries it (bf_rfilter); block_size: edge of the blocks the film is rendered in
+    bf_rfilter flatten(uint32_t block_size) const;
     const Class *class_() const override;
+
+protected:
+    void init_discretization();
+    float m_radius = 0.f, m_scale_factor = 0.f;
+    float m_values[BF_FILTER_RESOLUTION + 1] = {};
+    uint32_t m_border_size = 0;
 };
 
 class Sampler : public Object {

@@ -61,6 +61,8 @@ def lib():
     l.bfh_bitmap.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     l.bfh_channel_name.argtypes = [vp, C.c_uint]
     l.bfh_channel_name.restype = cp
+    l.bfh_rfilter_eval.argtypes = [vp, C.c_float, C.c_int, C.POINTER(C.c_float)]
+    l.bfh_rfilter_flatten.argtypes = [vp, C.c_uint, C.POINTER(capi.bf_rfilter)]
     l.bfh_loaded_plugins.argtypes = [C.c_char_p, C.c_int]
     _lib = l
     return l
@@ -241,9 +243,36 @@ class Scene(_Handle):
         return h
 
 
+class ReconstructionFilter(_Handle):
+    """mitsuba.core.ReconstructionFilter (src/libcore/python/rfilter.cpp): eval / eval_discretized / radius / border_size."""
+
+    def _eval(self, x, discretized):
+        out = C.c_float()
+        check(lib().bfh_rfilter_eval(self._ptr, float(x), discretized, C.byref(out)))
+        return out.value
+
+    def eval(self, x):
+        return self._eval(x, 0)
+
+    def eval_discretized(self, x):
+        return self._eval(x, 1)
+
+    def flatten(self, block_size=0):
+        """The filter as the C ABI carries it (capi.bf_rfilter: goes into bf_sensor.rfilter)."""
+        f = capi.bf_rfilter()
+        check(lib().bfh_rfilter_flatten(self._ptr, block_size, C.byref(f)))
+        return f
+
+    def radius(self):
+        return self.flatten().radius
+
+    def border_size(self):
+        return self.flatten().border
+
+
 def wrap(ptr, dict_src=None):
     name = lib().bfh_class_name(ptr).decode()
-    cls = {"Scene": Scene}.get(name, _Handle)
+    cls = {"Scene": Scene, "ReconstructionFilter": ReconstructionFilter}.get(name, _Handle)
     o = cls(ptr, owned=True)
     o._dict = dict_src
     return o

@@ -151,6 +151,24 @@ enum {
                                     to_world * origin along to_world * +z, weight 1 */
 };
 
+/* Reconstruction filter of the film / ADC (include/mitsuba/core/rfilter.h:10,55-66, src/libcore/rfilter.cpp:9-21).  The
+ * host evaluates the filter (src/rfilters/{box,tent,gaussian,mitchell,catmullrom,lanczos}.cpp) into the reference's
+ * discretisation; the kernels only look the table up, exactly as ImageBlock::put / SignalBlock::put do
+ * (imageblock.cpp:109-165, signalblock.cpp:111-161): eval_discretized(x) = values[min(int(|x * scale|), 31)].
+ * radius <= 0.5 + RayEpsilon (e.g. the zero-initialised struct) selects put()'s box branch — one pixel, weight 1 — and
+ * nothing else of the struct is read.                                                                                   */
+#define BF_FILTER_RESOLUTION 31              /* MTS_FILTER_RESOLUTION */
+typedef struct bf_rfilter {
+    float radius;                            /* m_radius                                                  */
+    float scale;                             /* m_scale_factor = MTS_FILTER_RESOLUTION / m_radius          */
+    uint32_t border;                         /* m_border_size = ceil(radius - .5 - 2 RayEpsilon)           */
+    uint32_t block_size;                     /* render(): edge of the image blocks a film is rendered in (integrator.cpp:
+                                                101-114, MTS_BLOCK_SIZE 32); a sample's position is taken relative to ITS
+                                                block's offset - border (imageblock.cpp:113), which matters to the last bit
+                                                only.  0: the film / ADC is one block (receive(): integrator.cpp:624-627)  */
+    float values[BF_FILTER_RESOLUTION + 1];  /* m_values; values[31] = 0                                   */
+} bf_rfilter;
+
 typedef struct bf_sensor {
     uint32_t type;
     int32_t  shape;          /* fluxmeter / receivers: carrying shape        */
@@ -169,6 +187,7 @@ typedef struct bf_sensor {
     uint32_t rx_sig_is_delta;  /* wignerreceiver.cpp:258 reads an uninitialised
                                   m_sig_is_delta in raw mode; made explicit  */
     bf_phased_array array;   /* BF_RECEIVER_PHASED                           */
+    bf_rfilter rfilter;      /* film->reconstruction_filter() / adc->reconstruction_filter() */
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

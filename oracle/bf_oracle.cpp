@@ -1829,6 +1829,106 @@ static bool imageblock_put_box(double *data, uint32_t w, uint32_t h, uint32_t nc
     return true;
 }
 
+// Reconstruction filters — src/rfilters/{box,tent,gaussian,mitchell,catmullrom,lanczos}.cpp (eval) and
+// ReconstructionFilter::init_discretization (src/libcore/rfilter.cpp:9-21), scalar float arithmetic as written there.
+// kind: 0 box (p0 = radius property), 1 tent, 2 gaussian (p0 = stddev), 3 mitchell (p0 = B, p1 = C), 4 catmullrom,
+// 5 lanczos (p0 = lobes)
+struct RFilter {
+    int kind;
+    float radius, p0, p1, alpha, bias;
+    RFilter(int k, float a, float b) : kind(k), radius(0.f), p0(a), p1(b), alpha(0.f), bias(0.f) {
+        switch (kind) {
+            case 0: radius = p0 + kRayEpsilon; break;                       // box.cpp:33
+            case 1: radius = 1.f; break;                                    // tent.cpp:29
+            case 2:                                                         // gaussian.cpp:33-42
+                radius = 4 * p0;
+                alpha = -1.f / (2.f * p0 * p0);
+                bias = std::exp(alpha * (radius * radius));
+                break;
+            case 3: radius = 2.f; break;                                    // mitchell.cpp:33
+            case 4: radius = 2.f; p0 = 0.f; p1 = .5f; break;                // catmullrom.cpp:26,34
+            default: radius = (float) (int) p0; break;                      // lanczos.cpp:38
+        }
+    }
+    float cubic(float x, float B, float C) const {                          // mitchell.cpp:41-55 == catmullrom.cpp:30-45
+        x = std::fabs(x);
+        float x2 = x * x, x3 = x2 * x;
+        float result = (1.f / 6.f) * (x < 1 ? (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B)
+                                            : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
+        return x < 2.f ? result : 0.f;
+    }
+    float eval(float x) const {
+        switch (kind) {
+            case 0: return std::fabs(x) <= radius ? 1.f : 0.f;              // box.cpp:38
+            case 1: return std::max(0.f, 1.f - std::fabs(x * (1.f / radius)));   // tent.cpp:35
+            case 2: return std::max(0.f, std::exp(alpha * (x * x)) - bias); // gaussian.cpp:47
+            case 3:
+            case 4: return cubic(x, p0, p1);
+            default: {                                                      // lanczos.cpp:43-52
+                x = std::fabs(x);
+                float x1 = kPi * x, x2 = x1 / radius, result = (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+                return x < kEpsilon ? 1.f : (x > radius ? 0.f : result);
+            }
+        }
+    }
+    void discretise(bf_rfilter &out) const {                                // rfilter.cpp:9-21
+        std::memset(&out, 0, sizeof(out));
+        for (size_t i = 0; i < BF_FILTER_RESOLUTION; ++i) out.values[i] = eval((radius * i) / BF_FILTER_RESOLUTION);
+        out.values[BF_FILTER_RESOLUTION] = 0;
+        out.radius = radius;
+        out.scale = BF_FILTER_RESOLUTION / radius;
+        out.border = (uint32_t) (int) std::ceil(radius - .5f - 2.f * kRayEpsilon);
+    }
+};
+static float rfilter_eval_discretized(const bf_rfilter &f, float x) {       // rfilter.h:62-65
+    int index = std::min((int) std::fabs(x * f.scale), BF_FILTER_RESOLUTION);
+    return f.values[index];
+}
+static bool rfilter_wide(const bf_rfilter &f) { return f.radius > 0.5f + kRayEpsilon; }     // imageblock.cpp:115
+
+// ImageBlock::put, filtered branch — src/librender/imageblock.cpp:109-165 (SignalBlock::put: signalblock.cpp:111-161,
+// the same code) on a block of bw x bh cells at offset (offx, offy) with a border of f.border cells.  add(x, y, weight)
+// receives block coordinates INCLUDING the border (0 .. bw + 2 border - 1).
+template <typename Add>
+static void imageblock_put_wide(const bf_rfilter &f, int offx, int offy, int bw, int bh, float posx, float posy, Add add) {
+    const int border = (int) f.border;
+    const int sizex = bw + 2 * border, sizey = bh + 2 * border;
+    // Point2f pos = pos_ - (m_offset - m_border_size + .5f)
+    float px = posx - ((float) (offx - border) + .5f), py = posy - ((float) (offy - border) + .5f);
+    int lox = std::max((int) std::ceil(px - f.radius), 0), loy = std::max((int) std::ceil(py - f.radius), 0);
+    int hix = std::min((int) std::floor(px + f.radius), sizex - 1), hiy = std::min((int) std::floor(py + f.radius), sizey - 1);
+    uint32_t n = (uint32_t) (int) std::ceil((f.radius - 2.f * kRayEpsilon) * 2.f);
+    float basex = (float) lox - px, basey = (float) loy - py;
+    std::vector<float> wx(n), wy(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        wx[i] = rfilter_eval_discretized(f, basex + (float) i);
+        wy[i] = rfilter_eval_discretized(f, basey + (float) i);
+    }
+    for (uint32_t yr = 0; yr < n; ++yr) {
+        int y = loy + (int) yr;
+        bool enabled = y <= hiy;
+        for (uint32_t xr = 0; xr < n; ++xr) {
+            int x = lox + (int) xr;
+            float weight = wy[yr] * wx[xr];
+            enabled = enabled && x <= hix;
+            if (enabled) add(x, y, weight);
+        }
+    }
+}
+// the block is added to the film / ADC storage (ImageBlock::put(block), imageblock.cpp:56-74: accumulate_2d clips what
+// lies outside the w x h storage); `value[k] * weight` in float as imageblock.cpp:160, summed in double like every
+// histogram of this file
+static void storage_put_wide(const bf_rfilter &f, double *data, uint32_t w, uint32_t h, uint32_t nchan, int offx, int offy, int bw, int bh,
+                             float posx, float posy, const float *value) {
+    const int border = (int) f.border;
+    imageblock_put_wide(f, offx, offy, bw, bh, posx, posy, [&](int x, int y, float weight) {
+        int gx = offx + x - border, gy = offy + y - border;
+        if (gx < 0 || gx >= (int) w || gy < 0 || gy >= (int) h) return;
+        double *dst = data + (size_t) nchan * ((size_t) gy * w + (size_t) gx);
+        for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) (value[k] * weight);
+    });
+}
+
 // ---------------------------------------------------------------------------
 // film: SamplingIntegrator::render_sample (integrator.cpp:259-310) +
 // RangeIntegrator / TimeIntegrator AOV fill (range.cpp:141-161,
@@ -1935,6 +2035,17 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     for (uint32_t k = 0; k < nchan; ++k) ok = ok && std::isfinite(aovs[k]);
     // (film level: pos = position_sample - (0 - 0 + .5), imageblock.cpp:113,166-172; the reference applies
     // the same rule per spiral block, whose size follows the thread count)
+    if (rfilter_wide(sc.sensor.rfilter)) {
+        // the sample's block: render() walks the film in blocks of block_size (integrator.cpp:101-114,139-142; spiral.cpp:
+        // offset = position * block_size, size = min(block_size, film - offset)); 0 = one block
+        const bf_rfilter &f = sc.sensor.rfilter;
+        const uint32_t B = f.block_size;
+        const int offx = B ? (int) (px / B * B) : 0, offy = B ? (int) (py / B * B) : 0;
+        const int bw = B ? std::min((int) B, (int) film_w - offx) : (int) film_w, bh = B ? std::min((int) B, (int) film_h - offy) : (int) film_h;
+        if (ok) storage_put_wide(f, hist, film_w, film_h, nchan, offx, offy, bw, bh, posx, posy, aovs.data());
+        out.put = ok;
+        return out;
+    }
     out.put = ok && imageblock_put_box(hist, film_w, film_h, nchan, posx, posy, aovs.data());
     return out;
 }
@@ -1989,6 +2100,19 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
             aov[k] = (ax < 0.5f) ? v : 0.f;                            // math::rect(...) > 0
             ok = ok && std::isfinite(aov[k]);
         }
+    }
+    if (rfilter_wide(s.rfilter)) {
+        // receive(): ONE SignalBlock of the ADC's size at offset 0 (integrator.cpp:624-627), then adc->put(block)
+        out.put = ok;
+        if (ok) {
+            std::vector<float> v(3 + P);
+            v[0] = a0;
+            v[1] = a1;
+            v[2] = a2;
+            for (uint32_t k = 0; k < P; ++k) v[3 + k] = aov[k];
+            storage_put_wide(s.rfilter, hist, lp.bins, lp.bins_y, 3 + P, 0, 0, (int) lp.bins, (int) lp.bins_y, tf0, tf1, v.data());
+        }
+        return out;
     }
     // pos = tf - (offset - border + .5); lo = ceil(pos - .5)
     float lx = std::ceil((tf0 - .5f) - .5f), ly = std::ceil((tf1 - .5f) - .5f);
@@ -2417,6 +2541,31 @@ int bfo_imageblock_put(double *data, uint32_t w, uint32_t h, uint32_t nchan, flo
     for (uint32_t k = 0; k < nchan; ++k)
         if (!std::isfinite(value[k])) return 0;
     return imageblock_put_box(data, w, h, nchan, posx, posy, value) ? 1 : 0;
+}
+/* Reconstruction filters (RFilter above).  bfo_rfilter: the discretised filter as the C ABI carries it; bfo_rfilter_eval:
+ * eval(x) (discretized = 0) or eval_discretized(x). */
+void bfo_rfilter(int kind, float p0, float p1, bf_rfilter *out) { RFilter(kind, p0, p1).discretise(*out); }
+float bfo_rfilter_eval(int kind, float p0, float p1, float x, int discretized) {
+    RFilter f(kind, p0, p1);
+    if (!discretized) return f.eval(x);
+    bf_rfilter t;
+    f.discretise(t);
+    return rfilter_eval_discretized(t, x);
+}
+/* ImageBlock::put with a reconstruction filter on a caller-owned block double[h + 2 border][w + 2 border][nchan] at offset
+ * (offx, offy) — the block INCLUDING its border, as ImageBlock::data() (test_imageblock.py:145-213); the box branch for
+ * radius <= 0.5 + RayEpsilon (border 0).  Returns 0 if a value is not finite (warn_invalid: the sample is dropped). */
+int bfo_imageblock_put_filtered(const bf_rfilter *f, double *data, uint32_t w, uint32_t h, uint32_t nchan, int offx, int offy, float posx,
+                                float posy, const float *value) {
+    for (uint32_t k = 0; k < nchan; ++k)
+        if (!std::isfinite(value[k])) return 0;
+    if (!rfilter_wide(*f)) return imageblock_put_box(data, w, h, nchan, posx - (float) offx, posy - (float) offy, value) ? 1 : 0;
+    const uint32_t sx = w + 2 * f->border;
+    imageblock_put_wide(*f, offx, offy, (int) w, (int) h, posx, posy, [&](int x, int y, float weight) {
+        double *dst = data + (size_t) nchan * ((size_t) y * sx + (size_t) x);
+        for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) (value[k] * weight);
+    });
+    return 1;
 }
 /* MicrofacetDistribution unit access (golden vectors of src/librender/tests/test_microfacet.py).
  * op: 0 eval(m), 1 pdf(wi, m), 2 smith_g1(v = m argument, m = wi argument), 3 sample(wi, (s0, s1)) -> out[0..2] = m,
