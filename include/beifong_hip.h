@@ -236,11 +236,13 @@ typedef struct bf_launch {
     uint32_t flags;           /* BF_FLAG_*                                    */
     uint32_t phase_bins;      /* receive mode: PhaseIntegrator AOVs S{k}.Y after Y,A,W
                                  (phase.cpp:80-141); 0 = plain pathtimefrequency */
-    /* Film of the render modes (integrator.cpp:58-204, Film::crop_size with crop_offset 0, box
-     * reconstruction filter): global path g (= path_offset + local index) samples pixel g / spp,
+    /* Film of the render modes (integrator.cpp:58-204, Film::crop_size with crop_offset 0):
+     * global path g (= path_offset + local index) samples pixel g / spp,
      * pixels in row-major order as in the reference's wavefront branch (integrator.cpp:171-187);
-     * its film position is pixel + next_2d and it lands in pixel ceil(pos - 1) per axis
-     * (ImageBlock::put, imageblock.cpp:166-172).  The histogram becomes
+     * its film position is pixel + next_2d and, under the box filter, it lands in pixel ceil(pos - 1)
+     * per axis (ImageBlock::put, imageblock.cpp:166-172); a wider reconstruction filter
+     * (bf_sensor.rfilter) spreads it over the pixels within its radius (imageblock.cpp:115-165).
+     * The histogram becomes
      * [film_height][film_width][channels].  spp == 0 (or a 0 x 0 film) means the 1 x 1 film of
      * the radar scenes: every path samples pixel 0.  path_offset + n_paths must not exceed
      * film_width * film_height * spp.  Receive modes have an ADC instead and need these 0 or 1. */
