@@ -57,6 +57,7 @@ class bf_emitter(C.Structure):
 
 
 BF_FILTER_RESOLUTION = 31
+BF_VARIANT_LEAN, BF_VARIANT_WIDE = 1, 2
 
 
 class bf_rfilter(C.Structure):
@@ -111,7 +112,8 @@ class bf_stats(C.Structure):
                 ("n_nodes_lds", C.c_uint64), ("n_nodes_tail", C.c_uint64), ("n_wnodes_tail", C.c_uint64),
                 ("n_tris_tail", C.c_uint64), ("n_bounces_tail", C.c_uint64), ("n_shade_loads", C.c_uint64),
                 ("n_shade_stores", C.c_uint64), ("n_shade_shadow", C.c_uint64), ("n_shade_rays", C.c_uint64),
-                ("n_guard", C.c_uint64), ("n_launches_tail", C.c_uint32), ("n_launches_shade", C.c_uint32)]
+                ("n_guard", C.c_uint64), ("n_launches_tail", C.c_uint32), ("n_launches_shade", C.c_uint32),
+                ("kernel_variant", C.c_uint32), ("reserved_", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -125,6 +125,7 @@ struct bf_tunables {
     uint32_t roll_live = 3u << 19;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
     bool no_wide = false, quant = false;
     int wide_rows_log = -1;
+    bool lean = true;                        // BF_LEAN=0: never use the kernels' lean variants (bf_device.h: kLean)
 };
 static bf_tunables read_tunables() {
     bf_tunables t;
@@ -153,6 +154,7 @@ static bf_tunables read_tunables() {
     t.no_wide = getenv("BF_NO_WIDE_BVH") != nullptr;
     t.quant = num("BF_QUANT_BVH", 0) != 0;
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
+    t.lean = num("BF_LEAN", 1) != 0;
     return t;
 }
 
@@ -182,6 +184,7 @@ struct bf_scene {
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
     bfd::DSensor sensor_host;              // host copy of the device sensor record
+    mutable uint32_t last_variant = 0;     // BF_VARIANT_* of the latest render (bf_stats.kernel_variant)
     uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
     float4 *tris0 = nullptr, *nodes0 = nullptr, *wnodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
@@ -1493,6 +1496,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.lp.batch_seeds = nullptr;              // seeds, offsets and buffers of a rolling render live in its descriptor
         r.lp.batch_offsets = nullptr;
         r.lp.box_slack = 0.f;
+        r.lp.has_records = 0u;
         r.per_call = K;
         r.offsets = with_offsets;
         r.dmax = 0.f;
@@ -1541,6 +1545,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
     }
     if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, sizeof(uint32_t), stream));
     const uint32_t n_chan1 = lp.n_chan;
+    if (records_dev) lp.has_records = 1u;
     for (uint32_t j = 0; j < K; ++j) {
         bfd::DRoll d;
         d.seed = (batch && batch->seeds) ? batch->seeds[j] : launch->seed;
@@ -1704,6 +1709,7 @@ static void fill_stats(const bf_scene *scene, const unsigned long long *c, uint6
     st->n_bounce_iters = scene->wf_iters;
     st->n_launches_tail = scene->wf_tail_launches;
     st->n_launches_shade = scene->wf_shade_launches;
+    st->kernel_variant = scene->last_variant;
 }
 
 // Stream order between the successive uses of a handle's pool: work enqueued on another stream than the previous
@@ -1725,6 +1731,20 @@ static bf_status close_sequence(const bf_scene *scene, hipStream_t stream) {
     bf_status st = wf_roll_flush(scene, stream, false);
     if (st != BF_OK) return st;
     return mark_last(scene, stream);
+}
+
+// The lean profile (bf_device.h: kLean): what the scene and the launch must look like for the kernels that have everything else
+// compiled out.  Every radar scene of the reference's scripts and every BASELINE config fits; anything else runs the
+// general kernels (same results: tests/test_gpu_parity.py::test_lean_and_general_kernels_agree).
+static bool lean_profile(const bf_scene *scene, const bf_launch *launch, bool receive_mode, bool multi_pixel) {
+    // lean builds exist of the default register budgets only (three waves per SIMD), and not of the one-kernel variant
+    if ((launch->flags & BF_FLAG_MEGAKERNEL) || scene->tun.shade_waves != 3 || scene->tun.tail_waves != 3) return false;
+    if (!scene->tun.lean || scene->d.n_emitters != 1 || scene->d.uvs != nullptr || scene->sensor_host.filt_n != 0u) return false;
+    const uint32_t et = scene->emitter_types[0];
+    if (receive_mode)
+        return (et == BF_TRANSMITTER_AREA || et == BF_TRANSMITTER_WIGNER) && scene->sensor_host.type == BF_RECEIVER_OMNI &&
+               launch->phase_bins == 0 && !(launch->flags & (BF_FLAG_DOPPLER | BF_FLAG_MIX_RESAMPLE));
+    return et == BF_EMITTER_AREA && scene->sensor_host.type == BF_SENSOR_PERSPECTIVE && !multi_pixel && launch->mode != BF_MODE_TIME;
 }
 
 static bf_status render_common(const bf_scene *scene, const bf_launch *launch, const bf_batch *batch, float *hist_dev,
@@ -1820,7 +1840,9 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.time_c = launch->time_c;
     lp.n_chan = bf_launch_channels(launch);
     lp.chan_px = lp.n_chan / (lp.film_w * lp.film_h);
-    lp.wide = scene->sensor_host.filt_n != 0u ? 1u : 0u;      // reconstruction filter wider than a pixel: the kernels' kWide variants
+    lp.lean = lean_profile(scene, launch, receive_mode, multi_pixel) ? 1u : 0u;
+    lp.wide = scene->sensor_host.filt_n != 0u ? 1u : 0u;
+    scene->last_variant = (lp.lean ? (uint32_t) BF_VARIANT_LEAN : 0u) | (lp.wide ? (uint32_t) BF_VARIANT_WIDE : 0u);      // reconstruction filter wider than a pixel: the kernels' kWide variants
     lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
     lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;

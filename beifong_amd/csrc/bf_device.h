@@ -63,6 +63,19 @@ struct DEmitter {
     float wid[3];
 };
 
+// Kernel variant word V — the template parameter (`RX`) of the path logic and of the kernels built on it:
+//   bits 0-1  mode class: 0 render modes (path / range / time), 1 receive modes, 2 decided at run time (tail, one-kernel variant)
+//   kWide     the sensor's reconstruction filter is wider than a pixel (DLaunch::wide)
+//   kLean     scene and launch fit the LEAN PROFILE (DLaunch::lean, bf_api.cpp: lean_profile) — what every radar scene of the
+//             reference's scripts and all BASELINE configs use: ONE emitter of an area type (area light, area / Wigner
+//             transmitter: no spot, point or phased-array source), no texture coordinates, a perspective camera (render
+//             modes) or the omnidirectional receiver (receive modes), the 1 x 1 film, no time-resolved mode, no phase bins, no
+//             Doppler hook, no mix_resample.  The code for everything outside the profile is compiled out: wf_shade 168 -> 159
+//             VGPRs, a quarter fewer scalar spills, -4.5 % of its time on C2 (profiles/r03_lean_variant_ab.txt).
+constexpr int kModeMask = 3, kWide = 4, kLean = 8;
+// rare<V>(c): a condition the lean profile guarantees to be false
+template <int V> __device__ __forceinline__ constexpr bool rare(bool c) { return (V & kLean) ? false : c; }
+
 struct DSensor {
     uint32_t type;
     int32_t rect;
@@ -156,6 +169,8 @@ struct DLaunch {
     uint32_t lds_floats;            // floats of dynamic LDS the histogram code zeroes: the privatised histogram (n_chan_all, if lds_hist)
                                     // followed, in a rolling launch, by the base-channel table [kRollBase][5] at float offset base_off
     uint32_t base_off;
+    uint32_t has_records;           // rolling sequence: some render of it writes per-path records (DRoll::records)
+    uint32_t lean;                  // 1: scene and launch fit the lean profile: the kernels' kLean variants
     uint32_t wide;                  // 1: the sensor's reconstruction filter is wider than a pixel (DSensor::filt_n != 0): the kernels' kWide variants
 };
 

@@ -698,7 +698,7 @@ struct SIGeom {
     V3 n, dp_du, dp_dv;
 };
 
-template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si, SIGeom *geom = nullptr,
+template <bool FULL = false, int V = 0> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, const Hit &h, SI &si, SIGeom *geom = nullptr,
                                                  const Shift &sh = no_shift()) {
     si.t = h.t;
     V3 dp_du;
@@ -728,7 +728,7 @@ template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, c
             nc = nq[2];
         }
         float4 duv = make_float4(0, 0, 0, 0);   // (uv1 - uv0, uv2 - uv0), same speculation
-        if (sc.uvs) duv = sc.uvs[h.slot];
+        if (rare<V>(sc.uvs != nullptr)) duv = sc.uvs[h.slot];
         V3 p0 = shifted(mk(a.x, a.y, a.z), sh), p1 = shifted(mk(b.x, b.y, b.z), sh), p2 = shifted(mk(c.x, c.y, c.z), sh);
         si.shape = __float_as_uint(b.w);
         const uint32_t tag = __float_as_uint(c.w);
@@ -740,7 +740,7 @@ template <bool FULL = false> BF_DEV void make_si(const DScene &sc, V3 o, V3 d, c
         V3 n = normalize(cross(dp0, dp1));
         V3 dp_dv;
         coordinate_system(n, dp_du, dp_dv);
-        if (tag & 2u) {
+        if (rare<V>((tag & 2u) != 0u)) {
             // mesh.cpp:493-512: tangents of the UV parameterisation; a degenerate one keeps coordinate_system(n)
             float det = fmsub(duv.x, duv.w, duv.y * duv.z), inv_det = rcp(det);
             if (det != 0.f) {
@@ -1027,8 +1027,8 @@ BF_DEV float spot_falloff(const DEmitter &e, V3 d) {
     return (cos_theta <= e.cos_cutoff) ? 0.f : beam_res;
 }
 
-BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
-    if (e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT) {
+template <int V = 0> BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
+    if (rare<V>(e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT)) {
         V3 p = mk(e.to_world[3], e.to_world[7], e.to_world[11]);
         ds.pdf = 1.f;
         ds.delta = true;
@@ -1058,8 +1058,8 @@ BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 re
 }
 
 // pdf_emitter_direction for the hit `p_hit` (normal n_hit) seen from `p_ref`
-BF_DEV float emitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
-    if (e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT) return 0.f;
+template <int V = 0> BF_DEV float emitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
+    if (rare<V>(e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT)) return 0.f;
     const DRect &rc = sc.rects[e.rect];
     V3 d = p_hit - p_ref;
     float dist = norm(d);
@@ -1084,10 +1084,11 @@ BF_DEV void srgb_to_xyz_grey(float l, float &X, float &Y, float &Z) {
 }
 
 // sensor rays: fluxmeter.cpp:63-85, perspective.cpp:172-199
+template <int V = 0>
 BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, float ay, V3 &o, V3 &d, float &mint,
                                float &maxt) {
     const DSensor &s = *sc.sensor;
-    if (s.type == BF_SENSOR_FLUXMETER || s.type == BF_SENSOR_IRRADIANCEMETER) {
+    if (rare<V>(s.type == BF_SENSOR_FLUXMETER || s.type == BF_SENSOR_IRRADIANCEMETER)) {
         const DRect &rc = sc.rects[s.rect];
         o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
         V3 local = square_to_cosine_hemisphere(ax, ay);
@@ -1098,7 +1099,7 @@ BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, f
         mint = kRayEpsilon;
         maxt = BF_INF;
         return 1.f * kPi;
-    } else if (s.type == BF_SENSOR_RADIANCEMETER) {     // radiancemeter.cpp:91-108: position and aperture samples unused
+    } else if (rare<V>(s.type == BF_SENSOR_RADIANCEMETER)) {     // radiancemeter.cpp:91-108: position and aperture samples unused
         o = xf_point(s.to_world, mk(0.f, 0.f, 0.f));
         d = xf_vector(s.to_world, mk(0.f, 0.f, 1.f));
         mint = kRayEpsilon;

@@ -44,11 +44,11 @@ __device__ unsigned long long g_tail_prof[8192 * 24];
 #else
 #define BF_PROF_STAMP(var)
 #endif
-template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES, bool WIDE = false>
+template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES, int VX = 0>
 __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
-    constexpr int kRX = 2 | (WIDE ? kWide : 0);       // mode decided at run time; WIDE: the filtered put (bf_path_logic.h: kWide)
+    constexpr int kRX = 2 | VX;       // mode class decided at run time; VX: kWide (the filtered put) or kLean (bf_device.h: kernel variant word)
     extern __shared__ __align__(16) unsigned char s_raw[];
     int *s_stack = reinterpret_cast<int *>(s_raw);                         // [kStackDepth][kBlock]
     float *s_hist = reinterpret_cast<float *>(s_raw + sizeof(int) * kStackDepth * kBlock);
@@ -542,7 +542,7 @@ extern "C" hipError_t bfk_launch_render(const bfd::DScene *sc, const bfd::DLaunc
     const bool spill = sc->stack_need > (uint32_t) bfd::kStackDepth;
 #define BF_RENDER_LAUNCH(S, R, P, WF_, IT_)                                                                                              \
     if (lp->wide)                                                                                                                        \
-        hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P, BF_TAIL_WAVES, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P, BF_TAIL_WAVES, bfd::kWide>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, \
                            *lp, g_hist, records, counters, WF_, IT_);                                                                    \
     else                                                                                                                                 \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, R, P>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist,         \
@@ -583,8 +583,11 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     const bool two = tail_waves == 2;
 #define BF_TAIL_LAUNCH(S, P)                                                                                                           \
     if (lp->wide)                                                                                                                      \
-        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, true>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp,   \
-                           g_hist, records, counters, *wf, it);                                                                       \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, bfd::kWide>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc,  \
+                           *lp, g_hist, records, counters, *wf, it);                                                                  \
+    else if (lp->lean && !two)                                                                                                         \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, bfd::kLean>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc,  \
+                           *lp, g_hist, records, counters, *wf, it);                                                                  \
     else if (two)                                                                                                                      \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 2>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, *lp, g_hist, \
                            records, counters, *wf, it);                                                                               \

@@ -300,11 +300,11 @@ BF_DEV float tx_eval_signal(const DEmitter &e, float time, float frequency) {
 BF_DEV float freq_of(float c, float lambda_nm) { return (float) ((double) c * (1.0 / ((double) lambda_nm * 1e-9))); }
 
 // Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
-BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si, float si_time, float lambda0) {
+template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si, float si_time, float lambda0) {
     const DRect &rc = sc.rects[e.rect];
     if (e.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.radiance * rc.area : 0.f;
     float signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
-    if (e.type == BF_TRANSMITTER_PHASED) {
+    if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {
         // phasedtransmitter.cpp:296-381: geom_gain = antenna / area * sample_wigner(ds with the uninitialised d, Q5)
         float geom_gain = 1.f * rcp(rc.area);
         geom_gain *= phased_sample_wigner(e.velems, e.n_velems, e.wid, si.p, mk(-0.f, -0.f, -0.f), lambda0);
@@ -314,6 +314,7 @@ BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si,
     return (si.wi.z > 0.f) ? signal_power * e.gain * (1.f * ws) * 6.28318530717958647692f : 0.f;
 }
 // Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
+template <int V = 0>
 BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float ref_time, float lambda0,
                                           float sx, float sy, DirSample &ds) {
     const DRect &rc = sc.rects[e.rect];
@@ -336,7 +337,7 @@ BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V
     float t = ref_time;
     if ((double) ds.dist > 5e-7) t += -ds.dist / sc.c;                      // retarded time :422-425
     float signal_power = tx_eval_signal(e, t, freq_of(sc.c, lambda0));
-    if (e.type == BF_TRANSMITTER_PHASED) {
+    if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {
         // phasedtransmitter.cpp:560-585: geom_gain *= W; ds.pdf *= W; ds.pdf = sqrt(ds.pdf^2); extents = 1
         float w = phased_sample_wigner(e.velems, e.n_velems, e.wid, p, -ds.d, lambda0);
         geom_gain *= w;
@@ -351,7 +352,7 @@ BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V
     return active ? signal_power * e.gain * geom_gain * extents : 0.f;
 }
 // Transmitter::pdf_direction — areatransmitter.cpp:167-186, wignertransmitter.cpp:540-577
-BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit, float lambda0) {
+template <int V = 0> BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit, float lambda0) {
     const DRect &rc = sc.rects[e.rect];
     V3 d = p_hit - p_ref;
     float dist = norm(d);
@@ -360,7 +361,7 @@ BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p
     float value = rc.inv_area, adp = __builtin_fabsf(dot(d, n_hit));
     value *= (adp != 0.f) ? (dist * dist) / adp : 0.f;
     if (e.type == BF_TRANSMITTER_WIGNER) value *= rect_sample_wigner(rc, p_hit, -d, lambda0);
-    if (e.type == BF_TRANSMITTER_PHASED) {                         // phasedtransmitter.cpp:606-620
+    if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {                // phasedtransmitter.cpp:606-620
         value *= phased_sample_wigner(e.velems, e.n_velems, e.wid, p_hit, -d, lambda0);
         value = __builtin_sqrtf(value * value);
     }
@@ -368,6 +369,7 @@ BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p
 }
 
 // Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
+template <int V = 0>
 BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
                                  float &mint, float &maxt, float &lambda0) {
     const DSensor &s = *sc.sensor;
@@ -380,7 +382,7 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
     d = to_world(f, local);
     mint = kRayEpsilon;
     maxt = BF_INF;
-    if (s.type == BF_RECEIVER_OMNI) {
+    if ((V & kLean) || s.type == BF_RECEIVER_OMNI) {
         float lo = sc.lambda_min, hi = sc.lambda_max;
         lambda0 = wl_sample * (hi - lo) + lo;            // sample_uniform_spectrum (spectrum.h:312-316), lane 0
         return (hi - lo) * rc.area;
@@ -406,11 +408,10 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
 // Mode specialisation: RX = 0 compiles the render modes only (path / range / time), RX = 1 the receive modes only,
 // RX = 2 decides at run time (the one-kernel variant and the tail).  The receive branches carry the Wigner / phased-array
 // / signal-model code; a shading kernel that cannot reach them allocates fewer registers.
-template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return (RX & 3) == 2 ? lp.mode == BF_MODE_RECEIVE_RAW : (RX & 3) == 1; }
+template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return (RX & kModeMask) == 2 ? lp.mode == BF_MODE_RECEIVE_RAW : (RX & kModeMask) == 1; }
 // RX | kWide: the kernel variant for films / ADCs whose reconstruction filter is wider than a pixel (DLaunch::wide).  A variant
 // of its own, not a branch: the filtered put's live values cost the box-filter kernels 3 % of wf_shade when both were compiled
 // into one (profiles/r03_wide_filter_ab.txt), and every radar scene of the reference uses the box filter.
-constexpr int kWide = 4;
 
 // ---------------------------------------------------------------------------
 // path generation
@@ -451,11 +452,11 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
         float wl = next_1d(s.rng);
         s.t_rx = time;
         s.time = time;
-        float w = receiver_sample_ray(sc, wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
+        float w = receiver_sample_ray<RX>(sc, wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
     } else {
         // render_sample — integrator.cpp:263-283
-        if (sc.sensor->type != BF_SENSOR_PERSPECTIVE && sc.sensor->type != BF_SENSOR_RADIANCEMETER) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
+        if (rare<RX>(sc.sensor->type != BF_SENSOR_PERSPECTIVE && sc.sensor->type != BF_SENSOR_RADIANCEMETER)) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
             ax = next_1d(s.rng);
             ay = next_1d(s.rng);
         }
@@ -463,13 +464,13 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
         (void) next_1d(s.rng);     // wavelength sample (consumed in RGB mode too)
         // position_sample = pos + next_2d; adjusted_position = position_sample / crop_size (integrator.cpp:263,276-278)
         uint32_t px = 0, py = 0;
-        if (lp.spp) {
+        if (rare<RX>(lp.spp != 0u)) {
             const uint64_t q = (lp.path_offset + path_i) / lp.spp;
             px = (uint32_t) (q % lp.film_w);
             py = (uint32_t) (q / lp.film_w);
         }
         const float posx = (float) px + fx, posy = (float) py + fy;
-        (void) sensor_sample_ray(sc, posx / (float) lp.film_w, posy / (float) lp.film_h, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
+        (void) sensor_sample_ray<RX>(sc, posx / (float) lp.film_w, posy / (float) lp.film_h, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
         // ImageBlock::put, box branch (imageblock.cpp:166-172): the sample lands in pixel lo = ceil(pos - .5 - .5),
         // i.e. the pixel it was drawn in or, when next_2d returned exactly 0, its left / upper neighbour
         const float lx = __builtin_ceilf((posx - .5f) - .5f), ly = __builtin_ceilf((posy - .5f) - .5f);
@@ -550,18 +551,18 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
                          uint32_t &c_bounces BF_SHADEPROF_ARG BF_LANEPROF_ARG) {
     BF_SHADEPROF_STAMP(spf_t0);
     const bool receive = mode_receive<RX>(lp);
-    const bool is_range = !receive && lp.mode == BF_MODE_RANGE, is_time = !receive && lp.mode == BF_MODE_TIME;
+    const bool is_range = !receive && lp.mode == BF_MODE_RANGE, is_time = rare<RX>(!receive && lp.mode == BF_MODE_TIME);
     const bool iq = receive && lp.iq != 0u;
-    const bool phase_bins = receive && lp.phase_bins != 0u;
-    const bool doppler = receive && lp.doppler != 0u;
-    const uint32_t n_emit = sc.n_emitters;
+    const bool phase_bins = rare<RX>(receive && lp.phase_bins != 0u);
+    const bool doppler = rare<RX>(receive && lp.doppler != 0u);
+    const uint32_t n_emit = (RX & kLean) ? 1u : sc.n_emitters;
     sh.want = false;
     SI si;
     const bool si_valid = hit.t != BF_INF;
     int emitter = -1;
     SLP(10, si_valid);
     if (si_valid) {
-        make_si(sc, s.ro, s.rd, hit, si, nullptr, path_shift(lp, s.render));
+        make_si<false, RX>(sc, s.ro, s.rd, hit, si, nullptr, path_shift(lp, s.render));
         emitter = si.emitter;
     }
 #ifdef BF_TAIL_PROF
@@ -590,8 +591,8 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         SLP(11, emitter >= 0);
         if (emitter >= 0) {
             const DEmitter &e = sc.emitters[emitter];
-            float emitter_pdf = receive ? transmitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
-                                        : emitter_pdf_direction(sc, e, s.prev_p, si.p, si.sh.n);
+            float emitter_pdf = receive ? transmitter_pdf_direction<RX>(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
+                                        : emitter_pdf_direction<RX>(sc, e, s.prev_p, si.p, si.sh.n);
             if (n_emit != 1) emitter_pdf *= 1.f / (float) n_emit;
             s.emission_weight = mis_weight(s.bs_pdf, emitter_pdf);
         }
@@ -607,9 +608,9 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         if (doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
         float ev;
         if (receive)
-            ev = transmitter_eval(sc, e, si, s.time, s.lambda0);
+            ev = transmitter_eval<RX>(sc, e, si, s.time, s.lambda0);
         else
-            ev = (e.type == BF_EMITTER_AREA) ? ((si.wi.z > 0.f) ? e.radiance : 0.f) : 0.f;
+            ev = ((RX & kLean) || e.type == BF_EMITTER_AREA) ? ((si.wi.z > 0.f) ? e.radiance : 0.f) : 0.f;
         float contrib = s.emission_weight * s.throughput * ev;
         if (iq) {
             // optical length receiver -> ... -> this transmitter point: c * (t_rx - retarded time)
@@ -655,9 +656,9 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
             }
             const DEmitter &e = sc.emitters[index];
             if (receive)
-                emitter_val = transmitter_sample_direction(sc, e, si.p, s.time, s.lambda0, sx, sy, ds);
+                emitter_val = transmitter_sample_direction<RX>(sc, e, si.p, s.time, s.lambda0, sx, sy, ds);
             else
-                emitter_val = emitter_sample_direction(sc, e, si.p, sx, sy, ds);
+                emitter_val = emitter_sample_direction<RX>(sc, e, si.p, sx, sy, ds);
             if (n_emit > 1) {
                 ds.pdf *= emitter_pdf;
                 emitter_val *= rcp(emitter_pdf);
@@ -863,8 +864,8 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
         const DSensor &se = *sc.sensor;
         float tf0 = s.t_rx - se.adc_sampling_start;
-        float tf1 = freq_of(sc.c, lp.doppler ? s.lambda0 + s.dlambda : s.lambda0);
-        if (lp.mix) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, s.lambda0));      // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601)
+        float tf1 = freq_of(sc.c, rare<RX>(lp.doppler != 0u) ? s.lambda0 + s.dlambda : s.lambda0);
+        if (rare<RX>(lp.mix != 0u)) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, s.lambda0));      // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601)
         tf0 *= (float) se.t_bins / se.t_bandwidth;
         tf1 *= (float) se.f_bins / se.f_bandwidth;
         float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode
@@ -875,7 +876,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         // PhaseIntegrator::sample (phase.cpp:93-141): S{k}.Y takes hsum(L), before the receiver weight,
         // iff rect((phase - centre_k) / width) > 0; evaluated exactly as written there for the (at most
         // three) candidate bins around phase / width
-        const uint32_t P = lp.phase_bins;
+        const uint32_t P = (RX & kLean) ? 0u : lp.phase_bins;
         const float pv = valid ? 4.f * s.result : 0.f;
         int pk0 = 0;
         uint32_t pmask = 0u;            // bit i: bin pk0 - 1 + i takes the sample
@@ -932,12 +933,12 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         rec_L = a0;
         rec_aux = lp.iq ? a1 : s.t_rx - se.adc_sampling_start;
     } else {
-        const bool is_range = lp.mode == BF_MODE_RANGE, is_time = lp.mode == BF_MODE_TIME;
+        const bool is_range = lp.mode == BF_MODE_RANGE, is_time = rare<RX>(lp.mode == BF_MODE_TIME);
         // ray weight: fluxmeter.cpp:84 (wav_weight * pi), irradiancemeter.cpp:82 (wav_weight * pi / surface_area),
         // perspective.cpp:198 (wav_weight)
         float sensor_w = 1.f;
-        if (sc.sensor->type == BF_SENSOR_FLUXMETER) sensor_w = 1.f * kPi;
-        if (sc.sensor->type == BF_SENSOR_IRRADIANCEMETER) sensor_w = 1.f * kPi / sc.rects[sc.sensor->rect].area;
+        if (rare<RX>(sc.sensor->type == BF_SENSOR_FLUXMETER)) sensor_w = 1.f * kPi;
+        if (rare<RX>(sc.sensor->type == BF_SENSOR_IRRADIANCEMETER)) sensor_w = 1.f * kPi / sc.rects[sc.sensor->rect].area;
         float L = sensor_w * s.result;                        // integrator.cpp:286
         float X, Y, Z;
         if (lp.color_mode == BF_COLOR_RGB)
@@ -954,7 +955,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         // the five base channels of a 1 x 1 film are summed in registers while every lane of the wave feeds the same
         // histogram: a plain launch, or the newest render of a rolling sequence
         const bool use_acc = lp.batch == 0u || (lp.roll != nullptr && s.render == lp.roll_newest);
-        if (lp.spp) {
+        if (rare<RX>(lp.spp != 0u)) {
             const uint64_t q = (lp.path_offset + s.path_i) / lp.spp;
             const uint32_t px = (uint32_t) (q % lp.film_w) - ((s.flags & kFlagFilmLeft) ? 1u : 0u);
             const uint32_t py = (uint32_t) (q / lp.film_w) - ((s.flags & kFlagFilmUp) ? 1u : 0u);
@@ -1006,7 +1007,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 ++acc.invalid;
             }
         } else if (ok) {
-            if (lp.spp) {
+            if (rare<RX>(lp.spp != 0u)) {
                 if (X != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 0u, X);
                 if (Y != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 1u, Y);
                 if (Z != 0.f) hist_add(s_hist, g_hist, lds_hist, pix + 2u, Z);
@@ -1063,7 +1064,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
     }
     uint64_t rec_i = s.path_i;
     if (lp.roll) {              // rolling sequence: the render's own record array, indexed by the local path
-        records = lp.roll[s.render & (kRollRing - 1u)].records;
+        records = lp.has_records ? lp.roll[s.render & (kRollRing - 1u)].records : nullptr;     // (no per-path fetch of a null pointer)
         rec_i -= (uint64_t) s.render * lp.batch_paths;
     }
     if (records) {

@@ -657,7 +657,16 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 #define BF_SHADE_LAUNCH_WIDE(F)                          \
     if (rx) BF_SHADE_LAUNCH_RX(F, 3, 1 | bfd::kWide);    \
     else BF_SHADE_LAUNCH_RX(F, 3, 0 | bfd::kWide)
-    if (lp->wide) {
+#define BF_SHADE_LAUNCH_LEAN(F)                          \
+    if (rx) BF_SHADE_LAUNCH_RX(F, 3, 1 | bfd::kLean);    \
+    else BF_SHADE_LAUNCH_RX(F, 3, 0 | bfd::kLean)
+    if (lp->lean && !lp->wide && (first || waves == 3)) {
+        // scene and launch fit the lean profile (bf_device.h: kLean; three waves per SIMD only)
+        if (first == 3) { BF_SHADE_LAUNCH_LEAN(3); }
+        else if (first == 2) { BF_SHADE_LAUNCH_LEAN(2); }
+        else if (first) { BF_SHADE_LAUNCH_LEAN(1); }
+        else { BF_SHADE_LAUNCH_LEAN(0); }
+    } else if (lp->wide) {
         // reconstruction filter wider than a pixel: the kWide variants (three waves per SIMD only)
         if (first == 3) { BF_SHADE_LAUNCH_WIDE(3); }
         else if (first == 2) { BF_SHADE_LAUNCH_WIDE(2); }
@@ -679,6 +688,7 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
     }
 #undef BF_SHADE_LAUNCH
 #undef BF_SHADE_LAUNCH_WIDE
+#undef BF_SHADE_LAUNCH_LEAN
 #undef BF_SHADE_LAUNCH_RX
     return hipGetLastError();
 }

@@ -314,7 +314,14 @@ typedef struct bf_stats {
     uint32_t n_launches_tail;  /* tail kernel launches (timed renders / sequences)            */
     uint32_t n_launches_shade; /* wf_shade launches (timed renders / sequences: a rolling call has one more than
                                   bounce iterations, its wake launch)                          */
+    uint32_t kernel_variant;   /* which build of the shading / tail kernels ran: BF_VARIANT_LEAN = scene and launch fit the
+                                  lean profile (one area-type emitter, perspective camera or omnidirectional receiver, 1 x 1
+                                  film, ...: every radar scene of the reference) and everything else is compiled out of the
+                                  kernels; BF_VARIANT_WIDE = reconstruction filter wider than a pixel; 0 = general kernels.
+                                  Same results either way (BF_LEAN=0 in the environment forces the general ones)            */
+    uint32_t reserved_;
 } bf_stats;
+enum { BF_VARIANT_LEAN = 1, BF_VARIANT_WIDE = 2 };
 
 typedef struct bf_scene_info {
     uint32_t n_shapes, n_rects, n_triangles, n_bvh_nodes;

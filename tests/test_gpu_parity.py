@@ -1170,3 +1170,41 @@ def test_quantised_nodes_opt_in_is_bit_exact(hiplib, monkeypatch):
     for k in ("L", "aux"):
         assert np.array_equal(rb[1][k].view(np.uint32), rr[k].view(np.uint32))
         assert np.array_equal(rb[0][k].view(np.uint32), out[1][k].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["bus_range", "car_normals", "bus_receive", "bus_receive_iq", "not_lean_two_emitters"])
+def test_lean_and_general_kernels_agree(hiplib, monkeypatch, case):
+    """Scenes that fit the lean profile (bf_stats.kernel_variant) run shading / tail kernels with everything outside the profile
+    compiled out; BF_LEAN=0 (read when the scene is created) forces the general kernels.  Same per-path records, bit for bit, from
+    both — plain, planned and rolling renders — and both equal the oracle's; a scene outside the profile never gets the lean ones."""
+    if case == "bus_range":
+        sd, lp = scenes.bus_radar(n_tris=20000, n_paths=30000, bins=256, dr=0.1)
+    elif case == "car_normals":
+        sd, lp = scenes.car_radar(n_tris=30000, n_paths=30000, bins=1024, dr=0.03)
+    elif case == "not_lean_two_emitters":
+        sd, lp = _zoo_scene(two_emitters=True)
+    else:
+        sd, lp = scenes.bus_receive(n_tris=20000, n_paths=30000)
+        if case == "bus_receive_iq":
+            lp.mode = capi.BF_MODE_RECEIVE_IQ
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
+    out = {}
+    for lean in ("1", "0"):
+        monkeypatch.setenv("BF_LEAN", lean)
+        g = capi.Scene(sd)
+        h1, r1, s1 = g.render(lp, records=True)
+        want = capi.BF_VARIANT_LEAN if (lean == "1" and case != "not_lean_two_emitters") else 0
+        assert s1.kernel_variant == want
+        h2, r2, s2 = g.render(lp, records=True)                 # the planned render (no host synchronisation inside)
+        assert np.array_equal(r1, r2) and s2.kernel_variant == want
+        lp.flags |= capi.BF_FLAG_MEGAKERNEL                       # the one-kernel variant is always the general build
+        assert g.render(lp, records=True)[2].kernel_variant == 0
+        lp.flags &= ~capi.BF_FLAG_MEGAKERNEL
+        for k in ("n_rays", "valid"):
+            assert np.array_equal(r1[k], ro[k])
+        assert np.array_equal(r1["aux"].view(np.uint32), ro["aux"].view(np.uint32))
+        assert np.array_equal(r1["L"].view(np.uint32), ro["L"].view(np.uint32))
+        assert s1.n_rays_closest == so.n_rays_closest and s1.n_rays_shadow == so.n_rays_shadow and s1.n_invalid == so.n_invalid
+        out[lean] = (h1, r1)
+    assert np.array_equal(out["1"][1], out["0"][1])
+    assert np.allclose(out["1"][0], out["0"][0], rtol=2e-5, atol=1e-3)
