@@ -153,6 +153,7 @@ def add_stats(acc, st):
         acc[k] = acc.get(k, 0) + getattr(st, k)
     acc["n_tail_launches"] = acc.get("n_tail_launches", 0) + (st.n_launches_tail or (1 if st.tail_ms > 0 else 0))
     acc["n_shade_launches"] = acc.get("n_shade_launches", 0) + (st.n_launches_shade or st.n_bounce_iters)
+    acc["kernel_variant"] = st.kernel_variant
 
 
 def main():
@@ -361,10 +362,13 @@ def main():
                     "tail": max(tim["n_tail_launches"], 1)}
         bytes_ = {"wf_trace": b_trace, "wf_shade": b_shade, "tail": b_tail}
         # the symbols rocprofv3 prints (template arguments: wf_trace<STATS, W, SHIFT, QUANT>, wf_shade<FIRST, W, RX> with
-        # FIRST = 0 alive masks / 1 first bounce / 2 wake launch / 3 alive masks + eviction, bf_render_kernel<STATS, RESUME, SPILL, TW>)
+        # FIRST = 0 alive masks / 1 first bounce / 2 wake launch / 3 alive masks + eviction, bf_render_kernel<STATS, RESUME, SPILL, TW, VX>)
+        # RX = mode class (0 render modes, 1 receive modes) | 8 for the lean build; the tail's fifth argument likewise (absent = 0)
+        lean = tim.get("kernel_variant", 0) == capi.BF_VARIANT_LEAN
         names = {"wf_trace": "bfd::wf_trace<false, 5, %s, false>" % ("true" if w.sweep else "false"),
-                 "wf_shade": "bfd::wf_shade<0|1|2|3, 3, %d>" % (1 if w.receive else 0),
-                 "tail": "bfd::bf_render_kernel<false, true, %s, 3> (tail)" % ("true" if info.bvh_stack_need > 32 else "false")}
+                 "wf_shade": "bfd::wf_shade<0|1|2|3, 3, %d>" % ((1 if w.receive else 0) | (8 if lean else 0)),
+                 "tail": "bfd::bf_render_kernel<false, true, %s, 3%s> (tail)" % ("true" if info.bvh_stack_need > 32 else "false",
+                                                                                   ", 8" if lean else "")}
         traffic = pmc_traffic(w, args, rolling, n_streams)
         total_ms = sum(ms.values()) or 1.0
         kernels = []
@@ -414,6 +418,9 @@ def main():
                 "parallelism": "sample-sharded x%d (%s), RCCL all-reduce of the histogram" % (world, args.scaling),
                 "streams": n_streams,
                 "rolling": rolling,
+                # which build of wf_shade / the tail ran (bf_stats.kernel_variant): "lean" = everything outside the radar scenes'
+                # profile compiled out, chosen by the library per scene and launch; same per-path results
+                "kernels": {0: "general", 1: "lean", 2: "wide-filter"}.get(tim.get("kernel_variant", 0), "general"),
                 "mpaths_per_s": round(paths_all / dt / 1e6, 2),
                 "rays_per_path": round(rays_all / paths_all, 3),
             },
