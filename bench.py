@@ -219,6 +219,8 @@ def main():
         # batches of at most 2^24 paths (a handle's pool), dealt round-robin to the handles
         kmax = max(1, (1 << 24) // w.paths)
         n_chunks = max(n_streams, (w.n_pulses + kmax - 1) // kmax)
+        while w.n_pulses % n_chunks:          # equal batches: a handle's rolling sequence keeps one shape (K renders per call)
+            n_chunks += 1
         bounds = [w.n_pulses * j // n_chunks for j in range(n_chunks + 1)]
         for c in range(n_chunks):
             k0, k1 = bounds[c], bounds[c + 1]

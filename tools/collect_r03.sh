@@ -15,10 +15,7 @@ for c in c2 c3 c4shard c4 c5; do
 done
 cp $P/c2_pmc_sq_l2.txt profiles/r03_c2_pmc_sq_l2.txt
 cp $P/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
-python3 - <<'PY'
-import json, hashlib, glob, os
-h = hashlib.sha256()
-for f in sorted(glob.glob("beifong_amd/csrc/*.hip") + glob.glob("beifong_amd/csrc/*.h") + glob.glob("beifong_amd/csrc/*.cpp")):
-    h.update(open(f, "rb").read())
-print("csrc now", h.hexdigest()[:16], "profile", json.load(open("profiles/r03_pmc_traffic.json")).get("csrc_sha16"))
-PY
+python3 -c "
+import sys, json; sys.path.insert(0, '.')
+import bench
+print('csrc now', bench.csrc_hash(), 'profiled', json.load(open('profiles/r03_pmc_traffic.json')).get('csrc_sha16'))"
