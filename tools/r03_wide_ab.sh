@@ -1,6 +1,7 @@
 #!/bin/bash
 # does the filtered branch of film_put (reconstruction filters wider than a pixel) cost the box-filter scenes anything?
-# default build against make variant VARIANT=nowide EXTRA=-DBF_WIDE_FILTER=0
+# default build against libbeifong_hip_nowide.so = the library of the commit before the filters (the run-time-branch form
+# had a macro to compile the branch out; as shipped the box-filter kernels do not contain it at all: kWide variants)
 cd "$(dirname "$0")/.."
 out=gpurun_out/r03_wide_ab.txt
 : > $out
