@@ -104,6 +104,17 @@ def test_bfrender_cli(hiplib, tmp_path):
     assert img.shape == (1, 1, 155) and sorted(names) == names and "S49.B" in names
     assert img[0, 0, names.index("W")] == 5000
     assert np.allclose(sorted(img.ravel()), sorted(a.ravel()), rtol=1e-4, atol=1e-3)
+    # the long forms, a sensor index and several scene files in one call (mitsuba.cpp:171-183,228,266-292)
+    p2 = tmp_path / "second.xml"
+    p2.write_text(TRANS_RAD_LIKE)
+    r = subprocess.run([os.path.join(HOST, "bfrender"), "--mode", "scalar_rgb", "--define", "spp=300", "--sensor", "0", "--threads", "4",
+                        "--verbose", str(p), str(p2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name in ("scene.exr", "second.exr"):
+        img, names = _host.read_exr(str(tmp_path / name))
+        assert img[0, 0, names.index("W")] == 300
+    r = subprocess.run([os.path.join(HOST, "bfrender"), "-s", "3", str(p)], capture_output=True, text=True)
+    assert r.returncode == 1 and "out of bounds" in r.stderr
 
 
 def test_film_develop_through_the_python_layer(mitsuba, hiplib, tmp_path):
