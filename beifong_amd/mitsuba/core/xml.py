@@ -14,10 +14,12 @@ _OBJECT_TAGS = {
 # plugin type -> XML tag (class aliases, xml.cpp:153-161)
 _PLUGIN_TAG = {
     "path": "integrator", "pathlength": "integrator", "pathtime": "integrator", "range": "integrator", "time": "integrator",
-    "pathtimefrequency": "integrator", "rectangle": "shape", "obj": "shape", "ply": "shape", "diffuse": "bsdf",
-    "twosided": "bsdf", "roughconductor": "bsdf", "spot": "emitter", "area": "emitter", "areatransmitter": "transmitter",
-    "wignertransmitter": "transmitter", "fluxmeter": "sensor", "perspective": "sensor", "omnidirectional": "receiver",
-    "wignerreceiver": "receiver", "hdrfilm": "film", "hdradc": "adc", "box": "rfilter", "gaussian": "rfilter",
+    "pathtimefrequency": "integrator", "phase": "integrator", "rectangle": "shape", "obj": "shape", "ply": "shape", "diffuse": "bsdf",
+    "twosided": "bsdf", "roughconductor": "bsdf", "spot": "emitter", "point": "emitter", "area": "emitter",
+    "areatransmitter": "transmitter", "wignertransmitter": "transmitter", "phasedtransmitter": "transmitter",
+    "fluxmeter": "sensor", "irradiancemeter": "sensor", "radiancemeter": "sensor", "perspective": "sensor",
+    "omnidirectional": "receiver", "wignerreceiver": "receiver", "phasedreceiver": "receiver", "hdrfilm": "film", "hdradc": "adc",
+    "box": "rfilter", "tent": "rfilter", "gaussian": "rfilter", "mitchell": "rfilter", "catmullrom": "rfilter", "lanczos": "rfilter",
     "independent": "sampler",
 }
 
@@ -100,6 +102,11 @@ def load_dict(d, base_dir="."):
     matrix loses its analytic inverse (Transform(matrix) inverts numerically,
     transform.h), exactly as in the reference."""
     text = dict_to_xml(d)
+    if _PLUGIN_TAG.get(d.get("type")) == "rfilter":
+        # a reconstruction filter is complete on its own (eval / eval_discretized / radius: src/rfilters/tests/test_rfilter.py)
+        o = load_string(text.replace("<rfilter ", '<rfilter version="2.1.0" ', 1), base_dir=base_dir)
+        o._dict = dict(d)
+        return o
     if d.get("type") != "scene":
         # single objects cannot be instantiated standalone by the scene loader's
         # entry point; keep the dict so that a parent load_dict can embed it

@@ -198,6 +198,24 @@ def test_xml_default_filter_is_gaussian_and_reaches_the_flat_scene():
         assert d.sensor.rfilter.radius == radius and d.sensor.rfilter.border == border and d.sensor.rfilter.block_size == 32
 
 
+def test_load_dict_builds_filters_and_embeds_them():
+    """src/python/python/xml.py load_dict: a filter dictionary gives the same object as the XML, stands on its own, and can be
+    embedded in a film / ADC dictionary."""
+    from beifong_amd import mitsuba
+    mitsuba.set_variant("scalar_rgb")
+    from beifong_amd.mitsuba.core.xml import load_dict
+    f = load_dict({"type": "gaussian", "stddev": 0.7})
+    x = _host_filter("gaussian", stddev=0.7)
+    assert (f.radius(), f.border_size(), f.eval(0.3), f.eval_discretized(1.1)) == (x.radius(), x.border_size(), x.eval(0.3), x.eval_discretized(1.1))
+    scene = load_dict({"type": "scene", "integrator": {"type": "path"},
+                       "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 4, "height": 2, "rfilter": load_dict({"type": "lanczos", "lobes": 2})},
+                                  "sampler": {"type": "independent", "sample_count": 4}},
+                       "light": {"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "spectrum", "value": 1.0}}}})
+    d = scene.flat_desc(scene.sensors()[0]).desc
+    assert d.sensor.rfilter.radius == 2.0 and d.sensor.rfilter.border == 2
+    assert list(d.sensor.rfilter.values) == list(_host_filter("lanczos", lobes=2).flatten().values)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # HIP against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
