@@ -80,12 +80,42 @@ def params(kwargs):
     return n, keys, vals
 
 
-class Bitmap:
-    """Raw float32 storage of a film / ADC; np.array(bitmap) gives [rows, cols, channels]."""
+class Struct:
+    """mitsuba.core.Struct: only the component types Bitmap.convert is asked for in the reference's scripts."""
 
-    def __init__(self, arr, names):
+    class Type:
+        UInt8, Float16, Float32, Float64 = "uint8", "float16", "float32", "float64"
+
+
+class Bitmap:
+    """mitsuba.core.Bitmap, as far as the reference's radar scripts use it: the raw float32 storage of a film / ADC
+    (np.array(bitmap) gives [rows, cols, channels]; film.bitmap(raw=True)), construction from an array with a pixel format,
+    convert() to RGB / luminance with optional sRGB gamma, write() as .exr / .npy / .png (src/libcore/bitmap.cpp; no libjpeg
+    here: a '.jpg' destination is written as PNG next to it, with a note on stderr)."""
+
+    class PixelFormat:
+        Y, YA, RGB, RGBA, XYZ, XYZA, XYZAW, MultiChannel = "Y", "YA", "RGB", "RGBA", "XYZ", "XYZA", "XYZAW", "MultiChannel"
+
+    _CHANNELS = {"Y": ["Y"], "YA": ["Y", "A"], "RGB": ["R", "G", "B"], "RGBA": ["R", "G", "B", "A"], "XYZ": ["X", "Y", "Z"],
+                 "XYZA": ["X", "Y", "Z", "A"], "XYZAW": ["X", "Y", "Z", "A", "W"]}
+    _XYZ_TO_RGB = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]],
+                           dtype=np.float32)        # include/mitsuba/core/spectrum.h:289-295
+
+    def __init__(self, arr, names=None):
+        arr = np.asarray(arr)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
         self._arr = arr
-        self._names = names
+        if isinstance(names, str):                        # a PixelFormat
+            self._format = names
+            names = Bitmap._CHANNELS.get(names)
+            if names is None or len(names) != arr.shape[2]:
+                raise ValueError(f"Bitmap: pixel format {self._format} does not match {arr.shape[2]} channels")
+        else:
+            self._format = Bitmap.PixelFormat.MultiChannel
+            if names is None:
+                names = [f"ch{i}" for i in range(arr.shape[2])]
+        self._names = list(names)
 
     def __array__(self, dtype=None, copy=None):
         return self._arr if dtype is None else self._arr.astype(dtype)
@@ -96,8 +126,96 @@ class Bitmap:
     def size(self):
         return (self._arr.shape[1], self._arr.shape[0])
 
+    def width(self):
+        return self._arr.shape[1]
+
+    def height(self):
+        return self._arr.shape[0]
+
     def channel_count(self):
         return self._arr.shape[2]
+
+    def pixel_format(self):
+        return self._format
+
+    def convert(self, pixel_format, component_format=Struct.Type.Float32, srgb_gamma=False):
+        """Bitmap::convert for the colour formats: XYZ[A[W]] / RGB[A] / Y[A] -> RGB / RGBA / Y / XYZ; W divides the colour
+        channels (normalisation by the accumulated weight) as the reference's struct converter does."""
+        a = self._arr.astype(np.float32)
+        f = self._format
+        alpha = None
+        if f in ("XYZAW",):
+            w = a[:, :, 4:5]
+            a = np.concatenate([np.where(w != 0, a[:, :, :3] / np.where(w != 0, w, 1), 0), a[:, :, 3:4]], axis=2)
+            f = "XYZA"
+        if f in ("XYZA", "RGBA", "YA"):
+            alpha = a[:, :, -1:]
+            a = a[:, :, :-1]
+            f = f[:-1]
+        if f == "MultiChannel":
+            raise ValueError("Bitmap.convert: a multi-channel bitmap has no colour interpretation; pick channels first")
+        if f == "Y":
+            xyz = np.concatenate([a * np.float32(0.950456), a, a * np.float32(1.08875)], axis=2)
+        elif f == "RGB":
+            xyz = a @ np.linalg.inv(Bitmap._XYZ_TO_RGB).T.astype(np.float32)
+        else:
+            xyz = a
+        target = pixel_format[:-1] if pixel_format in ("RGBA", "XYZA", "YA") else pixel_format
+        if target == "RGB":
+            out = xyz @ Bitmap._XYZ_TO_RGB.T
+        elif target == "XYZ":
+            out = xyz
+        elif target == "Y":
+            out = xyz[:, :, 1:2]
+        else:
+            raise ValueError(f"Bitmap.convert: unsupported target format {pixel_format}")
+        if srgb_gamma:
+            o = np.clip(out, 0, None)
+            out = np.where(o <= 0.0031308, 12.92 * o, 1.055 * np.power(o, 1 / 2.4) - 0.055)
+        if pixel_format in ("RGBA", "XYZA", "YA"):
+            out = np.concatenate([out, alpha if alpha is not None else np.ones_like(out[:, :, :1])], axis=2)
+        if component_format == Struct.Type.UInt8:
+            out = np.clip(np.rint(out * 255.0), 0, 255).astype(np.uint8)
+        else:
+            out = out.astype(component_format)
+        return Bitmap(out, pixel_format)
+
+    def write(self, path):
+        path = str(path)
+        ext = os.path.splitext(path)[1].lower()
+        if ext == ".npy":
+            np.save(path, self._arr)
+        elif ext == ".exr":
+            write_exr(path, self._arr.astype(np.float32), self._names)
+        else:
+            if ext in (".jpg", ".jpeg"):
+                import sys
+                print(f"[beifong] no JPEG encoder in this build: writing {path}.png instead", file=sys.stderr)
+                path += ".png"
+            elif ext != ".png":
+                raise ValueError(f"Bitmap.write: unsupported file format '{ext}'")
+            _write_png(path, self._arr)
+
+
+def _write_png(path, arr):
+    """8-bit grey / grey+alpha / RGB / RGBA PNG (zlib + CRC32 from the standard library)."""
+    import struct
+    import zlib
+    a = np.asarray(arr)
+    if a.dtype != np.uint8:
+        a = np.clip(np.rint(a.astype(np.float32) * 255.0), 0, 255).astype(np.uint8)
+    h, w, c = a.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}.get(c)
+    if ctype is None:
+        raise ValueError("PNG needs 1-4 channels")
+    raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 class _Handle:

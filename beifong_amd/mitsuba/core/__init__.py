@@ -1,7 +1,7 @@
-"""mitsuba.core subset: Transform4f, Thread().file_resolver(), Bitmap."""
+"""mitsuba.core subset: Vector3f / Point3f, Transform4f (= ScalarTransform4f), Thread().file_resolver(), Bitmap, Struct."""
 import numpy as np
 
-from .._host import Bitmap  # noqa: F401
+from .._host import Bitmap, Struct  # noqa: F401
 from ...scenedesc import Transform4f as _T
 
 
@@ -65,3 +65,32 @@ class Thread:
     @staticmethod
     def file_resolver():
         return Thread._fr
+
+
+ScalarTransform4f = Transform4f      # the scalar variants' Transform4f IS ScalarTransform4f (python_scripts/Render.py:30)
+
+
+class _Vec3(np.ndarray):
+    """Vector3f / Point3f of the scalar variants: three float32 components (x, y, z attributes, numpy arithmetic)."""
+
+    def __new__(cls, x=0.0, y=None, z=None):
+        if y is None:
+            v = np.broadcast_to(np.asarray(x, dtype=np.float32), (3,)).copy()
+        else:
+            v = np.array([x, y, z], dtype=np.float32)
+        return v.view(cls)
+
+    x = property(lambda self: float(self[0]))
+    y = property(lambda self: float(self[1]))
+    z = property(lambda self: float(self[2]))
+
+
+class Vector3f(_Vec3):
+    pass
+
+
+class Point3f(_Vec3):
+    pass
+
+
+ScalarVector3f, ScalarPoint3f = Vector3f, Point3f
