@@ -307,13 +307,18 @@ class Shape(_Handle):
         return a.value
 
 
+def _bound(obj):
+    """An object made by load_dict outside a scene stands for its instance in the scene that was loaded with it last."""
+    return obj._resolve() if hasattr(obj, "_resolve") else obj
+
+
 class Integrator(_Handle):
     def render(self, scene, sensor):
-        check(lib().bfh_integrator_render(self._ptr, scene._ptr, sensor._ptr))
+        check(lib().bfh_integrator_render(self._ptr, scene._ptr, _bound(sensor)._ptr))
         return True
 
     def receive(self, scene, receiver):
-        check(lib().bfh_integrator_receive(self._ptr, scene._ptr, receiver._ptr))
+        check(lib().bfh_integrator_receive(self._ptr, scene._ptr, _bound(receiver)._ptr))
         return True
 
     def launch_for(self, endpoint):

@@ -46,14 +46,22 @@ def _fmt(x):
     return repr(float(np.float32(x))) if not isinstance(x, (int, np.integer)) else str(int(x))
 
 
-def dict_to_xml(d, name=None, indent=0):
-    """Serialise a Mitsuba scene dictionary (load_dict format) to scene XML."""
+def dict_to_xml(d, name=None, indent=0, _seen=None):
+    """Serialise a Mitsuba scene dictionary (load_dict format) to scene XML.  An object with an "id" that occurs several times
+    (the same load_dict result embedded in several parents: one shared instance in the reference) is written once and
+    referenced afterwards."""
     pad = "  " * indent
+    if _seen is None:
+        _seen = set()
     d = getattr(d, "_dict", d)          # objects returned by load_dict re-serialise from their source dict
     if not isinstance(d, dict) or "type" not in d:
         raise ValueError("load_dict: every object needs a 'type'")
     typ = d["type"]
     nm = f' name="{_esc(name)}"' if name and not str(name).startswith("_arg_") else ""
+    if typ != "ref" and "id" in d:
+        if d["id"] in _seen:
+            return f'{pad}<ref id="{_esc(d["id"])}"{nm}/>\n'
+        _seen.add(d["id"])
     if typ == "ref":
         return f'{pad}<ref id="{_esc(d["id"])}"{nm}/>\n'
     if typ == "spectrum":
@@ -77,7 +85,7 @@ def dict_to_xml(d, name=None, indent=0):
             continue
         vv = getattr(v, "_dict", v)
         if isinstance(vv, dict):
-            out += dict_to_xml(vv, k, indent + 1)
+            out += dict_to_xml(vv, k, indent + 1, _seen)
         elif isinstance(v, _T):
             m = " ".join(_fmt(x) for x in np.asarray(v.matrix, dtype=np.float32).reshape(16))
             out += f'{pad}  <transform name="{_esc(k)}"><matrix value="{m}"/></transform>\n'
@@ -108,14 +116,64 @@ def load_dict(d, base_dir="."):
         o._dict = dict(d)
         return o
     if d.get("type") != "scene":
-        # single objects cannot be instantiated standalone by the scene loader's
-        # entry point; keep the dict so that a parent load_dict can embed it
-        class Deferred:
-            pass
-
+        # an object outside a scene is kept as its dictionary until a scene that embeds it is loaded; from then on it stands
+        # for its instance in that scene (the reference's scripts keep using such objects: animated_trans_rad.py:316-377 renders
+        # `scene.integrator().render(scene, sen)` and reads `film.bitmap(raw=True)` with `sen`, `film` made by load_dict)
         o = Deferred()
         o._dict = dict(d)
         return o
     o = load_string(text, base_dir=base_dir)
     o._dict = dict(d)
+    _bind(d, o)
     return o
+
+
+class Deferred:
+    """Result of load_dict for an object that is not a scene (see load_dict)."""
+    _target = None
+
+    def _resolve(self):
+        if self._target is None:
+            raise AttributeError("this object was made by load_dict outside a scene: it becomes usable once a scene that "
+                                 "contains it has been loaded with load_dict")
+        return self._target() if callable(self._target) else self._target
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._resolve(), name)
+
+
+def _bind(scene_dict, scene):
+    """Point the Deferred objects embedded in a scene dictionary at their instances in the loaded scene: sensors and
+    receivers in the order of the dictionary, their film / adc / sampler children through them."""
+    sensors, receivers = scene.sensors(), scene.receivers()
+    si = ri = 0
+    for v in scene_dict.values():
+        dd = getattr(v, "_dict", v)
+        if not isinstance(dd, dict):
+            continue
+        tag = _PLUGIN_TAG.get(dd.get("type"))
+        # a shape may carry the sensor / receiver (rectangle with a child endpoint)
+        holders = [(v, dd)] + [(c, getattr(c, "_dict", c)) for c in dd.values() if isinstance(getattr(c, "_dict", c), dict)] \
+            if tag == "shape" else [(v, dd)]
+        for obj, od in holders:
+            t = _PLUGIN_TAG.get(od.get("type"))
+            inst = None
+            if t == "sensor" and si < len(sensors):
+                inst, si = sensors[si], si + 1
+            elif t == "receiver" and ri < len(receivers):
+                inst, ri = receivers[ri], ri + 1
+            if inst is None:
+                continue
+            if isinstance(obj, Deferred):
+                obj._target = inst
+            for c in od.values():
+                if isinstance(c, Deferred):
+                    ct = _PLUGIN_TAG.get(c._dict.get("type"))
+                    if ct == "film":
+                        c._target = inst.film
+                    elif ct == "adc":
+                        c._target = inst.adc
+                    elif ct == "sampler":
+                        c._target = inst.sampler

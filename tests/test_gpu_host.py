@@ -260,3 +260,40 @@ def test_file_loaded_mesh_renders_on_hip(mitsuba, hiplib, tmp_path, kind):
     assert np.array_equal(rg["n_rays"], ro["n_rays"]) and np.array_equal(rg["valid"], ro["valid"])
     assert sg.n_rays_closest == so.n_rays_closest and sg.n_rays_shadow == so.n_rays_shadow
     assert sg.n_rays_traced > 1000           # rays did walk the file-loaded mesh's BVH
+
+
+def test_animated_trans_rad_loop_as_the_script_writes_it(mitsuba, hiplib):
+    """python_scripts/animated_trans_rad.py:100-384 with the import line changed: sampler / film / bsdf / shapes made ONCE by
+    load_dict, per frame a new perspective sensor + area transmitter rectangle + scene, `scene.integrator().render(scene, sen)`
+    with the load_dict'd sensor, `film.bitmap(raw=True)` on the load_dict'd film, bin j read at channel 5 + 3 j."""
+    from beifong_amd.mitsuba.core.xml import load_dict
+    from beifong_amd.mitsuba.core import Vector3f, Transform4f
+    SPP, BINS, DR, N_FRAMES, STEP = 4000, 50, 0.2, 4, 25.0
+    bsdfs = load_dict({"type": "twosided", "id": "material", "bsdf": {"type": "diffuse", "reflectance": {"type": "spectrum", "value": 1}}})
+    targ = load_dict({"type": "rectangle", "id": "target", "to_world": Transform4f.look_at([0, -4, 0], [0, 0, 0], [0, 0, 1]), "bsdf": bsdfs})
+    gnd = load_dict({"type": "rectangle", "id": "gnd", "to_world": Transform4f.translate([0, 0, -1]) * Transform4f.scale([10, 10, 1]), "bsdf": bsdfs})
+    ints = load_dict({"type": "range", "dr": DR, "bins": BINS, "integrator": {"type": "pathlength"}})
+    sampler = load_dict({"type": "independent", "sample_count": SPP})
+    film = load_dict({"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}})
+    txa_size = Transform4f.scale([0.02, 0.05, 1.0])
+    rng_scan = np.zeros([N_FRAMES, BINS])
+    lorigin, boresight = Vector3f(0, 0, 0), Vector3f(0, -1, 0)
+    for i in range(N_FRAMES):
+        rotation_cur = Transform4f.rotate(Vector3f(0, 0, 1), i * STEP)
+        new_boresight_c = rotation_cur.transform_vector(boresight)
+        new_up_c = rotation_cur.transform_vector(Vector3f(0, 0, 1))
+        to_world_cur = Transform4f.look_at(lorigin, new_boresight_c, new_up_c)
+        sen = load_dict({"type": "perspective", "near_clip": DR, "far_clip": BINS * DR + DR, "fov_axis": "x", "fov": 45,
+                         "sampler": sampler, "film": film, "to_world": to_world_cur})
+        emit_r = load_dict({"type": "rectangle", "id": "txa", "to_world": to_world_cur * txa_size,
+                            "emitter": {"type": "area", "radiance": {"type": "spectrum", "value": 100}}})
+        scene = load_dict({"type": "scene", "integrator": ints, "sensor": sen, "emitter": emit_r, "so": targ, "s1": gnd})
+        scene.integrator().render(scene, sen)
+        bmp22_np = np.array(film.bitmap(raw=True))
+        assert bmp22_np.shape == (1, 1, 5 + BINS) and bmp22_np[0, 0, 4] == SPP
+        rng_scan[i] = bmp22_np[0, 0, 5:]
+    # frame 0 looks straight at the target plate 4 m away: its return sits in the bins around 2 x 4 m / 0.2 m (pathlength counts
+    # the way out and back, Q1); turned 75 degrees away the plate is out of the 45-degree beam and only the ground answers
+    k0 = int(np.argmax(rng_scan[0]))
+    assert 36 <= k0 <= 44 and rng_scan[0, k0] > 10 * rng_scan[3, 36:45].max()
+    assert sen.film().bitmap(raw=True).channel_names()[5] == "S0.Y" and sampler.sample_count() == SPP

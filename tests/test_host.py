@@ -629,3 +629,28 @@ def test_script_level_names_of_mitsuba_core(mitsuba, tmp_path):
     from beifong_amd.mitsuba import _host
     back, names = _host.read_exr(str(tmp_path / "frame.exr"))
     assert sorted(names) == ["A", "W", "X", "Y", "Z"] and np.allclose(back[:, :, names.index("X")], img[:, :, 0])
+
+
+def test_load_dict_objects_stand_for_their_instances_in_the_scene(mitsuba):
+    """animated_trans_rad.py / Receive.ipynb keep using the objects load_dict gave them BEFORE the scene existed (render(scene,
+    sen), film.bitmap(), adc.bitmap()): such an object is its dictionary until a scene embeds it, then the scene's instance."""
+    from beifong_amd.mitsuba.core import Transform4f
+    from beifong_amd.mitsuba.core.xml import load_dict, dict_to_xml
+    film = load_dict({"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}})
+    sampler = load_dict({"type": "independent", "sample_count": 16})
+    with pytest.raises(AttributeError, match="outside a scene"):
+        film.bitmap(raw=True)
+    mat = load_dict({"type": "twosided", "id": "material", "bsdf": {"type": "diffuse"}})
+    a = load_dict({"type": "rectangle", "bsdf": mat})
+    b = load_dict({"type": "rectangle", "to_world": Transform4f.translate([0, 0, 2]), "bsdf": mat})
+    sen = load_dict({"type": "perspective", "fov": 45, "sampler": sampler, "film": film})
+    d = {"type": "scene", "integrator": {"type": "path"}, "sensor": sen, "a": a, "b": b,
+         "light": {"type": "rectangle", "emitter": {"type": "area", "radiance": {"type": "spectrum", "value": 1.0}}}}
+    text = dict_to_xml(d)
+    assert text.count('id="material"') == 2 and text.count("<ref ") == 1          # one shared instance: written once, referenced once
+    scene = load_dict(d)
+    assert sen.class_name() == scene.sensors()[0].class_name() and sampler.sample_count() == 16
+    assert type(film._resolve()) is type(scene.sensors()[0].film())
+    # a later scene re-binds the same objects (the per-frame scenes of the sweep scripts)
+    scene2 = load_dict(dict(d, integrator={"type": "path", "max_depth": 3}))
+    assert sen._resolve()._ptr == scene2.sensors()[0]._ptr
