@@ -653,4 +653,5 @@ def test_load_dict_objects_stand_for_their_instances_in_the_scene(mitsuba):
     assert type(film._resolve()) is type(scene.sensors()[0].film())
     # a later scene re-binds the same objects (the per-frame scenes of the sweep scripts)
     scene2 = load_dict(dict(d, integrator={"type": "path", "max_depth": 3}))
-    assert sen._resolve()._ptr == scene2.sensors()[0]._ptr
+    ptr = lambda o: getattr(o._ptr, "value", o._ptr)
+    assert ptr(sen._resolve()) == ptr(scene2.sensors()[0]) != ptr(scene.sensors()[0])
