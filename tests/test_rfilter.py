@@ -333,3 +333,38 @@ def test_adc_with_a_wide_filter(hiplib, oracle, kind, f_bins, iq):
         _hist_close(hg, ho, lp.n_paths, float(np.abs(ro["L"]).max()))
     cells = hg.reshape(f_bins, 64, 3)
     assert (cells[:, :, 2] != 0).sum() > 8 and not np.array_equal(cells[:, :, 2], np.round(cells[:, :, 2]))
+
+
+@pytest.mark.gpu
+def test_batched_and_rolling_batched_renders_with_a_wide_filter(hiplib, oracle):
+    """The filtered put re-derives a path's film position from ITS render's seed: batched launches (one launch sequence for
+    several renders, per-render seeds) and rolling batches must agree with stand-alone oracle renders of those seeds."""
+    import torch
+    from tests.oracle_lib import OracleScene
+    sd, lp = scenes.trans_rad(spp=3000)
+    lp.mode, lp.bins, lp.bin_width = capi.BF_MODE_RANGE, 48, 0.25
+    sd.sensor.rfilter = _host_filter("gaussian", stddev=0.8).flatten(32)
+    sd.finalize()
+    seeds = [11, 12, 13, 14]
+    o = OracleScene(sd)
+    want = []
+    for sdd in seeds:
+        lp.seed = sdd
+        want.append(o.render(lp, records=True, threads=8))
+    g = capi.Scene(sd)
+    lp.seed = 0
+    hist, rec, st = g.render_batch(lp, len(seeds), seeds=seeds, records=True)
+    assert st.kernel_variant == capi.BF_VARIANT_WIDE
+    for k in range(len(seeds)):
+        _records_equal(rec[k], want[k][1])
+        _hist_close(hist[k], want[k][0], lp.n_paths, float(np.abs(want[k][1]["L"]).max()))
+    # the same four renders as two rolling batch calls of two
+    dev = torch.zeros((4, hist.shape[1]), dtype=torch.float32, device="cuda")
+    lp.flags = capi.BF_FLAG_ROLLING
+    for c in range(2):
+        g.render_batch_device(lp, 2, dev[2 * c].data_ptr(), seeds=seeds[2 * c: 2 * c + 2])
+    g.flush()
+    g.sync()
+    got = dev.cpu().numpy()
+    for k in range(len(seeds)):
+        _hist_close(got[k], want[k][0], lp.n_paths, float(np.abs(want[k][1]["L"]).max()))
