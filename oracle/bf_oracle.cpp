@@ -40,6 +40,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <xmmintrin.h>
+#endif
 
 namespace {
 
@@ -2307,8 +2310,18 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
     std::vector<bf_stats> th_stats(n_threads);
     for (auto &t : th_stats) std::memset(&t, 0, sizeof(t));
     auto t0 = std::chrono::steady_clock::now();
+    // The reference renders with denormals flushed (render(): `scoped_flush_denormals flush_denormals(true)`, integrator.cpp:136 —
+    // MXCSR FTZ + DAZ for the worker thread; the live branch of receive() does not, :556 is commented out).  This restatement and
+    // the kernels keep IEEE gradual underflow; BFO_FLUSH_DENORMALS=1 makes the render modes of THIS checker flush like the
+    // reference, so that tests/test_oracle_known_answers.py can show what the difference amounts to.
+    const char *ftz_env = std::getenv("BFO_FLUSH_DENORMALS");
+    const bool flush_denormals = !is_receive && ftz_env && ftz_env[0] == '1';
     auto work = [&](int tid) {
         uint64_t lo = lp->n_paths * tid / n_threads, hi = lp->n_paths * (tid + 1) / n_threads;
+#if defined(__SSE2__)
+        const unsigned csr = _mm_getcsr();
+        if (flush_denormals) _mm_setcsr(csr | 0x8040u);        // FTZ (bit 15) | DAZ (bit 6)
+#endif
         t_nodes = 0;
         t_tris = 0;
         Sampler smp;
@@ -2335,6 +2348,9 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
                 records_out[i].n_rays = o.pr.n_closest + o.pr.n_shadow;
             }
         }
+#if defined(__SSE2__)
+        _mm_setcsr(csr);
+#endif
     };
     if (n_threads == 1)
         work(0);
@@ -2566,6 +2582,20 @@ int bfo_imageblock_put_filtered(const bf_rfilter *f, double *data, uint32_t w, u
         for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) (value[k] * weight);
     });
     return 1;
+}
+/* What BFO_FLUSH_DENORMALS switches on for the render modes (bfo_render): the product of two small floats, computed in a thread
+ * with the reference's denormal mode (flush = 1: MXCSR FTZ | DAZ, scoped_flush_denormals) or with gradual underflow (0). */
+float bfo_denormal_probe(int flush, float a, float b) {
+    volatile float x = a, y = b, r = 0.f;
+#if defined(__SSE2__)
+    const unsigned csr = _mm_getcsr();
+    if (flush) _mm_setcsr(csr | 0x8040u);
+    r = x * y;
+    _mm_setcsr(csr);
+#else
+    r = x * y;
+#endif
+    return r;
 }
 /* MicrofacetDistribution unit access (golden vectors of src/librender/tests/test_microfacet.py).
  * op: 0 eval(m), 1 pdf(wi, m), 2 smith_g1(v = m argument, m = wi argument), 3 sample(wi, (s0, s1)) -> out[0..2] = m,
