@@ -368,3 +368,49 @@ def test_batched_and_rolling_batched_renders_with_a_wide_filter(hiplib, oracle):
     got = dev.cpu().numpy()
     for k in range(len(seeds)):
         _hist_close(got[k], want[k][0], lp.n_paths, float(np.abs(want[k][1]["L"]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_filters_films_and_modes(hiplib, oracle, seed):
+    """Random filter (kind, parameters, block size) x film (1 x 1 ... 13 x 9) x mode (path / range / time) x launch form (plain,
+    one-kernel, global atomics, two path_offset shards) on the zoo scene: records per path and the filtered histograms against the
+    oracle."""
+    from tests.test_gpu_parity import _zoo_scene
+    from tests.oracle_lib import OracleScene
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["gaussian", "tent", "mitchell", "catmullrom", "lanczos", "box"][seed % 6]
+    props = {"gaussian": {"stddev": float(rng.uniform(0.3, 1.4))}, "tent": {}, "mitchell": {"B": float(rng.uniform(0, 1)), "C": float(rng.uniform(0, 1))},
+             "catmullrom": {}, "lanczos": {"lobes": int(rng.integers(1, 5))}, "box": {"radius": float(rng.uniform(0.55, 2.2))}}[kind]
+    film = (int(rng.integers(1, 14)), int(rng.integers(1, 10))) if seed % 4 else (1, 1)
+    mode = [capi.BF_MODE_RANGE, capi.BF_MODE_PATH, capi.BF_MODE_TIME][seed % 3]
+    block = int(rng.choice([0, 1, 2, 5, 32]))
+    sd, _ = _zoo_scene(two_emitters=bool(seed & 1))
+    T = Transform4f
+    sd.set_perspective(T.translate([0, 0, 0.3]) * T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90), fov=float(rng.uniform(30, 80)), near_clip=0.1,
+                       far_clip=100.0, film=film)
+    sd.sensor.rfilter = _host_filter(kind, **props).flatten(block)
+    sd.finalize()
+    spp = int(rng.integers(40, 200)) if film != (1, 1) else 6000
+    bins = int(rng.integers(8, 70))
+    kw = dict(seed=int(rng.integers(1, 1 << 30)), bins=bins, bin_width=0.2 if mode == capi.BF_MODE_RANGE else 1e-9, color_mode=int(rng.integers(0, 2)))
+    if film != (1, 1):
+        kw.update(film=film, spp=spp)
+    n = film[0] * film[1] * spp
+    lp = capi.make_launch(mode, n, **kw)
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
+    g = capi.Scene(sd)
+    amax = float(np.abs(ro["L"]).max())
+    for flags in (0, capi.BF_FLAG_MEGAKERNEL, capi.BF_FLAG_GLOBAL_ATOMICS):
+        lp.flags = flags
+        hg, rg, sg = g.render(lp, records=True)
+        _records_equal(rg, ro)
+        assert sg.n_invalid == so.n_invalid and (sg.kernel_variant == capi.BF_VARIANT_WIDE or flags == capi.BF_FLAG_MEGAKERNEL)
+        _hist_close(hg, ho, max(spp, 64) * 16, amax)
+    lp.flags = 0
+    half = n // 2 + 3
+    parts = []
+    for off, cnt in ((0, half), (half, n - half)):
+        l2 = capi.make_launch(mode, cnt, path_offset=off, **kw)
+        parts.append(g.render(l2)[0])
+    _hist_close(parts[0] + parts[1], ho, max(spp, 64) * 16, amax)
