@@ -186,6 +186,7 @@ struct bf_scene {
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     mutable uint32_t last_variant = 0;     // BF_VARIANT_* of the latest render (bf_stats.kernel_variant)
     uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
+    uint32_t adc_t = 0, adc_f = 0;         // what a receive-mode launch bins into: the ADC's window, or the whole ADC
     float4 *tris0 = nullptr, *nodes0 = nullptr, *wnodes0 = nullptr;   // pristine geometry, kept once bf_scene_translate_meshes is used
     // device copies of the phased-array element tables: one per emitter (nullptr if none) + the receiver's
     std::vector<bfd::DShape> shapes_host;         // as created: mesh triangles carry their shape's material / emitter index
@@ -400,6 +401,7 @@ struct Flat {
     std::vector<bf::BuildTri> btris;      // filled only when with_meshes
     std::vector<TriMeta> meta;
     bool any_normals = false, any_uvs = false;
+    uint32_t window_t = 0, window_f = 0;      // ADC window size (0: the whole ADC)
     std::vector<bfd::DEmitter> emitters;
     bfd::DSensor sensor;
     uint32_t n_tris = 0;
@@ -607,6 +609,19 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         sen.freq_ext = desc->sensor.freq_ext;
         sen.gain = desc->sensor.gain;
         sen.rx_sig_is_delta = desc->sensor.rx_sig_is_delta;
+        {
+            const bf_sensor &ds = desc->sensor;
+            if (ds.window_t_bins || ds.window_f_bins || ds.window_offset_t || ds.window_offset_f) {      // adc.cpp:80-91
+                if (ds.window_t_bins == 0 || ds.window_f_bins == 0 || (uint64_t) ds.window_offset_t + ds.window_t_bins > ds.t_bins ||
+                    (uint64_t) ds.window_offset_f + ds.window_f_bins > ds.f_bins)
+                    return fail(BF_ERR_INVALID, "Invalid window specification! offset (%u, %u) + window size (%u, %u) vs full size (%u, %u)",
+                                ds.window_offset_t, ds.window_offset_f, ds.window_t_bins, ds.window_f_bins, ds.t_bins, ds.f_bins);
+                sen.win_off_t = ds.window_offset_t;
+                sen.win_off_f = ds.window_offset_f;
+                f.window_t = ds.window_t_bins;
+                f.window_f = ds.window_f_bins;
+            }
+        }
         if (desc->sensor.type == BF_RECEIVER_PHASED) {
             if (!desc->sensor.array.velems || desc->sensor.array.n_velems == 0)
                 return fail(BF_ERR_INVALID, "phased receiver without array elements");
@@ -697,6 +712,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     }
     sc->sensor_host = flat.sensor;
     sc->film_w = desc->sensor.film_width;
+    sc->adc_t = flat.window_t ? flat.window_t : flat.sensor.t_bins;
+    sc->adc_f = flat.window_f ? flat.window_f : flat.sensor.f_bins;
     sc->film_h = desc->sensor.film_height;
     sc->origin_scale_built = origin_scale;
     bf::BVH bvh;
@@ -920,6 +937,8 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
     }
     scene->sensor_host = f.sensor;
     scene->film_w = desc->sensor.film_width;
+    scene->adc_t = f.window_t ? f.window_t : f.sensor.t_bins;
+    scene->adc_f = f.window_f ? f.window_f : f.sensor.f_bins;
     scene->film_h = desc->sensor.film_height;
     scene->emitter_types.clear();
     for (const auto &e : f.emitters) scene->emitter_types.push_back(e.type);
@@ -1030,6 +1049,8 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     sc->n_materials = src->n_materials;
     sc->sensor_host = src->sensor_host;
     sc->film_w = src->film_w;
+    sc->adc_t = src->adc_t;
+    sc->adc_f = src->adc_f;
     sc->film_h = src->film_h;
     sc->shapes_host = src->shapes_host;
     sc->origin_scale_built = src->origin_scale_built;
@@ -1740,6 +1761,7 @@ static bool lean_profile(const bf_scene *scene, const bf_launch *launch, bool re
     // lean builds exist of the default register budgets only (three waves per SIMD), and not of the one-kernel variant
     if ((launch->flags & BF_FLAG_MEGAKERNEL) || scene->tun.shade_waves != 3 || scene->tun.tail_waves != 3) return false;
     if (!scene->tun.lean || scene->d.n_emitters != 1 || scene->d.uvs != nullptr || scene->sensor_host.filt_n != 0u) return false;
+    if (scene->sensor_host.win_off_t || scene->sensor_host.win_off_f) return false;      // ADC window away from the origin
     const uint32_t et = scene->emitter_types[0];
     if (receive_mode)
         return (et == BF_TRANSMITTER_AREA || et == BF_TRANSMITTER_WIGNER) && scene->sensor_host.type == BF_RECEIVER_OMNI &&
@@ -1764,9 +1786,9 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     const bool receive_mode = launch->mode == BF_MODE_RECEIVE_RAW || launch->mode == BF_MODE_RECEIVE_IQ;
     if (receive_mode) {
         if (!is_rx) return fail(BF_ERR_INVALID, "receive mode needs a receiver (omnidirectional / wigner)");
-        if (launch->bins != scene->sensor_host.t_bins || launch->bins_y != scene->sensor_host.f_bins)
-            return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size (%u x %u)", launch->bins,
-                        launch->bins_y, scene->sensor_host.t_bins, scene->sensor_host.f_bins);
+        if (launch->bins != scene->adc_t || launch->bins_y != scene->adc_f)
+            return fail(BF_ERR_INVALID, "receive mode: launch bins (%u x %u) must equal the ADC size — its window, if it has one — (%u x %u)",
+                        launch->bins, launch->bins_y, scene->adc_t, scene->adc_f);
         for (uint32_t i = 0; i < scene->d.n_emitters; ++i)
             if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER &&
                 scene->emitter_types[i] != BF_TRANSMITTER_PHASED)

@@ -767,6 +767,7 @@ struct WideSample {
     int offx, offy;           // block offset
     int bw, bh;               // block size (without border)
     int W, H;                 // storage extent in cells
+    int cropx, cropy;         // block coordinate of the storage's first cell (the ADC's window offset; 0 for films)
     uint32_t C;               // channels per cell
     float v0, v1, v2, v3, v4; // base channels (scalars, no indexed array: the hot kernels must stay free of scratch)
     bool five;                // five base channels (render modes) or three (receive modes)
@@ -797,12 +798,12 @@ BF_DEV void put_wide(const DSensor &se, const WideSample &ws, const HistDst &hd)
         const int y = loy + yr;
         if (y > hiy) break;
         const float wy = filt_eval(se, basey + (float) yr);
-        const int gy = ws.offy + y - border;
+        const int gy = ws.offy + y - border - ws.cropy;
         for (int xr = 0; xr < n; ++xr) {
             const int x = lox + xr;
             if (x > hix) break;
             const float w = wy * filt_eval(se, basex + (float) xr);
-            const int gx = ws.offx + x - border;
+            const int gx = ws.offx + x - border - ws.cropx;
             if (gx < 0 || gx >= ws.W || gy < 0 || gy >= ws.H) continue;
             const uint32_t cell = ws.C * ((uint32_t) gy * (uint32_t) ws.W + (uint32_t) gx);
             put_wide_add(hd, cell + 0u, ws.v0, w);
@@ -895,15 +896,21 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
             }
             ok = ok && __builtin_isfinite(pv);
         }
-        float lx = __builtin_ceilf((tf0 - .5f) - .5f), ly = __builtin_ceilf((tf1 - .5f) - .5f);
+        // pos = tf - (m_offset - m_border_size + .5f), lo = ceil(pos - .5f) (signalblock.cpp:115,163): the block sits at the ADC's
+        // window offset (integrator.cpp:627; 0 without a window), the histogram is the window
+        const uint32_t wot = rare<RX>(se.win_off_t != 0u) ? se.win_off_t : 0u, wof = rare<RX>(se.win_off_f != 0u) ? se.win_off_f : 0u;
+        float lx = __builtin_ceilf((tf0 - ((float) wot + .5f)) - .5f), ly = __builtin_ceilf((tf1 - ((float) wof + .5f)) - .5f);
         if (wide) {
             if (ok) {
                 WideSample ws;
                 ws.posx = tf0;
                 ws.posy = tf1;
-                ws.offx = ws.offy = 0;                       // receive(): ONE block of the ADC's size (integrator.cpp:624-627)
+                ws.offx = (int) wot;                         // receive(): ONE block, the ADC's window (integrator.cpp:624-628)
+                ws.offy = (int) wof;
                 ws.bw = ws.W = (int) lp.bins;
                 ws.bh = ws.H = (int) lp.bins_y;
+                ws.cropx = (int) wot;
+                ws.cropy = (int) wof;
                 ws.C = 3u + P;
                 ws.v0 = a0;
                 ws.v1 = a1;
@@ -977,6 +984,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 ws.offy = B ? (int) (qy / B * B) : 0;
                 ws.W = (int) lp.film_w;
                 ws.H = (int) lp.film_h;
+                ws.cropx = ws.cropy = 0;
                 ws.bw = B ? min((int) B, ws.W - ws.offx) : ws.W;
                 ws.bh = B ? min((int) B, ws.H - ws.offy) : ws.H;
                 ws.C = lp.chan_px;

@@ -84,8 +84,8 @@ int main(int argc, char **argv) {
             Receiver *r = scene->receivers()[endpoint_i].get();
             in->receive(scene, r);
             data = r->adc()->bitmap().data();
-            rows = r->adc()->f_bins();
-            cols = r->adc()->t_bins();
+            rows = r->adc()->window_f_bins();
+            cols = r->adc()->window_t_bins();
             ch = (unsigned) r->adc()->channels().size();
             names = &r->adc()->channels();
         } else {

@@ -172,8 +172,8 @@ int bfh_bitmap(void *endpoint, const float **data, unsigned *rows, unsigned *col
         } else if (auto *re = dynamic_cast<Receiver *>((Object *) endpoint)) {
             ADC *a = re->adc();
             *data = a->bitmap().data();
-            *rows = a->f_bins();
-            *cols = a->t_bins();
+            *rows = a->window_f_bins();
+            *cols = a->window_t_bins();
             *channels = (unsigned) a->channels().size();
         } else {
             Throw("object is neither a Sensor nor a Receiver");

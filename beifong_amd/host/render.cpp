@@ -186,15 +186,22 @@ void Film::develop() const {
 }
 void ADC::develop() const {
     if (m_channels.empty()) Throw("develop(): nothing has been received yet");
-    write_exr(exr_path(m_dest), m_t_bins, m_f_bins, m_channels, m_storage.data());
+    write_exr(exr_path(m_dest), m_window_t, m_window_f, m_channels, m_storage.data());
 }
 
 ADC::ADC(const Properties &props) {
     m_t_bins = (uint32_t) props.int_("t_bins", 1024);           // adc.cpp:9-13
     m_f_bins = (uint32_t) props.int_("f_bins", 1024);
-    if (props.int_("window_t_bins", m_t_bins) != (int64_t) m_t_bins || props.int_("window_f_bins", m_f_bins) != (int64_t) m_f_bins ||
-        props.int_("window_offset_t", 0) != 0 || props.int_("window_offset_f", 0) != 0)
-        Throw("ADC: crop windows are not supported");
+    // window, in bins; by default the full ADC (adc.cpp:26-38, set_window :80-91)
+    const int64_t wt = props.int_("window_t_bins", m_t_bins), wf = props.int_("window_f_bins", m_f_bins);
+    const int64_t ot = props.int_("window_offset_t", 0), of = props.int_("window_offset_f", 0);
+    if (ot < 0 || of < 0 || wt <= 0 || wf <= 0 || ot + wt > (int64_t) m_t_bins || of + wf > (int64_t) m_f_bins)
+        Throw("Invalid window specification!\noffset [%lld, %lld] + window size [%lld, %lld] vs full size [%u, %u]", (long long) ot, (long long) of,
+              (long long) wt, (long long) wf, m_t_bins, m_f_bins);
+    m_window_t = (uint32_t) wt;
+    m_window_f = (uint32_t) wf;
+    m_window_offset_t = (uint32_t) ot;
+    m_window_offset_f = (uint32_t) of;
     m_t_bandwidth = props.float_("t_bandwidth", 3.81e-6f);      // adc.cpp:27-29
     m_f_bandwidth = props.float_("f_bandwidth", 250e6f);
     (void) props.bool_("high_quality_edges", false);
@@ -202,7 +209,7 @@ ADC::ADC(const Properties &props) {
 }
 void ADC::prepare(const std::vector<std::string> &channels) {
     m_channels = channels;
-    m_storage.assign((size_t) m_t_bins * m_f_bins * channels.size(), 0.f);
+    m_storage.assign((size_t) m_window_t * m_window_f * channels.size(), 0.f);      // HDRADC::prepare: SignalBlock(m_window_size) (hdradc.cpp:166)
 }
 void ADC::put(const float *data, size_t n) {
     if (n != m_storage.size()) Throw("ADC::put(): mismatched block size");
@@ -486,6 +493,12 @@ void Scene::flatten(const Endpoint *endpoint) {
     } else if (auto *re = dynamic_cast<const Receiver *>(endpoint)) {
         re->flatten(sen, sen.shape);
         sen.rfilter = re->adc()->reconstruction_filter()->flatten(0);      // receive(): one block of the ADC's size
+        if (re->adc()->window_t_bins() != re->adc()->t_bins() || re->adc()->window_f_bins() != re->adc()->f_bins()) {
+            sen.window_t_bins = re->adc()->window_t_bins();
+            sen.window_f_bins = re->adc()->window_f_bins();
+            sen.window_offset_t = re->adc()->window_offset_t();
+            sen.window_offset_f = re->adc()->window_offset_f();
+        }
     }
     if (!endpoint_found) Throw("Scene: the given sensor / receiver does not belong to this scene");
     // physics constants of the fork at HEAD (spectrum.h:15-40, math.h:40-41)
@@ -631,8 +644,8 @@ void SamplingIntegrator::receive_launch(const Receiver *receiver, bf_launch &lp)
     lp.time_c = 3.0e8f;
     configure(lp);
     if (lp.mode != BF_MODE_RECEIVE_RAW) Throw("this integrator does not implement receive()");
-    lp.bins = receiver->adc()->t_bins();
-    lp.bins_y = receiver->adc()->f_bins();
+    lp.bins = receiver->adc()->window_t_bins();
+    lp.bins_y = receiver->adc()->window_f_bins();
 }
 
 bool SamplingIntegrator::receive(Scene *scene, Receiver *receiver) {

@@ -95,6 +95,11 @@ public:
     explicit ADC(const Properties &props);
     uint32_t t_bins() const { return m_t_bins; }
     uint32_t f_bins() const { return m_f_bins; }
+    /// ADC::window_size / window_offset (adc.h): what receive() bins into and the storage holds
+    uint32_t window_t_bins() const { return m_window_t; }
+    uint32_t window_f_bins() const { return m_window_f; }
+    uint32_t window_offset_t() const { return m_window_offset_t; }
+    uint32_t window_offset_f() const { return m_window_offset_f; }
     float t_bandwidth() const { return m_t_bandwidth; }
     float f_bandwidth() const { return m_f_bandwidth; }
     const ReconstructionFilter *reconstruction_filter() const { return m_filter.get(); }
@@ -109,6 +114,7 @@ public:
 
 protected:
     uint32_t m_t_bins, m_f_bins;
+    uint32_t m_window_t, m_window_f, m_window_offset_t, m_window_offset_f;
     float m_t_bandwidth, m_f_bandwidth;
     ref<ReconstructionFilter> m_filter;
     std::vector<std::string> m_channels;

@@ -181,13 +181,17 @@ typedef struct bf_sensor {
     float shutter_open, shutter_open_time;
     /* receiver / ADC (receiver.cpp:16-62, adc.cpp:18-46)                    */
     float adc_sampling_start, adc_sampling_time;
-    uint32_t t_bins, f_bins;
+    uint32_t t_bins, f_bins;               /* the ADC's FULL size: tf is scaled by size / bandwidth (integrator.cpp:1639)   */
     float t_bandwidth, f_bandwidth;
     float freq_centre, freq_ext, gain;     /* wigner receiver                */
     uint32_t rx_sig_is_delta;  /* wignerreceiver.cpp:258 reads an uninitialised
                                   m_sig_is_delta in raw mode; made explicit  */
     bf_phased_array array;   /* BF_RECEIVER_PHASED                           */
     bf_rfilter rfilter;      /* film->reconstruction_filter() / adc->reconstruction_filter() */
+    /* ADC window (adc.cpp:26-38, set_window :80-91): receive() bins into a SignalBlock of window size at the window's offset
+     * (integrator.cpp:627-628) and the ADC stores just that (hdradc.cpp:166-167): the histogram of a receive-mode launch is
+     * [window_f_bins][window_t_bins][channels] and bf_launch.bins / bins_y name the WINDOW.  All four zero: the whole ADC.      */
+    uint32_t window_offset_t, window_offset_f, window_t_bins, window_f_bins;
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

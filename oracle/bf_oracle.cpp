@@ -2104,8 +2104,11 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
             ok = ok && std::isfinite(aov[k]);
         }
     }
+    // receive(): ONE SignalBlock at the ADC's window (block->set_offset(window_offset), set_size(window_size), integrator.cpp:624-628;
+    // the whole ADC at offset 0 without one), then adc->put(block) into a storage of the same window (hdradc.cpp:166-167): lp.bins /
+    // bins_y are the window's size, the histogram is the window
+    const int wot = (int) s.window_offset_t, wof = (int) s.window_offset_f;
     if (rfilter_wide(s.rfilter)) {
-        // receive(): ONE SignalBlock of the ADC's size at offset 0 (integrator.cpp:624-627), then adc->put(block)
         out.put = ok;
         if (ok) {
             std::vector<float> v(3 + P);
@@ -2113,12 +2116,18 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
             v[1] = a1;
             v[2] = a2;
             for (uint32_t k = 0; k < P; ++k) v[3 + k] = aov[k];
-            storage_put_wide(s.rfilter, hist, lp.bins, lp.bins_y, 3 + P, 0, 0, (int) lp.bins, (int) lp.bins_y, tf0, tf1, v.data());
+            const int border = (int) s.rfilter.border;
+            imageblock_put_wide(s.rfilter, wot, wof, (int) lp.bins, (int) lp.bins_y, tf0, tf1, [&](int x, int y, float weight) {
+                const int gx = x - border, gy = y - border;          // block cell -> window cell
+                if (gx < 0 || gx >= (int) lp.bins || gy < 0 || gy >= (int) lp.bins_y) return;
+                double *dst = hist + (size_t) (3 + P) * ((size_t) gy * lp.bins + (size_t) gx);
+                for (uint32_t k = 0; k < 3 + P; ++k) dst[k] += (double) (v[k] * weight);
+            });
         }
         return out;
     }
     // pos = tf - (offset - border + .5); lo = ceil(pos - .5)
-    float lx = std::ceil((tf0 - .5f) - .5f), ly = std::ceil((tf1 - .5f) - .5f);
+    float lx = std::ceil((tf0 - ((float) wot + .5f)) - .5f), ly = std::ceil((tf1 - ((float) wof + .5f)) - .5f);
     ok = ok && lx >= 0.f && lx < (float) lp.bins && ly >= 0.f && ly < (float) lp.bins_y;
     out.put = ok;
     if (ok) {

@@ -414,3 +414,74 @@ def test_fuzz_filters_films_and_modes(hiplib, oracle, seed):
         l2 = capi.make_launch(mode, cnt, path_offset=off, **kw)
         parts.append(g.render(l2)[0])
     _hist_close(parts[0] + parts[1], ho, max(spp, 64) * 16, amax)
+
+
+WINDOW_XML = """<scene version='2.0.0'>
+    <integrator type='pathtimefrequency'/>
+    <shape type='rectangle'><receiver type='omnidirectional'>
+        <adc type='hdradc'><integer name='t_bins' value='64'/><integer name='f_bins' value='8'/>%s<rfilter type='box'/></adc>
+        <sampler type='independent'><integer name='sample_count' value='4'/></sampler></receiver></shape>
+    <shape type='rectangle'><transform name='to_world'><translate z='3'/></transform>
+        <transmitter type='areatransmitter'><spectrum name='radiance' value='1'/></transmitter></shape>
+</scene>"""
+
+
+def test_adc_window_properties_like_the_reference():
+    """adc.cpp:26-38,80-91 (the fork's ADC; src/films/tests/test_hdrfilm.py:35-72 is the film's twin): window_{t,f}_bins and
+    window_offset_{t,f}; a window that leaves the ADC is an error; the flattened sensor carries it and the launch names the window."""
+    from beifong_amd import mitsuba
+    mitsuba.set_variant("scalar_spectral")
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    win = "<integer name='window_t_bins' value='20'/><integer name='window_f_bins' value='3'/><integer name='window_offset_t' value='7'/><integer name='window_offset_f' value='2'/>"
+    sc = load_string(WINDOW_XML % win)
+    rx = sc.receivers()[0]
+    d = sc.flat_desc(rx).desc.sensor
+    assert (d.t_bins, d.f_bins) == (64, 8)
+    assert (d.window_t_bins, d.window_f_bins, d.window_offset_t, d.window_offset_f) == (20, 3, 7, 2)
+    lp = sc.integrator().launch_for(rx)
+    assert (lp.bins, lp.bins_y) == (20, 3)
+    d0 = load_string(WINDOW_XML % "")
+    s0 = d0.flat_desc(d0.receivers()[0]).desc.sensor
+    assert (s0.window_t_bins, s0.window_f_bins, s0.window_offset_t, s0.window_offset_f) == (0, 0, 0, 0)
+    with pytest.raises(HostError, match="Invalid window specification"):
+        load_string(WINDOW_XML % "<integer name='window_offset_t' value='60'/>")              # 60 + 64 > 64: the size does not adjust
+    load_string(WINDOW_XML % "<integer name='window_offset_t' value='60'/><integer name='window_t_bins' value='4'/>")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["box", "gaussian"])
+def test_adc_window(hiplib, oracle, kind):
+    """receive() into an ADC window (integrator.cpp:624-628): the launch bins into the window, the time / frequency scaling stays
+    the full ADC's.  Against the oracle; and, for the box filter, the window equals that part of the whole ADC's render."""
+    from tests.oracle_lib import OracleScene
+    sd, lp = scenes.bus_receive(n_tris=5000, n_paths=30000, t_bins=64)
+    sd.sensor.f_bins = 8
+    sd.sensor.f_bandwidth = sd.physics.c / (sd.physics.lambda_min_nm * 1e-9)
+    if kind != "box":
+        sd.sensor.rfilter = _host_filter(kind).flatten(0)
+    sd.finalize()
+    lp.bins_y = 8
+    full = capi.Scene(sd).render(lp, records=True)
+    ot, of, wt, wf = 5, 1, 40, 6
+    sd.sensor.window_offset_t, sd.sensor.window_offset_f, sd.sensor.window_t_bins, sd.sensor.window_f_bins = ot, of, wt, wf
+    sd.finalize()
+    g = capi.Scene(sd)
+    with pytest.raises(capi.BeifongError, match="window"):
+        g.render(lp)                                            # the launch still names the whole ADC
+    lp.bins, lp.bins_y = wt, wf
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
+    for flags in (0, capi.BF_FLAG_MEGAKERNEL):
+        lp.flags = flags
+        hg, rg, sg = g.render(lp, records=True)
+        _records_equal(rg, ro)
+        assert sg.n_invalid == so.n_invalid and sg.kernel_variant in (0, capi.BF_VARIANT_WIDE)       # a window off the origin: general kernels
+        _hist_close(hg, ho, lp.n_paths, float(np.abs(ro["L"]).max()))
+    _records_equal(rg, full[1])                                 # the window changes where samples land, not the paths
+    crop = full[0].reshape(8, 64, 3)[of:of + wf, ot:ot + wt]
+    assert np.allclose(hg.reshape(wf, wt, 3), crop, rtol=3e-5, atol=lp.n_paths * 2.0 ** -24 * 4 * max(1.0, float(np.abs(ro["L"]).max())))
+    assert (crop[:, :, 2] != 0).sum() > 5
+    sd.sensor.window_offset_t = 30                              # 30 + 40 > 64
+    sd.finalize()
+    with pytest.raises(capi.BeifongError, match="Invalid window"):
+        capi.Scene(sd)
