@@ -75,7 +75,8 @@ class bf_sensor(C.Structure):
                 ("t_bandwidth", C.c_float), ("f_bandwidth", C.c_float),
                 ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32),
                 ("array", bf_phased_array), ("rfilter", bf_rfilter),
-                ("window_offset_t", C.c_uint32), ("window_offset_f", C.c_uint32), ("window_t_bins", C.c_uint32), ("window_f_bins", C.c_uint32)]
+                ("window_offset_t", C.c_uint32), ("window_offset_f", C.c_uint32), ("window_t_bins", C.c_uint32), ("window_f_bins", C.c_uint32),
+                ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32)]
 
 
 class bf_physics(C.Structure):

@@ -652,6 +652,9 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
             if (rf.border > 64u || !(rf.scale > 0.f)) return fail(BF_ERR_INVALID, "reconstruction filter: border %u, scale %g", rf.border, rf.scale);
         }
     }
+    sen.crop_x = desc->sensor.crop_offset_x;
+    sen.crop_y = desc->sensor.crop_offset_y;
+    if (sen.crop_x > (1u << 20) || sen.crop_y > (1u << 20)) return fail(BF_ERR_INVALID, "film crop offset (%u, %u) out of range", sen.crop_x, sen.crop_y);
     sen.near_clip = desc->sensor.near_clip;
     sen.far_clip = desc->sensor.far_clip;
     sen.shutter_open = desc->sensor.shutter_open;
@@ -1762,6 +1765,7 @@ static bool lean_profile(const bf_scene *scene, const bf_launch *launch, bool re
     if ((launch->flags & BF_FLAG_MEGAKERNEL) || scene->tun.shade_waves != 3 || scene->tun.tail_waves != 3) return false;
     if (!scene->tun.lean || scene->d.n_emitters != 1 || scene->d.uvs != nullptr || scene->sensor_host.filt_n != 0u) return false;
     if (scene->sensor_host.win_off_t || scene->sensor_host.win_off_f) return false;      // ADC window away from the origin
+    if (scene->sensor_host.crop_x || scene->sensor_host.crop_y) return false;            // film crop window away from the origin
     const uint32_t et = scene->emitter_types[0];
     if (receive_mode)
         return (et == BF_TRANSMITTER_AREA || et == BF_TRANSMITTER_WIGNER) && scene->sensor_host.type == BF_RECEIVER_OMNI &&

@@ -96,6 +96,7 @@ struct DSensor {
     uint32_t filt_border, filt_block;
     float filt_radius, filt_scale;
     float filt_tab[32];
+    uint32_t crop_x, crop_y;            // film crop offset (render modes): position sample = (pixel + crop) + next_2d
     uint32_t win_off_t, win_off_f;      // ADC window offset (receive modes; DLaunch::bins / bins_y are the window's size)
 };
 

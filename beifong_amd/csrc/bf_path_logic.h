@@ -469,11 +469,15 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
             px = (uint32_t) (q % lp.film_w);
             py = (uint32_t) (q / lp.film_w);
         }
-        const float posx = (float) px + fx, posy = (float) py + fy;
-        (void) sensor_sample_ray<RX>(sc, posx / (float) lp.film_w, posy / (float) lp.film_h, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt);
-        // ImageBlock::put, box branch (imageblock.cpp:166-172): the sample lands in pixel lo = ceil(pos - .5 - .5),
-        // i.e. the pixel it was drawn in or, when next_2d returned exactly 0, its left / upper neighbour
-        const float lx = __builtin_ceilf((posx - .5f) - .5f), ly = __builtin_ceilf((posy - .5f) - .5f);
+        // film crop window (film.cpp:17-27): pixels are counted inside the crop, positions in the full film
+        const uint32_t cx = rare<RX>(sc.sensor->crop_x != 0u) ? sc.sensor->crop_x : 0u, cy = rare<RX>(sc.sensor->crop_y != 0u) ? sc.sensor->crop_y : 0u;
+        const float posx = (float) (px + cx) + fx, posy = (float) (py + cy) + fy;
+        (void) sensor_sample_ray<RX>(sc, (posx - (float) cx) / (float) lp.film_w, (posy - (float) cy) / (float) lp.film_h, ax, ay, s.ro, s.rd,
+                                     s.rmint, s.rmaxt);
+        // ImageBlock::put, box branch (imageblock.cpp:113,166-172): pos = pos_ - (offset + .5) with the block's offset (the crop's,
+        // plus whole blocks), the sample lands in pixel lo = ceil(pos - .5), i.e. the pixel it was drawn in or, when next_2d
+        // returned exactly 0, its left / upper neighbour
+        const float lx = __builtin_ceilf((posx - ((float) cx + .5f)) - .5f), ly = __builtin_ceilf((posy - ((float) cy + .5f)) - .5f);
         film_ok = lx >= 0.f && lx < (float) lp.film_w && ly >= 0.f && ly < (float) lp.film_h;
         film_left = lx < (float) px;
         film_up = ly < (float) py;
@@ -977,16 +981,18 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 uint32_t qx, qy;
                 float fx, fy;
                 film_position(lp, s, qx, qy, fx, fy);
-                ws.posx = (float) qx + fx;
-                ws.posy = (float) qy + fy;
+                ws.cropx = (int) sc.sensor->crop_x;         // blocks tile the crop window from its offset (spiral.cpp: offset += m_offset)
+                ws.cropy = (int) sc.sensor->crop_y;
+                ws.posx = (float) (qx + (uint32_t) ws.cropx) + fx;
+                ws.posy = (float) (qy + (uint32_t) ws.cropy) + fy;
                 const uint32_t B = sc.sensor->filt_block;
-                ws.offx = B ? (int) (qx / B * B) : 0;
-                ws.offy = B ? (int) (qy / B * B) : 0;
+                const int bx0 = B ? (int) (qx / B * B) : 0, by0 = B ? (int) (qy / B * B) : 0;
+                ws.offx = ws.cropx + bx0;
+                ws.offy = ws.cropy + by0;
                 ws.W = (int) lp.film_w;
                 ws.H = (int) lp.film_h;
-                ws.cropx = ws.cropy = 0;
-                ws.bw = B ? min((int) B, ws.W - ws.offx) : ws.W;
-                ws.bh = B ? min((int) B, ws.H - ws.offy) : ws.H;
+                ws.bw = B ? min((int) B, ws.W - bx0) : ws.W;
+                ws.bh = B ? min((int) B, ws.H - by0) : ws.H;
                 ws.C = lp.chan_px;
                 ws.v0 = X;
                 ws.v1 = Y;

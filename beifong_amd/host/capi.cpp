@@ -65,6 +65,21 @@ int bfh_rfilter_eval(void *obj, float x, int discretized, float *out) {
 }
 int bfh_rfilter_flatten(void *obj, unsigned block_size, bf_rfilter *out) { BFH_TRY(*out = as_rfilter(obj)->flatten(block_size)) }
 
+/* Film::size / crop_size / crop_offset of a sensor's film (film.cpp:10-27): out = full w, h, crop w, h, crop offset x, y */
+int bfh_film_geometry(void *sensor, unsigned *out) {
+    BFH_TRY({
+        auto *se = dynamic_cast<Sensor *>((Object *) sensor);
+        if (!se) Throw("object is not a Sensor");
+        const Film *f = se->film();
+        out[0] = f->full_width();
+        out[1] = f->full_height();
+        out[2] = f->width();
+        out[3] = f->height();
+        out[4] = f->crop_offset_x();
+        out[5] = f->crop_offset_y();
+    })
+}
+
 static Scene *as_scene(void *o) {
     auto *s = dynamic_cast<Scene *>((Object *) o);
     if (!s) Throw("object is not a Scene");

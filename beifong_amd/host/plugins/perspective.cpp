@@ -11,7 +11,7 @@ public:
         if (m_near_clip <= 0.f) Throw("The 'near_clip' parameter must be greater than zero!");
         if (m_near_clip >= m_far_clip) Throw("The 'near_clip' parameter must be smaller than 'far_clip'.");
         // parse_fov — include/mitsuba/render/sensor.h
-        float aspect = m_film->width() / (float) m_film->height();
+        float aspect = m_film->full_width() / (float) m_film->full_height();      // m_film->size(): the full film
         if (props.has_property("fov") && props.has_property("focal_length"))
             Throw("Please specify either a focal length ('focal_length') or a field of view ('fov')!");
         float fov = props.float_("fov", 0.f);
@@ -39,9 +39,11 @@ public:
     void flatten(bf_sensor &s, int32_t) const override {
         s.type = BF_SENSOR_PERSPECTIVE;
         s.shape = -1;
-        // perspective_projection — sensor.h:196-231 (no crop) and its inverse
-        const float aspect = m_film->width() / (float) m_film->height();
-        Transform4f c2s = Transform4f::scale({1.f, 1.f, 1.f}) * Transform4f::translate({0.f, 0.f, 0.f}) *
+        // perspective_projection — sensor.h:196-231 (film size, crop size, crop offset) and its inverse
+        const float fw = (float) m_film->full_width(), fh = (float) m_film->full_height(), aspect = fw / fh;
+        const float rel_w = (float) m_film->width() / fw, rel_h = (float) m_film->height() / fh;
+        const float rel_x = (float) m_film->crop_offset_x() / fw, rel_y = (float) m_film->crop_offset_y() / fh;
+        Transform4f c2s = Transform4f::scale({1.f / rel_w, 1.f / rel_h, 1.f}) * Transform4f::translate({-rel_x, -rel_y, 0.f}) *
                           Transform4f::scale({-0.5f, -0.5f * aspect, 1.f}) * Transform4f::translate({-1.f, -1.f / aspect, 0.f}) *
                           Transform4f::perspective(m_x_fov, m_near_clip, m_far_clip);
         for (int i = 0; i < 16; ++i) {

@@ -98,8 +98,19 @@ static ref<ReconstructionFilter> find_filter(const Properties &props, const char
 }
 
 Film::Film(const Properties &props) {
-    m_width = (uint32_t) props.int_("width", 768);              // film.cpp
-    m_height = (uint32_t) props.int_("height", 576);
+    m_full_width = (uint32_t) props.int_("width", 768);         // film.cpp:10-14
+    m_full_height = (uint32_t) props.int_("height", 576);
+    // crop window, by default the full film (film.cpp:17-27, set_crop_window :54-64: the size does not adjust to the offset)
+    const int64_t ox = props.int_("crop_offset_x", 0), oy = props.int_("crop_offset_y", 0);
+    const int64_t cw = props.int_("crop_width", m_full_width), ch = props.int_("crop_height", m_full_height);
+    if (ox < 0 || oy < 0 || cw <= 0 || ch <= 0 || ox + cw > (int64_t) m_full_width || oy + ch > (int64_t) m_full_height)
+        Throw("Invalid crop window specification!\noffset [%lld, %lld] + crop size [%lld, %lld] vs full size [%u, %u]", (long long) ox, (long long) oy,
+              (long long) cw, (long long) ch, m_full_width, m_full_height);
+    m_width = (uint32_t) cw;
+    m_height = (uint32_t) ch;
+    m_crop_x = (uint32_t) ox;
+    m_crop_y = (uint32_t) oy;
+    m_high_quality_edges = props.bool_("high_quality_edges", false);
     m_filter = find_filter(props, "gaussian");
 }
 void Film::prepare(const std::vector<std::string> &channels) {
@@ -489,6 +500,8 @@ void Scene::flatten(const Endpoint *endpoint) {
         // render() walks the film in blocks of MTS_BLOCK_SIZE (spiral.h:10; integrator.cpp:101-114 halves it while there are
         // fewer blocks than threads — a choice of the machine, not of the scene: the default is what is flattened)
         sen.rfilter = se->film()->reconstruction_filter()->flatten(32);
+        sen.crop_offset_x = se->film()->crop_offset_x();
+        sen.crop_offset_y = se->film()->crop_offset_y();
         endpoint_found = true;
     } else if (auto *re = dynamic_cast<const Receiver *>(endpoint)) {
         re->flatten(sen, sen.shape);

@@ -68,8 +68,15 @@ public:
 class Film : public Object {
 public:
     explicit Film(const Properties &props);
+    /// crop_size(): what is rendered and stored (= size() without a crop window)
     uint32_t width() const { return m_width; }
     uint32_t height() const { return m_height; }
+    /// Film::size() / crop_offset() / has_high_quality_edges() — film.cpp:10-27
+    uint32_t full_width() const { return m_full_width; }
+    uint32_t full_height() const { return m_full_height; }
+    uint32_t crop_offset_x() const { return m_crop_x; }
+    uint32_t crop_offset_y() const { return m_crop_y; }
+    bool has_high_quality_edges() const { return m_high_quality_edges; }
     const ReconstructionFilter *reconstruction_filter() const { return m_filter.get(); }
     /// HDRFilm::prepare / put / bitmap(raw) — hdrfilm.cpp:190-211,251-275
     void prepare(const std::vector<std::string> &channels);
@@ -83,7 +90,8 @@ public:
 
 protected:
     std::string m_dest;
-    uint32_t m_width, m_height;
+    uint32_t m_width, m_height, m_full_width, m_full_height, m_crop_x, m_crop_y;
+    bool m_high_quality_edges = false;
     ref<ReconstructionFilter> m_filter;
     std::vector<std::string> m_channels;
     std::vector<float> m_storage;    // [H][W][C]

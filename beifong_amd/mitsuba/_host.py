@@ -61,6 +61,7 @@ def lib():
     l.bfh_bitmap.argtypes = [vp, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     l.bfh_channel_name.argtypes = [vp, C.c_uint]
     l.bfh_channel_name.restype = cp
+    l.bfh_film_geometry.argtypes = [vp, C.POINTER(C.c_uint)]
     l.bfh_rfilter_eval.argtypes = [vp, C.c_float, C.c_int, C.POINTER(C.c_float)]
     l.bfh_rfilter_flatten.argtypes = [vp, C.c_uint, C.POINTER(capi.bf_rfilter)]
     l.bfh_loaded_plugins.argtypes = [C.c_char_p, C.c_int]
@@ -271,12 +272,26 @@ class _Storage:
             raise RuntimeError("develop(): call set_destination_file() first")
         check(lib().bfh_develop(self._e._ptr, dest.encode()))
 
+    def _geometry(self):
+        if isinstance(self._e, Sensor):
+            g = (C.c_uint * 6)()
+            check(lib().bfh_film_geometry(self._e._ptr, g))
+            return list(g)
+        w, h = self.bitmap().size()              # an ADC: its window is what it stores
+        return [w, h, w, h, 0, 0]
+
     def size(self):
-        b = self.bitmap()
-        return b.size()
+        """Film::size(): the full film (film.cpp:10-14)."""
+        g = self._geometry()
+        return (g[0], g[1])
 
     def crop_size(self):
-        return self.size()
+        g = self._geometry()
+        return (g[2], g[3])
+
+    def crop_offset(self):
+        g = self._geometry()
+        return (g[4], g[5])
 
 
 class Sensor(_Handle):

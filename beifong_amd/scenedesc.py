@@ -121,8 +121,8 @@ def _coordinate_system(n):
     return s, t
 
 
-def perspective_sample_to_camera(fov_x_deg, near, far, aspect=1.0):
-    """m_sample_to_camera for a film of aspect = width / height without crop.
+def perspective_sample_to_camera(fov_x_deg, near, far, aspect=1.0, rel_size=(1.0, 1.0), rel_offset=(0.0, 0.0)):
+    """m_sample_to_camera for a film of aspect = width / height; rel_size / rel_offset: crop size and offset over the film size.
 
     include/mitsuba/render/sensor.h:196-231: camera_to_sample =
     scale(1/rel) * translate(-off) * scale(-.5, -.5*aspect, 1) *
@@ -130,7 +130,8 @@ def perspective_sample_to_camera(fov_x_deg, near, far, aspect=1.0):
     through Transform's analytic inverse composition.
     """
     aspect = float(f32(aspect))
-    t = (Transform4f.scale([1, 1, 1]) * Transform4f.translate([0, 0, 0]) * Transform4f.scale([-0.5, -0.5 * aspect, 1.0]) *
+    t = (Transform4f.scale([1.0 / float(f32(rel_size[0])), 1.0 / float(f32(rel_size[1])), 1]) *
+         Transform4f.translate([-float(f32(rel_offset[0])), -float(f32(rel_offset[1])), 0]) * Transform4f.scale([-0.5, -0.5 * aspect, 1.0]) *
          Transform4f.translate([-1.0, -1.0 / aspect, 0.0]) * Transform4f.perspective(fov_x_deg, near, far))
     return t.inv.copy()
 
@@ -327,13 +328,18 @@ class SceneDesc:
         self.sensor.type, self.sensor.shape = capi.BF_SENSOR_IRRADIANCEMETER, shape
         self.shapes[shape].is_sensor = 1
 
-    def set_perspective(self, to_world, fov=45.0, near_clip=0.01, far_clip=10000.0, film=(1, 1)):
-        """film = (width, height) in pixels; fov is the horizontal field of view (fov_axis "x")."""
+    def set_perspective(self, to_world, fov=45.0, near_clip=0.01, far_clip=10000.0, film=(1, 1), crop=None):
+        """film = (width, height) in pixels; fov is the horizontal field of view (fov_axis "x"); crop = (offset_x, offset_y,
+        width, height): the film's crop window (film.cpp:17-27) — the launch then names the crop size."""
         s = self.sensor
         s.type, s.shape = capi.BF_SENSOR_PERSPECTIVE, -1
-        s.film_width, s.film_height = int(film[0]), int(film[1])
+        ox, oy, cw, ch = crop if crop is not None else (0, 0, int(film[0]), int(film[1]))
+        s.film_width, s.film_height = int(cw), int(ch)
+        s.crop_offset_x, s.crop_offset_y = int(ox), int(oy)
         s.to_world = _m16(to_world.matrix)
-        s.sample_to_camera = _m16(perspective_sample_to_camera(fov, near_clip, far_clip, film[0] / film[1]))
+        fw, fh = f32(film[0]), f32(film[1])
+        s.sample_to_camera = _m16(perspective_sample_to_camera(fov, near_clip, far_clip, film[0] / film[1], (f32(cw) / fw, f32(ch) / fh),
+                                                               (f32(ox) / fw, f32(oy) / fh)))
         s.fov_x_deg, s.near_clip, s.far_clip = fov, near_clip, far_clip
 
     def finalize(self):

@@ -177,7 +177,8 @@ typedef struct bf_sensor {
                                    (perspective.cpp:104-109, sensor.h:196-231) */
     float fov_x_deg;         /* perspective (already resolved to the x axis) */
     float near_clip, far_clip;
-    uint32_t film_width, film_height;     /* hdrfilm size (no crop)          */
+    uint32_t film_width, film_height;     /* the film's CROP size (film.cpp:22-27; = its size without a crop window): what
+                                             the sensor samples, the launch names and the histogram holds               */
     float shutter_open, shutter_open_time;
     /* receiver / ADC (receiver.cpp:16-62, adc.cpp:18-46)                    */
     float adc_sampling_start, adc_sampling_time;
@@ -192,6 +193,10 @@ typedef struct bf_sensor {
      * (integrator.cpp:627-628) and the ADC stores just that (hdradc.cpp:166-167): the histogram of a receive-mode launch is
      * [window_f_bins][window_t_bins][channels] and bf_launch.bins / bins_y name the WINDOW.  All four zero: the whole ADC.      */
     uint32_t window_offset_t, window_offset_f, window_t_bins, window_f_bins;
+    /* Film crop window (film.cpp:17-27): the offset of the crop inside the full film.  The position sample of pixel p is
+     * (p + crop_offset) + next_2d and the sensor takes (position - crop_offset) / crop_size (integrator.cpp:263,276-278); a
+     * perspective camera's sample_to_camera already contains the crop (sensor.h:196-231).  Both zero without a crop window.   */
+    uint32_t crop_offset_x, crop_offset_y;
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

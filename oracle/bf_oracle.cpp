@@ -1824,8 +1824,10 @@ static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, 
 // block at offset 0 without border: pos = pos_ - 0.5; lo = ceil(pos - 0.5); the sample is added to pixel lo iff
 // 0 <= lo < size (the validity of the values is checked by the caller, :85-111).  SignalBlock::put is the same code
 // (signalblock.cpp:115,162-169).
-static bool imageblock_put_box(double *data, uint32_t w, uint32_t h, uint32_t nchan, float posx, float posy, const float *value) {
-    int lox = (int) std::ceil((posx - .5f) - .5f), loy = (int) std::ceil((posy - .5f) - .5f);
+static bool imageblock_put_box(double *data, uint32_t w, uint32_t h, uint32_t nchan, float posx, float posy, const float *value, int offx = 0,
+                               int offy = 0) {
+    // pos = pos_ - (m_offset - m_border_size + .5f) with border 0; lo = ceil(pos - .5f)
+    int lox = (int) std::ceil((posx - ((float) offx + .5f)) - .5f), loy = (int) std::ceil((posy - ((float) offy + .5f)) - .5f);
     if (!(lox >= 0 && lox < (int) w && loy >= 0 && loy < (int) h)) return false;
     double *dst = data + (size_t) nchan * ((size_t) loy * w + (size_t) lox);
     for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) value[k];
@@ -1918,19 +1920,8 @@ static void imageblock_put_wide(const bf_rfilter &f, int offx, int offy, int bw,
         }
     }
 }
-// the block is added to the film / ADC storage (ImageBlock::put(block), imageblock.cpp:56-74: accumulate_2d clips what
-// lies outside the w x h storage); `value[k] * weight` in float as imageblock.cpp:160, summed in double like every
-// histogram of this file
-static void storage_put_wide(const bf_rfilter &f, double *data, uint32_t w, uint32_t h, uint32_t nchan, int offx, int offy, int bw, int bh,
-                             float posx, float posy, const float *value) {
-    const int border = (int) f.border;
-    imageblock_put_wide(f, offx, offy, bw, bh, posx, posy, [&](int x, int y, float weight) {
-        int gx = offx + x - border, gy = offy + y - border;
-        if (gx < 0 || gx >= (int) w || gy < 0 || gy >= (int) h) return;
-        double *dst = data + (size_t) nchan * ((size_t) gy * w + (size_t) gx);
-        for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) (value[k] * weight);
-    });
-}
+// (the callers map block cells to the film / ADC storage themselves: ImageBlock::put(block), imageblock.cpp:56-74 —
+// accumulate_2d clips what lies outside; `value[k] * weight` in float as imageblock.cpp:160, summed in double)
 
 // ---------------------------------------------------------------------------
 // film: SamplingIntegrator::render_sample (integrator.cpp:259-310) +
@@ -1988,7 +1979,9 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     }
     float fx, fy;
     smp.next_2d(fx, fy);                                    // :263 position_sample = pos + next_2d
-    const float posx = (float) px + fx, posy = (float) py + fy;
+    // pos = block offset + pixel, the blocks tile the film's CROP window from its offset (spiral.cpp:47-49: offset += m_offset)
+    const uint32_t cx = sc.sensor.crop_offset_x, cy = sc.sensor.crop_offset_y;
+    const float posx = (float) (px + cx) + fx, posy = (float) (py + cy) + fy;
     float ax = .5f, ay = .5f;
     if (sensor_needs_aperture_sample(sc.sensor)) smp.next_2d(ax, ay);   // :265-267
     float time = sc.sensor.shutter_open;
@@ -1996,7 +1989,7 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
     float wl = smp.next_1d();                               // :273
     // adjusted_position = (position_sample - crop_offset) / crop_size (:276-278), crop_offset = 0
     Ray ray;
-    float w = sensor_sample_ray(sc, time, wl, posx / (float) film_w, posy / (float) film_h, ax, ay, ray);
+    float w = sensor_sample_ray(sc, time, wl, (posx - (float) cx) / (float) film_w, (posy - (float) cy) / (float) film_h, ax, ay, ray);
     out.pr = path_sample(sc, lp, smp, ray);
     float L = w * out.pr.L;
     out.L = L;
@@ -2043,13 +2036,23 @@ static SampleOut render_sample(const OScene &sc, const bf_launch &lp, Sampler &s
         // offset = position * block_size, size = min(block_size, film - offset)); 0 = one block
         const bf_rfilter &f = sc.sensor.rfilter;
         const uint32_t B = f.block_size;
-        const int offx = B ? (int) (px / B * B) : 0, offy = B ? (int) (py / B * B) : 0;
-        const int bw = B ? std::min((int) B, (int) film_w - offx) : (int) film_w, bh = B ? std::min((int) B, (int) film_h - offy) : (int) film_h;
-        if (ok) storage_put_wide(f, hist, film_w, film_h, nchan, offx, offy, bw, bh, posx, posy, aovs.data());
+        const int bx0 = B ? (int) (px / B * B) : 0, by0 = B ? (int) (py / B * B) : 0;
+        const int offx = (int) cx + bx0, offy = (int) cy + by0;
+        const int bw = B ? std::min((int) B, (int) film_w - bx0) : (int) film_w, bh = B ? std::min((int) B, (int) film_h - by0) : (int) film_h;
+        if (ok) {
+            const int border = (int) f.border;
+            imageblock_put_wide(f, offx, offy, bw, bh, posx, posy, [&](int x, int y, float weight) {
+                const int gx = offx + x - border - (int) cx, gy = offy + y - border - (int) cy;      // film->put(block): crop-relative storage
+                if (gx < 0 || gx >= (int) film_w || gy < 0 || gy >= (int) film_h) return;
+                double *dst = hist + (size_t) nchan * ((size_t) gy * film_w + (size_t) gx);
+                for (uint32_t k = 0; k < nchan; ++k) dst[k] += (double) (aovs[k] * weight);
+            });
+        }
         out.put = ok;
         return out;
     }
-    out.put = ok && imageblock_put_box(hist, film_w, film_h, nchan, posx, posy, aovs.data());
+    // box branch: pos = pos_ - (crop offset + .5) for the block at the crop's origin (whole blocks further on shift pos and lo alike)
+    out.put = ok && imageblock_put_box(hist, film_w, film_h, nchan, posx, posy, aovs.data(), (int) cx, (int) cy);
     return out;
 }
 

@@ -485,3 +485,84 @@ def test_adc_window(hiplib, oracle, kind):
     sd.finalize()
     with pytest.raises(capi.BeifongError, match="Invalid window"):
         capi.Scene(sd)
+
+
+CROP_XML = """<scene version='2.0.0'><integrator type='path'/>
+    <sensor type='perspective'><float name='fov' value='50'/>
+        <film type='hdrfilm'><integer name='width' value='32'/><integer name='height' value='21'/>%s<rfilter type='box'/></film>
+        <sampler type='independent'><integer name='sample_count' value='4'/></sampler></sensor>
+    <shape type='rectangle'><emitter type='area'><spectrum name='radiance' value='1'/></emitter></shape></scene>"""
+
+
+def test_film_crop_window_like_the_reference_test():
+    """src/films/tests/test_hdrfilm.py:35-72 (test02_crops): size / crop_size / crop_offset; a crop window that leaves the film
+    is an error because the crop size does not adjust.  And what the crop does to the camera (perspective_projection,
+    sensor.h:196-231): sample (u, v) of the crop is the full film's sample (offset + (u, v) crop_size) / film_size."""
+    from beifong_amd import mitsuba
+    mitsuba.set_variant("scalar_rgb")
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    crop = ("<integer name='crop_width' value='11'/><integer name='crop_height' value='5'/><integer name='crop_offset_x' value='2'/>"
+            "<integer name='crop_offset_y' value='3'/><boolean name='high_quality_edges' value='true'/>")
+    sc = load_string(CROP_XML % crop)
+    film = sc.sensors()[0].film()
+    assert film.size() == (32, 21) and film.crop_size() == (11, 5) and film.crop_offset() == (2, 3)
+    d = sc.flat_desc(sc.sensors()[0]).desc.sensor
+    assert (d.film_width, d.film_height, d.crop_offset_x, d.crop_offset_y) == (11, 5, 2, 3)
+    lp = sc.integrator().launch_for(sc.sensors()[0])
+    assert (lp.film_width, lp.film_height, lp.spp, lp.n_paths) == (11, 5, 4, 11 * 5 * 4)
+    incomplete = "<integer name='crop_offset_x' value='30'/><integer name='crop_offset_y' value='20'/>"
+    with pytest.raises(HostError, match="Invalid crop window"):
+        load_string(CROP_XML % incomplete)
+    sc2 = load_string(CROP_XML % (incomplete + "<integer name='crop_width' value='2'/><integer name='crop_height' value='1'/>"))
+    f2 = sc2.sensors()[0].film()
+    assert f2.size() == (32, 21) and f2.crop_size() == (2, 1) and f2.crop_offset() == (30, 20)
+    # the camera: crop sample -> the same near-plane point as the corresponding full-film sample
+    full = load_string(CROP_XML % "")
+    m_full = np.array(full.flat_desc(full.sensors()[0]).desc.sensor.sample_to_camera[:], dtype=np.float64).reshape(4, 4)
+    m_crop = np.array(d.sample_to_camera[:], dtype=np.float64).reshape(4, 4)
+    for u, v in ((0.0, 0.0), (0.3, 0.8), (1.0, 1.0)):
+        a = m_crop @ np.array([u, v, 0, 1.0])
+        b = m_full @ np.array([(2 + u * 11) / 32, (3 + v * 5) / 21, 0, 1.0])
+        assert np.allclose(a[:3] / a[3], b[:3] / b[3], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,block", [("box", 0), ("gaussian", 32), ("lanczos", 3)])
+def test_film_crop_window(hiplib, oracle, kind, block):
+    """A crop window of a 40 x 30 film through the perspective camera: per-path records and the (filtered) histogram against the
+    oracle, both pipelines; with the box filter every pixel of the crop holds its spp samples."""
+    from tests.test_gpu_parity import _zoo_scene
+    from tests.oracle_lib import OracleScene
+    film, crop, spp, bins = (40, 30), (7, 4, 17, 9), 40, 32
+    sd, _ = _zoo_scene(two_emitters=True)
+    T = Transform4f
+    sd.set_perspective(T.translate([0, 0, 0.3]) * T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90), fov=60.0, near_clip=0.1, far_clip=100.0,
+                       film=film, crop=crop)
+    if kind != "box":
+        sd.sensor.rfilter = _host_filter(kind).flatten(block)
+    sd.finalize()
+    cw, ch = crop[2], crop[3]
+    lp = capi.make_launch(capi.BF_MODE_RANGE, cw * ch * spp, seed=9, bins=bins, bin_width=0.2, color_mode=capi.BF_COLOR_RGB, film=(cw, ch), spp=spp)
+    ho, ro, so = OracleScene(sd).render(lp, records=True, threads=8)
+    g = capi.Scene(sd)
+    for flags in (0, capi.BF_FLAG_MEGAKERNEL, capi.BF_FLAG_GLOBAL_ATOMICS):
+        lp.flags = flags
+        hg, rg, sg = g.render(lp, records=True)
+        _records_equal(rg, ro)
+        assert sg.n_invalid == so.n_invalid and not (sg.kernel_variant & capi.BF_VARIANT_LEAN)
+        _hist_close(hg, ho, spp * 16, float(np.abs(ro["L"]).max()))
+    img = hg.reshape(ch, cw, 5 + bins)
+    if kind == "box":
+        assert np.array_equal(img[:, :, 4], np.full((ch, cw), float(spp)))
+    assert (img[:, :, 5:].sum(axis=2) != 0).mean() > 0.3
+    # the crop shows what that part of the full film shows: the same camera rays, different random numbers
+    sd.set_perspective(T.translate([0, 0, 0.3]) * T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90), fov=60.0, near_clip=0.1, far_clip=100.0,
+                       film=film)
+    sd.sensor.rfilter = capi.bf_rfilter()
+    sd.finalize()
+    lf = capi.make_launch(capi.BF_MODE_RANGE, film[0] * film[1] * spp, seed=10, bins=bins, bin_width=0.2, color_mode=capi.BF_COLOR_RGB, film=film, spp=spp)
+    full = capi.Scene(sd).render(lf)[0].reshape(film[1], film[0], 5 + bins)[crop[1]:crop[1] + ch, crop[0]:crop[0] + cw]
+    if kind == "box":
+        hit_c, hit_f = img[:, :, 3] / spp, full[:, :, 3] / spp                  # alpha: fraction of the pixel's rays that hit something
+        assert np.abs(hit_c - hit_f).mean() < 0.08 and np.corrcoef(hit_c.ravel(), hit_f.ravel())[0, 1] > 0.9
