@@ -33,7 +33,7 @@ class bf_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("twosided", C.c_uint32), ("reflectance", C.c_float),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("distribution", C.c_uint32),
                 ("sample_visible", C.c_uint32), ("eta", C.c_float), ("k", C.c_float),
-                ("has_specular_reflectance", C.c_uint32)]
+                ("has_specular_reflectance", C.c_uint32), ("back_material", C.c_uint32)]
 
 
 class bf_shape(C.Structure):

@@ -183,6 +183,7 @@ struct bf_scene {
     mutable bfd::WF wf;
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
+    bool any_back_material = false;        // some twosided material has a second nested BSDF (general kernels)
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     mutable uint32_t last_variant = 0;     // BF_VARIANT_* of the latest render (bf_stats.kernel_variant)
     uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
@@ -679,6 +680,12 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     *out = nullptr;
     if (desc->n_shapes && !desc->shapes) return fail(BF_ERR_INVALID, "shapes is null");
     if (desc->n_materials == 0 || !desc->materials) return fail(BF_ERR_INVALID, "at least one material is required");
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const uint32_t b = desc->materials[i].back_material;
+        if (b == 0) continue;
+        if (b > desc->n_materials || !desc->materials[i].twosided || !desc->materials[b - 1].twosided || desc->materials[b - 1].back_material != 0)
+            return fail(BF_ERR_INVALID, "material %u: back_material %u must name a twosided table entry without a back side of its own", i, b);
+    }
     if (desc->sensor.film_width == 0 || desc->sensor.film_height == 0)
         return fail(BF_ERR_INVALID, "sensor film is %u x %u", desc->sensor.film_width, desc->sensor.film_height);
     int ndev = 0;
@@ -839,6 +846,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(sensor_vec, sensor);
 #undef UP
     sc->n_materials = desc->n_materials;
+    sc->any_back_material = false;
+    for (uint32_t i = 0; i < desc->n_materials; ++i) sc->any_back_material = sc->any_back_material || desc->materials[i].back_material != 0;
     sc->shapes_host = shapes;
     sc->d.n_tris = (uint32_t) btris.size();
     sc->d.n_rects = (uint32_t) rects.size();
@@ -1050,6 +1059,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     sc->n_cus = src->n_cus;
     sc->emitter_types = src->emitter_types;
     sc->n_materials = src->n_materials;
+    sc->any_back_material = src->any_back_material;
     sc->sensor_host = src->sensor_host;
     sc->film_w = src->film_w;
     sc->adc_t = src->adc_t;
@@ -1766,6 +1776,7 @@ static bool lean_profile(const bf_scene *scene, const bf_launch *launch, bool re
     if (!scene->tun.lean || scene->d.n_emitters != 1 || scene->d.uvs != nullptr || scene->sensor_host.filt_n != 0u) return false;
     if (scene->sensor_host.win_off_t || scene->sensor_host.win_off_f) return false;      // ADC window away from the origin
     if (scene->sensor_host.crop_x || scene->sensor_host.crop_y) return false;            // film crop window away from the origin
+    if (scene->any_back_material) return false;                                            // twosided with two nested BSDFs
     const uint32_t et = scene->emitter_types[0];
     if (receive_mode)
         return (et == BF_TRANSMITTER_AREA || et == BF_TRANSMITTER_WIGNER) && scene->sensor_host.type == BF_RECEIVER_OMNI &&

@@ -635,7 +635,10 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     }
     if (depth >= (uint32_t) lp.max_depth || !active) return false;
 
-    const bf_material &mat = sc.materials[si.material];
+    // TwoSidedBRDF with two nested BSDFs (twosided.cpp:108-178): the second one answers for incident directions below the surface
+    const bf_material *mp = &sc.materials[si.material];
+    if (rare<RX>(mp->back_material != 0u) && si.wi.z < 0.f) mp = &sc.materials[mp->back_material - 1u];
+    const bf_material &mat = *mp;
     ++c_bounces;
     BF_SHADEPROF_STAMP(spf_t2);
     SLP(13, true);                                        // lanes that survive to NEE + BSDF sampling

@@ -448,6 +448,15 @@ void Scene::flatten(const Endpoint *endpoint) {
         if (it == mat_index.end()) {
             mat_index[s->bsdf()] = (uint32_t) fl->materials.size();
             fl->materials.push_back(s->bsdf()->flatten());
+            if (const BSDF *back = s->bsdf()->back()) {
+                // twosided with two nested BSDFs: the back side is a table entry of its own (flipped like any twosided entry)
+                bf_material b = back->flatten();
+                b.twosided = 1;
+                b.back_material = 0;
+                const size_t front = fl->materials.size() - 1;
+                fl->materials.push_back(b);
+                fl->materials[front].back_material = (uint32_t) fl->materials.size();      // index of `b`, plus one
+            }
             it = mat_index.find(s->bsdf());
         }
         bs.material = it->second;

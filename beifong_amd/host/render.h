@@ -62,6 +62,8 @@ class BSDF : public Object {
 public:
     /// flatten into the material table entry (diffuse.cpp, roughconductor.cpp, twosided.cpp)
     virtual bf_material flatten() const = 0;
+    /// TwoSidedBRDF with two nested BSDFs: the one that shades the back side (else null)
+    virtual const BSDF *back() const { return nullptr; }
     const Class *class_() const override;
 };
 

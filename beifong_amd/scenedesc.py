@@ -168,6 +168,12 @@ class SceneDesc:
         self.materials.append(m)
         return len(self.materials) - 1
 
+    def set_back_material(self, front, back):
+        """<bsdf type="twosided"> with TWO nested BSDFs (twosided.cpp:62-92): material `back` shades the back side of `front`."""
+        self.materials[front].twosided = self.materials[back].twosided = 1
+        self.materials[front].back_material = back + 1
+        return front
+
     # ---- shapes ----
     def add_rectangle(self, to_world, material, emitter=-1, is_sensor=False, velocity=None):
         s = capi.bf_shape()

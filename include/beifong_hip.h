@@ -67,6 +67,9 @@ typedef struct bf_material {
     uint32_t sample_visible; /* roughconductor sample_visible (default 1)    */
     float eta, k;            /* conductor complex IOR (defaults 0, 1)        */
     uint32_t has_specular_reflectance;
+    uint32_t back_material;  /* twosided with TWO nested BSDFs (twosided.cpp:62-92: the second one shades the back side):
+                                0 = the same BSDF on both sides; k + 1 = table entry k (itself twosided, back_material 0)
+                                is used when the incident direction is below the surface                            */
 } bf_material;
 
 /* ---------------- shapes ------------------------------------------------- */

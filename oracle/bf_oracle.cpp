@@ -57,6 +57,13 @@ constexpr float kInvSqrtPi = 0.56418958354775628695f;
 constexpr float kEpsilon = 5.9604644775390625e-8f;       // FLT_EPSILON / 2
 constexpr float kRayEpsilon = kEpsilon * 1500.f;
 constexpr float kShadowEpsilon = kRayEpsilon * 10.f;
+
+// TwoSidedBRDF — src/bsdfs/twosided.cpp:62-178: m_brdf[0] answers for wi.z > 0, m_brdf[1] (the same object unless two nested
+// BSDFs were given) for wi.z < 0 with wi and wo mirrored.  A table entry with back_material = k + 1 names entry k for the back.
+static const bf_material &material_for_side(const bf_material *table, uint32_t index, float wi_z) {
+    const bf_material &m = table[index];
+    return (m.back_material != 0u && wi_z < 0.f) ? table[m.back_material - 1u] : m;
+}
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 inline float fmadd(float a, float b, float c) { return std::fmaf(a, b, c); }
@@ -1400,7 +1407,7 @@ static PathResult path_sample(const OScene &sc, const bf_launch &lp, Sampler &sm
         }
         if ((uint32_t) depth >= (uint32_t) lp.max_depth || !active) break;
 
-        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+        const bf_material &mat = material_for_side(sc.materials.data(), sc.shapes[si.shape].material, si.wi.z);
         ++r.n_bounces;
         bool active_e = active && bsdf_smooth(mat);
         if (active_e) {
@@ -1719,7 +1726,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
             throughput *= rcp(q);
         }
         if ((uint32_t) depth >= (uint32_t) lp.max_depth || !active) break;
-        const bf_material &mat = sc.materials[sc.shapes[si.shape].material];
+        const bf_material &mat = material_for_side(sc.materials.data(), sc.shapes[si.shape].material, si.wi.z);
         ++r.n_bounces;
         if (bsdf_smooth(mat)) {
             float sx, sy;
@@ -2608,6 +2615,10 @@ float bfo_denormal_probe(int flush, float a, float b) {
     r = x * y;
 #endif
     return r;
+}
+/* which entry of a material table shades a vertex whose incident direction has the local z component wi_z (TwoSidedBRDF) */
+uint32_t bfo_material_for_side(const bf_material *table, uint32_t index, float wi_z) {
+    return (uint32_t) (&material_for_side(table, index, wi_z) - table);
 }
 /* MicrofacetDistribution unit access (golden vectors of src/librender/tests/test_microfacet.py).
  * op: 0 eval(m), 1 pdf(wi, m), 2 smith_g1(v = m argument, m = wi argument), 3 sample(wi, (s0, s1)) -> out[0..2] = m,

@@ -1208,3 +1208,34 @@ def test_lean_and_general_kernels_agree(hiplib, monkeypatch, case):
         out[lean] = (h1, r1)
     assert np.array_equal(out["1"][1], out["0"][1])
     assert np.allclose(out["1"][0], out["0"][0], rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("receive", [False, True])
+def test_twosided_with_two_nested_bsdfs(hiplib, receive):
+    """<bsdf type="twosided"> with a rough conductor in front and a bright diffuse BSDF behind (twosided.cpp:62-178): a plate in
+    front of the camera that shows it its BACK, and the zoo scene's conductor mesh given a diffuse inside.  Every path against
+    the oracle; and the back side really is the other BSDF (records differ from the same scene with the front BSDF on both sides)."""
+    T = Transform4f
+    out = {}
+    for two in (False, True):
+        sd, lp = _zoo_scene(two_emitters=not receive, receive=receive)
+        front = sd.add_roughconductor(alpha=0.2, twosided=True, specular_reflectance=0.6)
+        # the rectangle's normal is +z; turned to +x it points AWAY from the camera at the origin, which looks along +x
+        sd.add_rectangle(T.translate([2.0, -0.2, 0.9]) * T.rotate([0, 1, 0], 90) * T.scale([1.0, 1.2, 1]), front)
+        if two:
+            sd.set_back_material(front, sd.add_diffuse(reflectance=0.85, twosided=True))
+            for i in range(len(sd.materials)):
+                if sd.materials[i].type == capi.BF_BSDF_ROUGHCONDUCTOR and i != front:
+                    sd.set_back_material(i, sd.add_diffuse(reflectance=0.3, twosided=True))
+        sd.finalize()
+        hg, ho, st = _render_compare(sd, lp)
+        assert st.kernel_variant == 0 or not two            # general kernels: the lean profile has one BSDF per material
+        out[two] = capi.Scene(sd).render(lp, records=True)[1]
+    changed = (out[True]["L"].view(np.uint32) != out[False]["L"].view(np.uint32)).mean()
+    assert changed > 0.003, changed      # the paths that met the plate from behind (the receiver's cosine lobe sees less of it)
+    bad = sd.materials[front].back_material
+    sd.materials[front].back_material = len(sd.materials) + 5
+    sd.finalize()
+    with pytest.raises(capi.BeifongError, match="back_material"):
+        capi.Scene(sd)
+    sd.materials[front].back_material = bad

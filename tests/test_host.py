@@ -655,3 +655,27 @@ def test_load_dict_objects_stand_for_their_instances_in_the_scene(mitsuba):
     scene2 = load_dict(dict(d, integrator={"type": "path", "max_depth": 3}))
     ptr = lambda o: getattr(o._ptr, "value", o._ptr)
     assert ptr(sen._resolve()) == ptr(scene2.sensors()[0]) != ptr(scene.sensors()[0])
+
+
+def test_twosided_with_two_nested_bsdfs_flattens_to_a_front_and_a_back_entry(mitsuba):
+    """src/bsdfs/tests/test_twosided.py:33-41 (test01_create, second half): roughconductor in front, diffuse behind."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    xml = """<scene version='2.0.0'><integrator type='path'/>
+        <sensor type='perspective'><film type='hdrfilm'><integer name='width' value='1'/><integer name='height' value='1'/><rfilter type='box'/></film>
+            <sampler type='independent'><integer name='sample_count' value='4'/></sampler></sensor>
+        <shape type='rectangle'><bsdf type='twosided'><bsdf type='roughconductor'/><bsdf type='diffuse'><spectrum name='reflectance' value='0.9'/></bsdf></bsdf></shape>
+        <shape type='rectangle'><transform name='to_world'><translate z='2'/></transform><bsdf type='twosided'><bsdf type='diffuse'/></bsdf></shape>
+        <shape type='rectangle'><transform name='to_world'><translate z='5'/></transform><emitter type='area'><spectrum name='radiance' value='1'/></emitter></shape>
+    </scene>"""
+    sc = load_string(xml)
+    d = sc.flat_desc(sc.sensors()[0]).desc
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    front = mats[d.shapes[0].material]
+    assert front.type == capi.BF_BSDF_ROUGHCONDUCTOR and front.twosided == 1 and front.back_material != 0
+    back = mats[front.back_material - 1]
+    assert back.type == capi.BF_BSDF_DIFFUSE and back.twosided == 1 and back.back_material == 0 and abs(back.reflectance - 0.9) < 1e-7
+    single = mats[d.shapes[1].material]
+    assert single.type == capi.BF_BSDF_DIFFUSE and single.twosided == 1 and single.back_material == 0
+    with pytest.raises(HostError, match="At most two nested BSDFs"):
+        load_string(xml.replace("<bsdf type='roughconductor'/>", "<bsdf type='roughconductor'/><bsdf type='diffuse'/>"))

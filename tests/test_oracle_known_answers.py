@@ -577,12 +577,19 @@ def test_twosided_components_are_smooth_on_both_sides(oracle):
 
 
 def test_twosided_sample_eval_pdf_over_the_sphere(oracle):
-    # test03_sample_eval_pdf with the same diffuse BSDF on both sides (the engine's two-sided material nests ONE BSDF):
-    # for wi over the sphere (5 x 5 uniform-sphere grid) and 5 x 5 samples: weight * wo.z / pi (sign flipped below the
-    # surface) == eval within 1e-2, sampled pdf == pdf, no NaNs
-    m = _mat(reflectance=0.5, twosided=True)
+    # test03_sample_eval_pdf AS THE REFERENCE WRITES IT (test_twosided.py:62-100): a twosided BSDF with TWO nested diffuse BSDFs,
+    # reflectance 0.1 on the front and 0.9 on the back (bf_material.back_material; TwoSidedBRDF twosided.cpp:108-178).  For wi
+    # over the sphere (5 x 5 uniform-sphere grid) and 5 x 5 samples: weight * wo.z / pi (sign flipped below the surface) == eval
+    # within 1e-2, sampled pdf == pdf, no NaNs — and the weight is the reflectance of the side that was hit
+    table = (capi.bf_material * 2)(_mat(reflectance=0.1, twosided=True), _mat(reflectance=0.9, twosided=True))
+    table[0].back_material = 2
+    oracle.bfo_material_for_side.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+    oracle.bfo_material_for_side.restype = C.c_uint32
+    assert oracle.bfo_material_for_side(table, 0, 0.5) == 0 and oracle.bfo_material_for_side(table, 0, -0.5) == 1
+    assert oracle.bfo_material_for_side(table, 0, 0.0) == 0 and oracle.bfo_material_for_side(table, 1, -0.5) == 1
     n = 5
     checked = 0
+    sides = set()
     for u in range(n):
         for v in range(n):
             s0, s1 = u / (n - 1.0), v / (n - 1.0)
@@ -590,19 +597,22 @@ def test_twosided_sample_eval_pdf_over_the_sphere(oracle):
             r = math.sqrt(max(0.0, 1.0 - z * z))
             wi = np.array([r * math.cos(2 * math.pi * s0), r * math.sin(2 * math.pi * s0), z], np.float32)
             up = wi[2] > 0
+            m = table[oracle.bfo_material_for_side(table, 0, float(wi[2]))]
             for x in range(n):
                 for y in range(n):
                     wo = np.zeros(3, np.float32)
                     pdf = C.c_float()
                     w = oracle.bfo_bsdf_sample(C.byref(m), _ptr(wi), 0.5, x / (n - 1.0), y / (n - 1.0), _ptr(wo), C.byref(pdf))
                     if w > 0:
+                        assert np.isclose(w, 0.1 if up else 0.9, rtol=1e-6)
+                        sides.add(bool(up))
                         s_value = w * wo[2] / math.pi * (1 if up else -1)
                         e_value = oracle.bfo_bsdf_eval(C.byref(m), _ptr(wi), _ptr(wo))
                         p_pdf = oracle.bfo_bsdf_pdf(C.byref(m), _ptr(wi), _ptr(wo))
                         assert abs(s_value - e_value) < 1e-2 and not math.isnan(e_value)
                         assert np.isclose(pdf.value, p_pdf, rtol=1e-6)
                         checked += 1
-    assert checked >= 200          # wi.z == 0 (the equator of the grid) and grazing samples fail, as in the reference
+    assert checked >= 200 and sides == {True, False}      # wi.z == 0 (the equator of the grid) and grazing samples fail, as in the reference
 
 
 def _fresnel_dielectric(cos_theta_i, eta):
