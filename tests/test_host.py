@@ -679,3 +679,27 @@ def test_twosided_with_two_nested_bsdfs_flattens_to_a_front_and_a_back_entry(mit
     assert single.type == capi.BF_BSDF_DIFFUSE and single.twosided == 1 and single.back_material == 0
     with pytest.raises(HostError, match="At most two nested BSDFs"):
         load_string(xml.replace("<bsdf type='roughconductor'/>", "<bsdf type='roughconductor'/><bsdf type='diffuse'/>"))
+
+
+def test_hdrfilm_and_hdradc_constructor_checks(mitsuba):
+    """src/films/tests/test_hdrfilm.py:7-32 (test01_construct): default and given reconstruction filter; component_format "uint8"
+    and pixel_format "brga" are errors (hdrfilm.cpp:100-172).  The fork's hdradc: OpenEXR, luminance only (hdradc.cpp:107-147)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    assert load_string("<film version='2.0.0' type='hdrfilm'></film>") is not None
+    scene = """<scene version='2.0.0'><integrator type='path'/><sensor type='perspective'>%s
+        <sampler type='independent'/></sensor><shape type='rectangle'><emitter type='area'><spectrum name='radiance' value='1'/></emitter></shape></scene>"""
+    sc = load_string(scene % "<film type='hdrfilm'><rfilter type='gaussian'><float name='stddev' value='18.5'/></rfilter></film>")
+    assert sc.flat_desc(sc.sensors()[0]).desc.sensor.rfilter.radius == 4 * 18.5
+    sc = load_string(scene % "<film type='hdrfilm'/>")
+    assert sc.flat_desc(sc.sensors()[0]).desc.sensor.rfilter.radius == 2.0            # the default: gaussian, stddev 0.5
+    for bad in ("<string name='component_format' value='uint8'/>", "<string name='pixel_format' value='brga'/>",
+                "<string name='file_format' value='png'/>"):
+        with pytest.raises(HostError, match="parameter must"):
+            load_string("<film version='2.0.0' type='hdrfilm'>%s</film>" % bad)
+    for ok in ("<string name='pixel_format' value='XYZA'/>", "<string name='component_format' value='float32'/>", "<string name='file_format' value='exr'/>"):
+        load_string("<film version='2.0.0' type='hdrfilm'>%s</film>" % ok)
+    load_string("<adc version='2.0.0' type='hdradc'><string name='component_format' value='uint32'/></adc>")
+    for bad in ("<string name='pixel_format' value='rgb'/>", "<string name='file_format' value='pfm'/>", "<string name='component_format' value='uint8'/>"):
+        with pytest.raises(HostError, match="parameter must"):
+            load_string("<adc version='2.0.0' type='hdradc'>%s</adc>" % bad)
