@@ -508,7 +508,10 @@ void Scene::flatten(const Endpoint *endpoint) {
         se->flatten(sen, sen.shape);
         // render() walks the film in blocks of MTS_BLOCK_SIZE (spiral.h:10; integrator.cpp:101-114 halves it while there are
         // fewer blocks than threads — a choice of the machine, not of the scene: the default is what is flattened)
-        sen.rfilter = se->film()->reconstruction_filter()->flatten(32);
+        uint32_t block = 32;
+        if (auto *si = dynamic_cast<const SamplingIntegrator *>(m_integrator.get()))
+            if (si->block_size()) block = si->block_size();          // the integrator's "block_size" property
+        sen.rfilter = se->film()->reconstruction_filter()->flatten(block);
         sen.crop_offset_x = se->film()->crop_offset_x();
         sen.crop_offset_y = se->film()->crop_offset_y();
         endpoint_found = true;
@@ -599,6 +602,20 @@ static bf_status render_on_gpus(Scene *scene, const Endpoint *endpoint, const bf
 
 // ---- integrator ------------------------------------------------------------------
 SamplingIntegrator::SamplingIntegrator(const Properties &props) : Integrator(props) {
+    // SamplingIntegrator — integrator.cpp:26-43
+    const int64_t bs = props.int_("block_size", 0);
+    if (bs < 0) Throw("\"block_size\" must not be negative");
+    m_block_size = (uint32_t) bs;
+    uint32_t pow2 = 1;
+    while (pow2 < m_block_size) pow2 <<= 1;
+    if (m_block_size > 0 && pow2 != m_block_size) {
+        Log(Warn, "Setting block size from %u to next higher power of two: %u", m_block_size, pow2);
+        m_block_size = pow2;
+    }
+    const int64_t spp_pass = props.int_("samples_per_pass", -1);
+    m_samples_per_pass = spp_pass < 0 ? (size_t) -1 : (size_t) spp_pass;
+    (void) props.float_("timeout", -1.f);            // a render is milliseconds of GPU work: nothing to time out
+    (void) props.bool_("hide_emitters", false);      // read by `direct` / `volpath*` only, never by the radar integrators
     // MonteCarloIntegrator — integrator.cpp:1713-1728
     m_rr_depth = (int) props.int_("rr_depth", 5);
     if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
@@ -625,6 +642,12 @@ bool SamplingIntegrator::render(Scene *scene, Sensor *sensor) {
     std::memset(&lp, 0, sizeof(lp));
     lp.color_mode = color_mode_of_variant();
     lp.n_paths = sensor->sampler()->sample_count();
+    {
+        // integrator.cpp:66-75: passes of samples_per_pass samples; all of them are one launch here
+        const size_t total = sensor->sampler()->sample_count(), per_pass = m_samples_per_pass == (size_t) -1 ? total : std::min(m_samples_per_pass, total);
+        if (per_pass == 0 || total % per_pass != 0)
+            Throw("sample_count (%zu) must be a multiple of samples_per_pass (%zu).", total, per_pass);
+    }
     if (film->width() != 1 || film->height() != 1) {
         // sample_count samples per pixel, pixels row-major (bf_launch.spp)
         if (lp.n_paths > 0xffffffffull) Throw("sample_count %llu is too large", (unsigned long long) lp.n_paths);

@@ -288,6 +288,9 @@ public:
     virtual int rr_depth() const { return m_rr_depth; }
     /// "doppler" (not a reference property, default false = the reference's HEAD): BF_FLAG_DOPPLER for receive()
     virtual bool doppler() const { return m_doppler; }
+    /// SamplingIntegrator properties (integrator.cpp:27-43): edge of the image blocks (0: MTS_BLOCK_SIZE) and samples per pass
+    uint32_t block_size() const { return m_block_size; }
+    size_t samples_per_pass() const { return m_samples_per_pass; }
     /// the bf_launch receive() hands to bf_render for this receiver (receive_type -> flags, ADC -> bins)
     void receive_launch(const Receiver *receiver, bf_launch &launch) const;
     const Class *class_() const override;
@@ -295,6 +298,8 @@ public:
 protected:
     int m_max_depth = -1, m_rr_depth = 5;
     bool m_doppler = false;
+    uint32_t m_block_size = 0;
+    size_t m_samples_per_pass = (size_t) -1;
 };
 
 /// src/librender/scene.cpp:22-120

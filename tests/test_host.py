@@ -703,3 +703,22 @@ def test_hdrfilm_and_hdradc_constructor_checks(mitsuba):
     for bad in ("<string name='pixel_format' value='rgb'/>", "<string name='file_format' value='pfm'/>", "<string name='component_format' value='uint8'/>"):
         with pytest.raises(HostError, match="parameter must"):
             load_string("<adc version='2.0.0' type='hdradc'>%s</adc>" % bad)
+
+
+def test_sampling_integrator_base_properties(mitsuba):
+    """SamplingIntegrator (integrator.cpp:26-43,66-75): block_size (rounded up to a power of two; the blocks a film is rendered
+    in — it reaches the flattened reconstruction filter), samples_per_pass (sample_count must be a multiple), timeout and
+    hide_emitters (accepted: the radar integrators never read the latter, as in the reference)."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    xml = """<scene version='2.0.0'><integrator type='range'><integer name='bins' value='4'/><float name='dr' value='1'/>%s<integrator type='pathlength'/></integrator>
+     <sensor type='perspective'><film type='hdrfilm'><integer name='width' value='4'/><integer name='height' value='4'/></film>
+     <sampler type='independent'><integer name='sample_count' value='12'/></sampler></sensor>
+     <shape type='rectangle'><emitter type='area'><spectrum name='radiance' value='1'/></emitter></shape></scene>"""
+    sc = load_string(xml % "<integer name='block_size' value='5'/><integer name='samples_per_pass' value='4'/><float name='timeout' value='3'/>"
+                           "<boolean name='hide_emitters' value='true'/>")
+    assert sc.flat_desc(sc.sensors()[0]).desc.sensor.rfilter.block_size == 8
+    assert load_string(xml % "").flat_desc(load_string(xml % "").sensors()[0]).desc.sensor.rfilter.block_size == 32
+    bad = load_string(xml % "<integer name='samples_per_pass' value='5'/>")
+    with pytest.raises(HostError, match=r"sample_count \(12\) must be a multiple of samples_per_pass \(5\)"):
+        bad.integrator().render(bad, bad.sensors()[0])
