@@ -796,7 +796,11 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
         wnode_data.assign(32 * (bvh16.nodes.size() + 1), make_float4(0, 0, 0, 0));
         if (!bvh16.nodes.empty()) std::memcpy(wnode_data.data(), bvh16.nodes.data(), bvh16.nodes.size() * sizeof(bf::Node16));
     }
-    std::vector<bf_material> mats(desc->materials, desc->materials + desc->n_materials);
+    std::vector<bfd::DMaterial> mats(desc->n_materials);      // 48-byte device records (bf_device.h: DMaterial)
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        mats[i].m = desc->materials[i];
+        mats[i].pad = 0u;
+    }
 
     (void) hipGetDevice(&sc->device);
     hipDeviceProp_t prop;
@@ -925,7 +929,7 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
     // nothing read after this call returns
     {
         const size_t b_rects = f.rects.size() * sizeof(bfd::DRect), b_shapes = f.shapes.size() * sizeof(bfd::DShape);
-        const size_t b_emit = f.emitters.size() * sizeof(bfd::DEmitter), b_mat = (size_t) desc->n_materials * sizeof(bf_material);
+        const size_t b_emit = f.emitters.size() * sizeof(bfd::DEmitter), b_mat = (size_t) desc->n_materials * sizeof(bfd::DMaterial);
         const size_t b_sensor = sizeof(bfd::DSensor);
         auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
         const size_t o_rects = 0, o_shapes = o_rects + up16(b_rects), o_emit = o_shapes + up16(b_shapes), o_mat = o_emit + up16(b_emit),
@@ -937,7 +941,12 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         if (b_rects) std::memcpy(h + o_rects, f.rects.data(), b_rects);
         if (b_shapes) std::memcpy(h + o_shapes, f.shapes.data(), b_shapes);
         if (b_emit) std::memcpy(h + o_emit, f.emitters.data(), b_emit);
-        if (b_mat) std::memcpy(h + o_mat, desc->materials, b_mat);
+        for (uint32_t i = 0; i < desc->n_materials; ++i) {
+            bfd::DMaterial dm;
+            dm.m = desc->materials[i];
+            dm.pad = 0u;
+            std::memcpy(h + o_mat + (size_t) i * sizeof(dm), &dm, sizeof(dm));
+        }
         std::memcpy(h + o_sensor, &f.sensor, b_sensor);
         if (b_rects) HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, h + o_rects, b_rects, hipMemcpyHostToDevice, stream));
         if (b_shapes) HIP_TRY(hipMemcpyAsync((void *) scene->d.shapes, h + o_shapes, b_shapes, hipMemcpyHostToDevice, stream));
@@ -1097,7 +1106,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     }
     if ((st = dup(src->d.rects, sizeof(bfd::DRect) * src->d.n_rects, (const void **) &sc->d.rects)) != BF_OK) return fail_out(st);
     if ((st = dup(src->d.shapes, sizeof(bfd::DShape) * src->info.n_shapes, (const void **) &sc->d.shapes)) != BF_OK) return fail_out(st);
-    if ((st = dup(src->d.materials, sizeof(bf_material) * src->n_materials, (const void **) &sc->d.materials)) != BF_OK) return fail_out(st);
+    if ((st = dup(src->d.materials, sizeof(bfd::DMaterial) * src->n_materials, (const void **) &sc->d.materials)) != BF_OK) return fail_out(st);
     if ((st = dup(src->d.sensor, sizeof(bfd::DSensor), (const void **) &sc->d.sensor)) != BF_OK) return fail_out(st);
     // emitters carry device pointers to their phased-array tables: duplicate the tables and re-point the records
     std::vector<bfd::DEmitter> em(src->d.n_emitters);

@@ -49,6 +49,13 @@ struct DShape {
     float velocity[12];   // Shape "velocity" transform (shape.cpp:42), 3x4 row-major: BF_FLAG_DOPPLER only
 };
 
+// bf_material padded to 48 bytes: a vertex loads its material as three aligned 16-byte words (bf_device_core.h: load_material)
+struct alignas(16) DMaterial {
+    bf_material m;
+    uint32_t pad;
+};
+static_assert(sizeof(bf_material) == 44 && sizeof(DMaterial) == 48, "load_material reads eleven dwords of a 48-byte record");
+
 struct DEmitter {
     uint32_t type;
     int32_t rect;         // area types: rectangle index
@@ -108,7 +115,7 @@ struct DScene {
     const float4 *uvs;        // 1 float4 per triangle or nullptr
     const DRect *rects;
     const DShape *shapes;
-    const bf_material *materials;
+    const DMaterial *materials;
     const DEmitter *emitters;
     uint32_t n_tris, n_rects, n_emitters, n_nodes;
     int32_t root;             // child reference of the BVH root
@@ -126,6 +133,23 @@ struct DScene {
     uint32_t wrows_log;       // log2 of the most rows a gang may have: 16 * rows * depth stack entries must fit kWideStack
     const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
 };
+
+// The scene's SMALL TABLES (rectangles, shapes, materials, emitters, the sensor record, the rolling ring) are read through
+// constant-address-space pointers: the loads are invariant for the compiler, and one whose address is wave-uniform — the
+// rectangle loop of presolve_ray, the only emitter of the lean profile, the sensor — becomes a scalar load (s_load into
+// SGPRs: scalar cache, no vector-memory instruction, no vmcnt wait).  Through generic pointers every such read inside the
+// persistent loops was a uniform VECTOR load followed by s_waitcnt vmcnt(0) (the kernels store in between, so the compiler
+// could not prove the tables constant): ~50 serialised waits per shaded vertex in wf_shade.
+#define BF_CAS __attribute__((address_space(4)))
+typedef const BF_CAS DRect CRect;
+typedef const BF_CAS DShape CShape;
+typedef const BF_CAS DEmitter CEmitter;
+typedef const BF_CAS DSensor CSensor;
+template <class T> __device__ __forceinline__ const BF_CAS T *as_const(const T *p) { return (const BF_CAS T *) (uintptr_t) p; }
+__device__ __forceinline__ CRect *c_rects(const DScene &sc) { return as_const(sc.rects); }
+__device__ __forceinline__ CShape *c_shapes(const DScene &sc) { return as_const(sc.shapes); }
+__device__ __forceinline__ CEmitter *c_emitters(const DScene &sc) { return as_const(sc.emitters); }
+__device__ __forceinline__ CSensor &c_sensor(const DScene &sc) { return *as_const(sc.sensor); }
 
 // One render of a ROLLING SEQUENCE (bf_render_device with BF_FLAG_ROLLING): what differs between the renders of a
 // sequence.  The sequence is one batched launch whose path supply grows by one render per call: global path index

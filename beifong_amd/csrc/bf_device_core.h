@@ -31,15 +31,23 @@ BF_DEV bool tri_intersect(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, float max
 }
 
 // Rectangle::ray_intersect_preliminary — src/shapes/rectangle.cpp:229-249
-BF_DEV bool rect_intersect(const DRect &rc, V3 o, V3 d, float mint, float maxt, float &t, float &lx, float &ly) {
-    V3 oo = xf_point(rc.to_object, o);
-    V3 dd = xf_vector(rc.to_object, d);
-    float d_rcp_z = rcp(dd.z);
-    t = -oo.z * d_rcp_z;
-    V3 local = fmadd3(dd, t, oo);
-    lx = local.x;
-    ly = local.y;
-    return t >= mint && t <= maxt && __builtin_fabsf(local.x) <= 1.f && __builtin_fabsf(local.y) <= 1.f;
+// The z row of the object-space ray comes first: t = -o.z / d.z places most rays outside [mint, maxt] (every ray that
+// points away from the rectangle's plane), and those never touch the x / y rows (the same operations in the same order as
+// xf_point / xf_vector, so t and the local coordinates are the reference's bit for bit).
+BF_DEV bool rect_intersect(CRect &rc, V3 o, V3 d, float mint, float maxt, float &t, float &lx, float &ly) {
+    const float ooz = fmadd(rc.to_object[10], o.z, fmadd(rc.to_object[9], o.y, fmadd(rc.to_object[8], o.x, rc.to_object[11])));
+    const float ddz = fmadd(rc.to_object[10], d.z, fmadd(rc.to_object[9], d.y, rc.to_object[8] * d.x));
+    float d_rcp_z = rcp(ddz);
+    t = -ooz * d_rcp_z;
+    lx = ly = 0.f;
+    if (!(t >= mint && t <= maxt)) return false;
+    const float oox = fmadd(rc.to_object[2], o.z, fmadd(rc.to_object[1], o.y, fmadd(rc.to_object[0], o.x, rc.to_object[3])));
+    const float ooy = fmadd(rc.to_object[6], o.z, fmadd(rc.to_object[5], o.y, fmadd(rc.to_object[4], o.x, rc.to_object[7])));
+    const float ddx = fmadd(rc.to_object[2], d.z, fmadd(rc.to_object[1], d.y, rc.to_object[0] * d.x));
+    const float ddy = fmadd(rc.to_object[6], d.z, fmadd(rc.to_object[5], d.y, rc.to_object[4] * d.x));
+    lx = fmadd(ddx, t, oox);
+    ly = fmadd(ddy, t, ooy);
+    return __builtin_fabsf(lx) <= 1.f && __builtin_fabsf(ly) <= 1.f;
 }
 
 // Closest-hit tie rule: the reference shrinks ray.maxt and accepts t <= maxt
@@ -214,6 +222,7 @@ BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid,
 constexpr uint32_t kTopStride = 9;
 typedef float bf_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const bf_f4 *lds_f4_ptr;
+typedef const BF_CAS bf_f4 *c_f4_ptr;      // constant address space: a wave-uniform address loads through the scalar cache
 BF_DEV float4 to_float4(bf_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 BF_DEV void load_top_nodes(const float4 *__restrict__ nodes, uint32_t n_top, float4 *top, uint32_t tid, uint32_t n_threads) {
     for (uint32_t i = tid; i < n_top * 7u; i += n_threads) {
@@ -334,7 +343,7 @@ BF_DEV bool traverse_dyn(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     best.slot = 0;
     // analytic rectangles (antennas, target plate, ground): a handful per scene
     for (uint32_t i = 0; i < sc.n_rects; ++i) {
-        const DRect &rc = sc.rects[i];
+        CRect &rc = c_rects(sc)[i];
         float t, lx, ly;
         if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
             if (any) return true;
@@ -401,7 +410,7 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
     bool rect_hit = false;
     if (active) {
         for (uint32_t i = (uint32_t) q; i < sc.n_rects; i += 4u) {
-            const DRect &rc = sc.rects[i];
+            CRect &rc = c_rects(sc)[i];
             float t, lx, ly;
             if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
                 rect_hit = true;
@@ -550,7 +559,7 @@ BF_DEV void traverse_row16(const DScene &sc, uint32_t rlog, bool active, bool an
     bool rect_hit = false;
     if (active) {
         for (uint32_t i = j + 16u * row; i < sc.n_rects; i += 16u * rows) {
-            const DRect &rc = sc.rects[i];
+            CRect &rc = c_rects(sc)[i];
             float t, lx, ly;
             if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
                 rect_hit = true;
@@ -703,7 +712,7 @@ template <bool FULL = false, int V = 0> BF_DEV void make_si(const DScene &sc, V3
     si.t = h.t;
     V3 dp_du;
     if (h.slot < 0) {
-        const DRect &rc = sc.rects[-h.slot - 1];
+        CRect &rc = c_rects(sc)[-h.slot - 1];
         si.shape = rc.shape;
         si.material = rc.material;
         si.emitter = rc.emitter;
@@ -775,6 +784,26 @@ struct Microfacet {
     float au, av;
     bool sample_visible;
 };
+// A shaded vertex reads its material ONCE, whole (three 16-byte loads issued together as soon as the hit's record names it,
+// one wait at the first use) instead of field by field where the BSDF code happens to need one (a dozen dependent
+// round trips per vertex through a per-lane address).  Device table: DMaterial, bf_material padded to 48 bytes.
+BF_DEV bf_material load_material(const DScene &sc, uint32_t index) {
+    const c_f4_ptr mp = (c_f4_ptr) (uintptr_t) (sc.materials + index);
+    const bf_f4 a = mp[0], b = mp[1], c = mp[2];
+    bf_material m;
+    m.type = __float_as_uint(a.x);
+    m.twosided = __float_as_uint(a.y);
+    m.reflectance = a.z;
+    m.alpha_u = a.w;
+    m.alpha_v = b.x;
+    m.distribution = __float_as_uint(b.y);
+    m.sample_visible = __float_as_uint(b.z);
+    m.eta = b.w;
+    m.k = c.x;
+    m.has_specular_reflectance = __float_as_uint(c.y);
+    m.back_material = __float_as_uint(c.z);
+    return m;
+}
 BF_DEV Microfacet mf_make(const bf_material &m) {
     Microfacet d;
     d.type = m.distribution;
@@ -1019,7 +1048,7 @@ struct DirSample {
     bool delta;
 };
 
-BF_DEV float spot_falloff(const DEmitter &e, V3 d) {
+BF_DEV float spot_falloff(CEmitter &e, V3 d) {
     float result = e.radiance;
     V3 local_dir = normalize(d);
     float cos_theta = local_dir.z;
@@ -1027,7 +1056,7 @@ BF_DEV float spot_falloff(const DEmitter &e, V3 d) {
     return (cos_theta <= e.cos_cutoff) ? 0.f : beam_res;
 }
 
-template <int V = 0> BF_DEV float emitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
+template <int V = 0> BF_DEV float emitter_sample_direction(const DScene &sc, CEmitter &e, V3 ref_p, float sx, float sy, DirSample &ds) {
     if (rare<V>(e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT)) {
         V3 p = mk(e.to_world[3], e.to_world[7], e.to_world[11]);
         ds.pdf = 1.f;
@@ -1040,7 +1069,7 @@ template <int V = 0> BF_DEV float emitter_sample_direction(const DScene &sc, con
         V3 local_d = xf_vector(e.to_object, -ds.d);
         return spot_falloff(e, local_d) * (inv_dist * inv_dist);
     } else {
-        const DRect &rc = sc.rects[e.rect];
+        CRect &rc = c_rects(sc)[e.rect];
         V3 p = xf_point(rc.to_world, mk(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
         V3 n = mk(rc.n[0], rc.n[1], rc.n[2]);
         ds.pdf = rc.inv_area;
@@ -1058,9 +1087,9 @@ template <int V = 0> BF_DEV float emitter_sample_direction(const DScene &sc, con
 }
 
 // pdf_emitter_direction for the hit `p_hit` (normal n_hit) seen from `p_ref`
-template <int V = 0> BF_DEV float emitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
+template <int V = 0> BF_DEV float emitter_pdf_direction(const DScene &sc, CEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit) {
     if (rare<V>(e.type == BF_EMITTER_SPOT || e.type == BF_EMITTER_POINT)) return 0.f;
-    const DRect &rc = sc.rects[e.rect];
+    CRect &rc = c_rects(sc)[e.rect];
     V3 d = p_hit - p_ref;
     float dist = norm(d);
     d = d / dist;
@@ -1087,9 +1116,9 @@ BF_DEV void srgb_to_xyz_grey(float l, float &X, float &Y, float &Z) {
 template <int V = 0>
 BF_DEV float sensor_sample_ray(const DScene &sc, float px, float py, float ax, float ay, V3 &o, V3 &d, float &mint,
                                float &maxt) {
-    const DSensor &s = *sc.sensor;
+    CSensor &s = c_sensor(sc);
     if (rare<V>(s.type == BF_SENSOR_FLUXMETER || s.type == BF_SENSOR_IRRADIANCEMETER)) {
-        const DRect &rc = sc.rects[s.rect];
+        CRect &rc = c_rects(sc)[s.rect];
         o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
         V3 local = square_to_cosine_hemisphere(ax, ay);
         Frame f;

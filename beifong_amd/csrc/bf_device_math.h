@@ -274,21 +274,23 @@ BF_DEV V3 to_local(const Frame &f, V3 v) { return mk(dot(v, f.s), dot(v, f.t), d
 BF_DEV V3 to_world(const Frame &f, V3 v) { return f.s * v.x + f.t * v.y + f.n * v.z; }
 
 // 3x4 row-major affine: Transform::transform_affine (include/mitsuba/core/transform.h)
-BF_DEV V3 xf_point(const float *m, V3 p) {
+// (the matrix pointer is a template parameter: the scene's small tables are read through constant-address-space pointers,
+// bf_device.h: BF_CAS)
+template <class M> BF_DEV V3 xf_point(M m, V3 p) {
     V3 r = mk(m[3], m[7], m[11]);
     r = mk(fmadd(m[0], p.x, r.x), fmadd(m[4], p.x, r.y), fmadd(m[8], p.x, r.z));
     r = mk(fmadd(m[1], p.y, r.x), fmadd(m[5], p.y, r.y), fmadd(m[9], p.y, r.z));
     r = mk(fmadd(m[2], p.z, r.x), fmadd(m[6], p.z, r.y), fmadd(m[10], p.z, r.z));
     return r;
 }
-BF_DEV V3 xf_vector(const float *m, V3 v) {
+template <class M> BF_DEV V3 xf_vector(M m, V3 v) {
     V3 r = mk(m[0] * v.x, m[4] * v.x, m[8] * v.x);
     r = mk(fmadd(m[1], v.y, r.x), fmadd(m[5], v.y, r.y), fmadd(m[9], v.y, r.z));
     r = mk(fmadd(m[2], v.z, r.x), fmadd(m[6], v.z, r.y), fmadd(m[10], v.z, r.z));
     return r;
 }
 // 4x4 projective point transform (Transform::operator*(Point))
-BF_DEV V3 xf_point_proj(const float *m, V3 p) {
+template <class M> BF_DEV V3 xf_point_proj(M m, V3 p) {
     float r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void bf_trace_kernel(DScene sc, uint64_t n,
         if (out_prim) out_prim[i] = valid ? h.prim : 0xffffffffu;
         if (out_shape) {
             uint32_t s = 0xffffffffu;
-            if (valid) s = h.slot < 0 ? sc.rects[-h.slot - 1].shape : __float_as_uint(sc.tris[kTriStride * (size_t) h.slot + 1].w);
+            if (valid) s = h.slot < 0 ? c_rects(sc)[-h.slot - 1].shape : __float_as_uint(sc.tris[kTriStride * (size_t) h.slot + 1].w);
             out_shape[i] = s;
         }
         if (out_uv) {

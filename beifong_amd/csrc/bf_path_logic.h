@@ -88,7 +88,7 @@ BF_DEV void store_state(const WF &wf, uint32_t j, bool receive, const PathState 
 // Shape::doppler — src/librender/shape.cpp:375-389 (call sites commented out at the reference's HEAD:
 // pathtimefrequency.cpp:141-144, 180-183): 2 dot(si.wi, m_velocity * Point3f(si.to_local(si.p))) / MTS_C * wavelength
 BF_DEV float shape_doppler(const DScene &sc, const SI &si, float lambda_nm) {
-    V3 q = xf_point(sc.shapes[si.shape].velocity, to_local(si.sh, si.p));
+    V3 q = xf_point(c_shapes(sc)[si.shape].velocity, to_local(si.sh, si.p));
     return 2.f * dot(si.wi, q) / sc.c * lambda_nm;
 }
 // the mesh shift of the path's render (batched launches with moving meshes; off otherwise)
@@ -246,7 +246,7 @@ BF_DEV float fmodulo_j(float a, float b) {
 BF_DEV float wchirp_j(float t, float f, float w, float a) {
     return 2 * a * a * w * tri_j(t / w) * sinc_j(6.28318530717958647692f * f * w * tri_j(t / w));
 }
-BF_DEV float rect_sample_wigner(const DRect &rc, V3 p, V3 d, float lambda_nm) {
+BF_DEV float rect_sample_wigner(CRect &rc, V3 p, V3 d, float lambda_nm) {
     const float kTwoPi = 6.28318530717958647692f;
     V3 fs = mk(rc.s[0], rc.s[1], rc.s[2]), ft = mk(rc.t[0], rc.t[1], rc.t[2]), fn = mk(rc.n[0], rc.n[1], rc.n[2]);
     float wid_x = norm(fs), wid_y = norm(ft);
@@ -263,7 +263,7 @@ BF_DEV float rect_sample_wigner(const DRect &rc, V3 p, V3 d, float lambda_nm) {
 // real part of the sum over the n^2 virtual elements of
 //   W_rect_2D(r, nu, wid) * exp(j 2 pi nu . r') * psi',   r = velem_to_object * p / 2 (only |r.x|, |r.y| <= 0.5),
 //   nu = dir_to_local * d / (lambda 1e-9)
-BF_DEV float phased_sample_wigner(const float *__restrict__ tab, uint32_t n, const float *wid, V3 p, V3 d, float lambda_nm) {
+template <class W> BF_DEV float phased_sample_wigner(const float *__restrict__ tab, uint32_t n, W wid, V3 p, V3 d, float lambda_nm) {
     const float kTwoPi = 6.28318530717958647692f;
     const double inv = 1.0 / ((double) lambda_nm * 1e-9);
     float w_re = 0.f;
@@ -283,7 +283,7 @@ BF_DEV float phased_sample_wigner(const float *__restrict__ tab, uint32_t n, con
     }
     return w_re;
 }
-BF_DEV float tx_eval_signal(const DEmitter &e, float time, float frequency) {
+BF_DEV float tx_eval_signal(CEmitter &e, float time, float frequency) {
     if (e.signal_type == BF_SIGNAL_LINFMCW) {
         float t = fmodulo_j(time, rcp(e.prf));
         float ti = 0 + e.pulse_len / 2;
@@ -300,8 +300,8 @@ BF_DEV float tx_eval_signal(const DEmitter &e, float time, float frequency) {
 BF_DEV float freq_of(float c, float lambda_nm) { return (float) ((double) c * (1.0 / ((double) lambda_nm * 1e-9))); }
 
 // Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
-template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, const DEmitter &e, const SI &si, float si_time, float lambda0) {
-    const DRect &rc = sc.rects[e.rect];
+template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, CEmitter &e, const SI &si, float si_time, float lambda0) {
+    CRect &rc = c_rects(sc)[e.rect];
     if (e.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.radiance * rc.area : 0.f;
     float signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
     if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {
@@ -315,9 +315,9 @@ template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, const DEmit
 }
 // Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
 template <int V = 0>
-BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V3 ref_p, float ref_time, float lambda0,
+BF_DEV float transmitter_sample_direction(const DScene &sc, CEmitter &e, V3 ref_p, float ref_time, float lambda0,
                                           float sx, float sy, DirSample &ds) {
-    const DRect &rc = sc.rects[e.rect];
+    CRect &rc = c_rects(sc)[e.rect];
     V3 p = xf_point(rc.to_world, mk(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
     V3 n = mk(rc.n[0], rc.n[1], rc.n[2]);
     ds.pdf = rc.inv_area;
@@ -352,8 +352,8 @@ BF_DEV float transmitter_sample_direction(const DScene &sc, const DEmitter &e, V
     return active ? signal_power * e.gain * geom_gain * extents : 0.f;
 }
 // Transmitter::pdf_direction — areatransmitter.cpp:167-186, wignertransmitter.cpp:540-577
-template <int V = 0> BF_DEV float transmitter_pdf_direction(const DScene &sc, const DEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit, float lambda0) {
-    const DRect &rc = sc.rects[e.rect];
+template <int V = 0> BF_DEV float transmitter_pdf_direction(const DScene &sc, CEmitter &e, V3 p_ref, V3 p_hit, V3 n_hit, float lambda0) {
+    CRect &rc = c_rects(sc)[e.rect];
     V3 d = p_hit - p_ref;
     float dist = norm(d);
     d = d / dist;
@@ -372,8 +372,8 @@ template <int V = 0> BF_DEV float transmitter_pdf_direction(const DScene &sc, co
 template <int V = 0>
 BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
                                  float &mint, float &maxt, float &lambda0) {
-    const DSensor &s = *sc.sensor;
-    const DRect &rc = sc.rects[s.rect];
+    CSensor &s = c_sensor(sc);
+    CRect &rc = c_rects(sc)[s.rect];
     o = xf_point(rc.to_world, mk(px * 2.f - 1.f, py * 2.f - 1.f, 0.f));
     V3 local = square_to_cosine_hemisphere(ax, ay);
     Frame f;
@@ -444,9 +444,9 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
         // receive_sample — integrator.cpp:1544-1572
         ax = next_1d(s.rng);
         ay = next_1d(s.rng);
-        float time = sc.sensor->adc_sampling_start;
-        if (sc.sensor->adc_sampling_time > 0.f)
-            time += next_1d(s.rng) * sc.sensor->adc_sampling_time;
+        float time = c_sensor(sc).adc_sampling_start;
+        if (c_sensor(sc).adc_sampling_time > 0.f)
+            time += next_1d(s.rng) * c_sensor(sc).adc_sampling_time;
         else
             time = 0.f;
         float wl = next_1d(s.rng);
@@ -456,11 +456,11 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
     } else {
         // render_sample — integrator.cpp:263-283
-        if (rare<RX>(sc.sensor->type != BF_SENSOR_PERSPECTIVE && sc.sensor->type != BF_SENSOR_RADIANCEMETER)) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
+        if (rare<RX>(c_sensor(sc).type != BF_SENSOR_PERSPECTIVE && c_sensor(sc).type != BF_SENSOR_RADIANCEMETER)) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
             ax = next_1d(s.rng);
             ay = next_1d(s.rng);
         }
-        if (sc.sensor->shutter_open_time > 0.f) (void) next_1d(s.rng);
+        if (c_sensor(sc).shutter_open_time > 0.f) (void) next_1d(s.rng);
         (void) next_1d(s.rng);     // wavelength sample (consumed in RGB mode too)
         // position_sample = pos + next_2d; adjusted_position = position_sample / crop_size (integrator.cpp:263,276-278)
         uint32_t px = 0, py = 0;
@@ -470,7 +470,7 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
             py = (uint32_t) (q / lp.film_w);
         }
         // film crop window (film.cpp:17-27): pixels are counted inside the crop, positions in the full film
-        const uint32_t cx = rare<RX>(sc.sensor->crop_x != 0u) ? sc.sensor->crop_x : 0u, cy = rare<RX>(sc.sensor->crop_y != 0u) ? sc.sensor->crop_y : 0u;
+        const uint32_t cx = rare<RX>(c_sensor(sc).crop_x != 0u) ? c_sensor(sc).crop_x : 0u, cy = rare<RX>(c_sensor(sc).crop_y != 0u) ? c_sensor(sc).crop_y : 0u;
         const float posx = (float) (px + cx) + fx, posy = (float) (py + cy) + fy;
         (void) sensor_sample_ray<RX>(sc, (posx - (float) cx) / (float) lp.film_w, (posy - (float) cy) / (float) lp.film_h, ax, ay, s.ro, s.rd,
                                      s.rmint, s.rmaxt);
@@ -565,9 +565,13 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     const bool si_valid = hit.t != BF_INF;
     int emitter = -1;
     SLP(10, si_valid);
+    bf_material mat;
+    mat.type = ~0u;
+    mat.back_material = 0u;
     if (si_valid) {
         make_si<false, RX>(sc, s.ro, s.rd, hit, si, nullptr, path_shift(lp, s.render));
         emitter = si.emitter;
+        mat = load_material(sc, si.material);      // issued here, waited for where NEE / BSDF sampling first read it
     }
 #ifdef BF_TAIL_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -594,7 +598,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         }
         SLP(11, emitter >= 0);
         if (emitter >= 0) {
-            const DEmitter &e = sc.emitters[emitter];
+            CEmitter &e = c_emitters(sc)[(RX & kLean) ? 0 : emitter];      // lean: ONE emitter, a wave-uniform record
             float emitter_pdf = receive ? transmitter_pdf_direction<RX>(sc, e, s.prev_p, si.p, si.sh.n, s.lambda0)
                                         : emitter_pdf_direction<RX>(sc, e, s.prev_p, si.p, si.sh.n);
             if (n_emit != 1) emitter_pdf *= 1.f / (float) n_emit;
@@ -608,7 +612,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     // head of iteration `depth` — path.cpp:121-145
     SLP(12, emitter >= 0);
     if (emitter >= 0) {
-        const DEmitter &e = sc.emitters[emitter];
+        CEmitter &e = c_emitters(sc)[(RX & kLean) ? 0 : emitter];
         if (doppler) s.dlambda += shape_doppler(sc, si, s.lambda0);               // :180-183
         float ev;
         if (receive)
@@ -636,9 +640,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     if (depth >= (uint32_t) lp.max_depth || !active) return false;
 
     // TwoSidedBRDF with two nested BSDFs (twosided.cpp:108-178): the second one answers for incident directions below the surface
-    const bf_material *mp = &sc.materials[si.material];
-    if (rare<RX>(mp->back_material != 0u) && si.wi.z < 0.f) mp = &sc.materials[mp->back_material - 1u];
-    const bf_material &mat = *mp;
+    if (rare<RX>(mat.back_material != 0u) && si.wi.z < 0.f) mat = load_material(sc, mat.back_material - 1u);
     ++c_bounces;
     BF_SHADEPROF_STAMP(spf_t2);
     SLP(13, true);                                        // lanes that survive to NEE + BSDF sampling
@@ -661,7 +663,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
                 index = min((uint32_t) (sx * (float) n_emit), n_emit - 1u);
                 sx = (sx - index * emitter_pdf) * (float) n_emit;
             }
-            const DEmitter &e = sc.emitters[index];
+            CEmitter &e = c_emitters(sc)[index];
             if (receive)
                 emitter_val = transmitter_sample_direction<RX>(sc, e, si.p, s.time, s.lambda0, sx, sy, ds);
             else
@@ -746,8 +748,8 @@ struct HistDst {
 BF_DEV HistDst hist_dst(const DLaunch &lp, uint32_t render, float *s_hist, float *g_hist, bool lds_hist) {
     HistDst h;
     if (lp.roll) {
-        h.g = lp.roll[render & (kRollRing - 1u)].hist;
         h.lds = lds_hist && render >= lp.roll_lo;
+        h.g = h.lds ? nullptr : lp.roll[render & (kRollRing - 1u)].hist;      // (no descriptor fetch for the samples that stay in LDS)
         h.s = s_hist + (h.lds ? (render - lp.roll_lo) * lp.n_chan : 0u);
     } else {
         const uint32_t hb = lp.batch != 0u ? render * lp.n_chan : 0u;
@@ -783,7 +785,7 @@ struct WideSample {
     bool e3;                  // three values per bin (time mode) or one
     float e0, e1, e2;
 };
-BF_DEV float filt_eval(const DSensor &se, float x) {
+BF_DEV float filt_eval(CSensor &se, float x) {
     const int idx = min((int) __builtin_fabsf(x * se.filt_scale), 31);
     return se.filt_tab[idx];
 }
@@ -791,7 +793,7 @@ BF_DEV void put_wide_add(const HistDst &hd, uint32_t idx, float v, float w) {
     const float a = v * w;          // value[k] * weight (imageblock.cpp:160)
     if (a != 0.f) hist_add(hd.s, hd.g, hd.lds, idx, a);
 }
-BF_DEV void put_wide(const DSensor &se, const WideSample &ws, const HistDst &hd) {
+BF_DEV void put_wide(CSensor &se, const WideSample &ws, const HistDst &hd) {
     const int border = (int) se.filt_border, n = (int) se.filt_n;
     const float r = se.filt_radius;
     // pos = pos_ - (m_offset - m_border_size + .5f)
@@ -870,7 +872,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
     constexpr bool wide = (RX & kWide) != 0;       // reconstruction filter wider than a pixel (uniform; the radar scenes use box)
     if (mode_receive<RX>(lp)) {
         // receive_sample tail — integrator.cpp:1625-1665; SignalBlock::put — signalblock.cpp:162-169
-        const DSensor &se = *sc.sensor;
+        CSensor &se = c_sensor(sc);
         float tf0 = s.t_rx - se.adc_sampling_start;
         float tf1 = freq_of(sc.c, rare<RX>(lp.doppler != 0u) ? s.lambda0 + s.dlambda : s.lambda0);
         if (rare<RX>(lp.mix != 0u)) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, s.lambda0));      // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601)
@@ -951,8 +953,8 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         // ray weight: fluxmeter.cpp:84 (wav_weight * pi), irradiancemeter.cpp:82 (wav_weight * pi / surface_area),
         // perspective.cpp:198 (wav_weight)
         float sensor_w = 1.f;
-        if (rare<RX>(sc.sensor->type == BF_SENSOR_FLUXMETER)) sensor_w = 1.f * kPi;
-        if (rare<RX>(sc.sensor->type == BF_SENSOR_IRRADIANCEMETER)) sensor_w = 1.f * kPi / sc.rects[sc.sensor->rect].area;
+        if (rare<RX>(c_sensor(sc).type == BF_SENSOR_FLUXMETER)) sensor_w = 1.f * kPi;
+        if (rare<RX>(c_sensor(sc).type == BF_SENSOR_IRRADIANCEMETER)) sensor_w = 1.f * kPi / c_rects(sc)[c_sensor(sc).rect].area;
         float L = sensor_w * s.result;                        // integrator.cpp:286
         float X, Y, Z;
         if (lp.color_mode == BF_COLOR_RGB)
@@ -984,11 +986,11 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                 uint32_t qx, qy;
                 float fx, fy;
                 film_position(lp, s, qx, qy, fx, fy);
-                ws.cropx = (int) sc.sensor->crop_x;         // blocks tile the crop window from its offset (spiral.cpp: offset += m_offset)
-                ws.cropy = (int) sc.sensor->crop_y;
+                ws.cropx = (int) c_sensor(sc).crop_x;         // blocks tile the crop window from its offset (spiral.cpp: offset += m_offset)
+                ws.cropy = (int) c_sensor(sc).crop_y;
                 ws.posx = (float) (qx + (uint32_t) ws.cropx) + fx;
                 ws.posy = (float) (qy + (uint32_t) ws.cropy) + fy;
-                const uint32_t B = sc.sensor->filt_block;
+                const uint32_t B = c_sensor(sc).filt_block;
                 const int bx0 = B ? (int) (qx / B * B) : 0, by0 = B ? (int) (qy / B * B) : 0;
                 ws.offx = ws.cropx + bx0;
                 ws.offy = ws.cropy + by0;
@@ -1019,7 +1021,7 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
                         if (s.aux >= lo && s.aux < hi) ws.emask |= 1u << (i - (k - 1));
                     }
                 }
-                put_wide(*sc.sensor, ws, hd);
+                put_wide(c_sensor(sc), ws, hd);
             } else {
                 ++acc.invalid;
             }

@@ -58,7 +58,7 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     best.slot = 0;
     found = false;
     for (uint32_t i = 0; i < sc.n_rects; ++i) {
-        const DRect &rc = sc.rects[i];
+        CRect &rc = c_rects(sc)[i];
         float t, lx, ly;
         if (rect_intersect(rc, o, d, mint, maxt, t, lx, ly)) {
             if (any) {
@@ -70,8 +70,10 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
     }
     if (sc.n_tris == 0) return false;
     if (sc.root < 0) return true;                 // the whole mesh is one leaf
-    const float4 *np = sc.nodes + 8u * (uint32_t) sc.root;
-    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], ch = np[6];
+    // the root node's address is wave-uniform: scalar loads (constant address space, bf_device.h: BF_CAS)
+    const c_f4_ptr np = (c_f4_ptr) (uintptr_t) (sc.nodes + 8u * (uint32_t) sc.root);
+    const float4 lx = to_float4(np[0]), ly = to_float4(np[1]), lz = to_float4(np[2]), hx = to_float4(np[3]), hy = to_float4(np[4]),
+                 hz = to_float4(np[5]), ch = to_float4(np[6]);
     V3 id, oid, ohi;
     ray_inverse_shift(o, d, shf, id, oid, ohi);
     float tmax = any ? maxt : __builtin_fminf(maxt, best.t), tn;
