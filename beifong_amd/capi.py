@@ -24,7 +24,7 @@ BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
 BF_COLOR_RGB, BF_COLOR_MONO = range(2)
 BF_FLAG_STATS, BF_FLAG_GLOBAL_ATOMICS, BF_FLAG_MEGAKERNEL, BF_FLAG_DOPPLER, BF_FLAG_MIX_RESAMPLE = 1, 2, 4, 8, 16
-BF_FLAG_ROLLING, BF_FLAG_TIMING = 32, 64
+BF_FLAG_ROLLING, BF_FLAG_TIMING, BF_FLAG_COUNT = 32, 64, 128
 
 M16 = C.c_float * 16
 

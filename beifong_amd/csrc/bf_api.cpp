@@ -15,7 +15,26 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (bf_allreduce_device)
+// RCCL is dlopen'ed on first use (bf_allreduce_device); only the handful of types and prototypes below are needed, so a ROCm
+// install without the RCCL development headers still builds the core (the values are rccl.h's: ncclSuccess 0, ncclFloat32 7,
+// ncclSum 0)
+#if defined(__has_include) && __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <map>
 #include <mutex>
@@ -126,6 +145,8 @@ struct bf_tunables {
     bool no_wide = false, quant = false;
     int wide_rows_log = -1;
     bool lean = true;                        // BF_LEAN=0: never use the kernels' lean variants (bf_device.h: kLean)
+    bool tab_cache = true;                   // BF_TAB_CACHE=0: materials / rectangles stay in device memory (no LDS copies)
+    uint32_t debug_surv_batches = 0;         // BF_DEBUG_SURV_BATCHES (tests): size of the survivor area in batches, sizing rule off
 };
 static bf_tunables read_tunables() {
     bf_tunables t;
@@ -155,6 +176,8 @@ static bf_tunables read_tunables() {
     t.quant = num("BF_QUANT_BVH", 0) != 0;
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
     t.lean = num("BF_LEAN", 1) != 0;
+    t.tab_cache = num("BF_TAB_CACHE", 1) != 0;
+    t.debug_surv_batches = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_DEBUG_SURV_BATCHES", 0), 1 << 14));
     return t;
 }
 
@@ -273,6 +296,17 @@ struct BusyGuard {
         if (ok) s->busy.clear(std::memory_order_release);
     }
 };
+// the handle's device for the calls that allocate or launch before (or without) taking the busy flag
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void) hipSetDevice(prev);
+    }
+};
 #define BF_ENTER(scene)                                                                                                   \
     BusyGuard busy_guard_(scene);                                                                                         \
     if (!busy_guard_.ok)                                                                                                  \
@@ -387,7 +421,8 @@ static bf_status stage_release_after(bf_scene::Stage *st, hipStream_t stream) {
 
 static int32_t bfd_no_node() { return INT32_MIN; }
 static_assert(bf::kTopNodes == bfd::kTopNodes, "the builder's breadth-first prefix is what wf_trace caches");
-static_assert(bfd::CTR_GUARD + 1 == bfd::CTR_COUNT, "the sticky guard word is the last counter: renders clear the ones before it");
+static_assert(bfd::CTR_GUARD + 2 == bfd::CTR_COUNT && bfd::CTR_SURV_GUARD + 1 == bfd::CTR_COUNT,
+              "the two sticky guard words are the last counters: renders clear the ones before them");
 
 namespace {
 struct TriMeta {
@@ -850,6 +885,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     UP(sensor_vec, sensor);
 #undef UP
     sc->n_materials = desc->n_materials;
+    sc->d.n_materials = desc->n_materials;
+    sc->d.tab_cache = (sc->tun.tab_cache && desc->n_materials <= bfd::kTabMaxMaterials && rects.size() <= bfd::kTabMaxRects) ? 1u : 0u;
     sc->any_back_material = false;
     for (uint32_t i = 0; i < desc->n_materials; ++i) sc->any_back_material = sc->any_back_material || desc->materials[i].back_material != 0;
     sc->shapes_host = shapes;
@@ -1292,6 +1329,9 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
         // all the claims of one launch must be distinct batches (wf_shade: surv_take)
         const uint32_t surv_min = (uint32_t) scene->n_cus * 4u * (uint32_t) std::max(2, scene->tun.shade_waves) * 64u;
         n_surv = std::max<uint32_t>(surv_min, std::min<uint32_t>(1u << 21, (n_main / 8 + 63) & ~63u));
+        // test hook (BF_DEBUG_SURV_BATCHES): a survivor area far too small for the claims its waves may make, to see the loud
+        // check of surv_take fire (tests/test_gpu_rolling.py)
+        if (scene->tun.debug_surv_batches) n_surv = scene->tun.debug_surv_batches * 64u;
     }
     bf_status st = wf_ensure(scene, n_main + n_surv);
     if (st != BF_OK) return st;
@@ -1322,7 +1362,7 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.count_nodes = count_nodes;
     c.timed = timed;
     c.mask_bytes = 3 * nb * sizeof(unsigned long long);
-    c.lds_shade = (sizeof(float) * lp.lds_floats + 15) & ~size_t(15);
+    c.lds_shade = ((sizeof(float) * lp.lds_floats + 15) & ~size_t(15)) + (scene->d.tab_cache ? bfd::kTabBytes : 0u);      // histogram | tables
     c.lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + c.lds_shade;
     // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
     // 5 workgroups per CU (28.6 KiB of LDS each: stacks + the tree's top levels; 96 VGPRs)
@@ -1332,6 +1372,10 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) scene->tun.trace_waves, max_blocks));
     c.tail_max = wf_tail_threshold(scene, rolling ? wf.n_main / 2 : wf.n_slots);
     wf.surv_claims_max = (wf.n_surv / 64u) / std::max(1u, c.grid_shade * batches_per_block);      // >= 1 by the sizing above
+    if (rolling && scene->tun.debug_surv_batches) {                                                   // (the test hook: no rule at all)
+        const char *e = getenv("BF_DEBUG_SURV_CLAIMS");
+        wf.surv_claims_max = e ? (uint32_t) strtoul(e, nullptr, 10) : 1u << 20;
+    }
     return BF_OK;
 }
 // One bounce iteration `it`: clear the next parity's masks, shade (first: 0 alive masks, 1 first bounce of a pool, 2 alive
@@ -1384,9 +1428,37 @@ static bf_status wf_tail_launch(const WfCtx &c, uint32_t it, uint32_t est_live, 
     return BF_OK;
 }
 // The guard word of wf_trace (CTR_GUARD) is never cleared by a render, so it is sticky across the renders of a handle.
-static bf_status wf_guard_error(unsigned long long lost) {
-    return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays in an earlier render of this scene: that render's "
-                               "histogram is wrong (a traversal bug; please report the scene)", lost);
+// So is the survivor-area word of rolling sequences (CTR_SURV_GUARD: wf_shade: surv_take refused a claim).
+static bf_status wf_guard_error(unsigned long long lost, unsigned long long refused = 0) {
+    if (lost)
+        return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays in an earlier render of this scene: that render's "
+                                   "histogram is wrong (a traversal bug; please report the scene)", lost);
+    return fail(BF_ERR_DEVICE, "a launch of a rolling sequence of this scene tried to claim %llu survivor batches beyond the size of "
+                               "its survivor area (the claims were refused: no path was lost, but the sizing rule of wf_setup is "
+                               "violated; please report the scene and the launch)", refused);
+}
+// every path of a completed render / sequence was binned exactly once (CTR_FILM counts film_put calls): the loud form of the
+// tests' "sum of the weight channel + invalid samples == paths"
+static bf_status check_film_count(const unsigned long long *c, uint64_t n_paths) {
+#ifdef BF_NO_FILM_CTR      // developer A/B build without the counter
+    return BF_OK;
+#endif
+    if (c[bfd::CTR_FILM] != n_paths)
+        return fail(BF_ERR_DEVICE, "%llu of %llu paths were binned: paths were lost or binned twice (a scheduling bug; please report the "
+                                   "scene and the launch)", (unsigned long long) c[bfd::CTR_FILM], (unsigned long long) n_paths);
+    return BF_OK;
+}
+// read + clear the sticky words of a handle whose work has completed; *lost / *refused as found
+static bf_status read_guards(const bf_scene *scene, unsigned long long *lost, unsigned long long *refused) {
+    unsigned long long g[2] = {0, 0};
+    HIP_TRY(hipMemcpy(g, scene->counters + bfd::CTR_GUARD, sizeof(g), hipMemcpyDeviceToHost));
+    if (g[0] || g[1]) {
+        HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(g)));
+        scene->wf_fb_pending = false;       // (a copy of the words may be in flight to the next planned render's feedback)
+    }
+    *lost = g[0];
+    *refused = g[1];
+    return BF_OK;
 }
 
 // Host control loop.  Per bounce `it`: [zero the next masks] -> wf_shade(it) ->
@@ -1425,9 +1497,10 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         // live counts of the last planned render: move the switch to the tail to where it belongs
         scene->wf_fb_pending = false;
         const unsigned long long lost = reinterpret_cast<volatile unsigned long long *>(scene->wf_host)[1];
-        if (lost) {
-            HIP_TRY(hipMemsetAsync(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long), stream));
-            return wf_guard_error(lost);
+        const unsigned long long refused = reinterpret_cast<volatile unsigned long long *>(scene->wf_host)[2];
+        if (lost || refused) {
+            HIP_TRY(hipMemsetAsync(scene->counters + bfd::CTR_GUARD, 0, 2 * sizeof(unsigned long long), stream));
+            return wf_guard_error(lost, refused);
         }
         const uint32_t *nl = scene->wf_feedback;
         uint32_t k = 0;
@@ -1452,7 +1525,7 @@ static bf_status wf_render(const bf_scene *scene, const bfd::DLaunch &lp, float 
         if (!scene->wf_fb_pending) {
             HIP_TRY(hipMemcpyAsync(scene->wf_feedback, wf.n_live, plan.iters * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(reinterpret_cast<unsigned long long *>(scene->wf_host) + 1, wf.counters + bfd::CTR_GUARD,
-                                   sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                                   2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(scene->wf_fb_event, stream));
             scene->wf_fb_pending = true;
             scene->wf_fb_iters = plan.iters;
@@ -1586,7 +1659,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         scene->wf.wake_b0 = lo / 64u;
         scene->wf.wake_nb = (uint32_t) std::min<uint64_t>(n_main / 64u, ((uint64_t) (lo % 64u) + (uint64_t) K * lp.batch_paths + 63u) / 64u);
     }
-    if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, sizeof(uint32_t), stream));
+    if (fresh_pool) HIP_TRY(hipMemsetAsync(scene->wf.surv_cursor, 0, 2 * sizeof(uint32_t), stream));
     const uint32_t n_chan1 = lp.n_chan;
     if (records_dev) lp.has_records = 1u;
     for (uint32_t j = 0; j < K; ++j) {
@@ -1889,13 +1962,14 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     lp.lean = lean_profile(scene, launch, receive_mode, multi_pixel) ? 1u : 0u;
     lp.wide = scene->sensor_host.filt_n != 0u ? 1u : 0u;
     scene->last_variant = (lp.lean ? (uint32_t) BF_VARIANT_LEAN : 0u) | (lp.wide ? (uint32_t) BF_VARIANT_WIDE : 0u);      // reconstruction filter wider than a pixel: the kernels' kWide variants
+    lp.count = ((launch->flags & (BF_FLAG_STATS | BF_FLAG_COUNT)) || stats_out) ? 1u : 0u;
     lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
     lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;
     lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;
     lp.lds_floats = lp.lds_hist ? lp.n_chan_all : 0u;
     size_t lds = sizeof(int) * bfd::kStackDepth * bfd::kBlock + (lp.lds_hist ? sizeof(float) * lp.n_chan_all : 0);
-    lds = (lds + 15) & ~size_t(15);
+    lds = ((lds + 15) & ~size_t(15)) + (scene->d.tab_cache ? bfd::kTabBytes : 0u);      // stacks | histogram | tables (bf_device_core.h: load_tables_lds)
     if (batch && !rolling) {
         // one launch sequence over n_renders * n_paths global path indices (DLaunch::batch); the per-render seeds and
         // mesh offsets travel through the scene's pinned staging ring, so the caller's arrays are free on return
@@ -1980,12 +2054,15 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
         (void) hipEventDestroy(ev1);
         if (he != hipSuccess) return fail(BF_ERR_DEVICE, "hipEventElapsedTime: %s", hipGetErrorString(he));
         stats_out->kernel_ms = ms;
-        if (c[bfd::CTR_GUARD]) {
-            // reported here: clear the sticky word and the copy of it that may be in flight to the next planned render
-            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
+        if (c[bfd::CTR_GUARD] || c[bfd::CTR_SURV_GUARD]) {
+            // reported here: clear the sticky words and the copy of them that may be in flight to the next planned render
+            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, 2 * sizeof(unsigned long long)));
             scene->wf_fb_pending = false;
-            return fail(BF_ERR_DEVICE, "wf_trace's iteration guard dropped %llu rays: the histogram is wrong (a traversal bug; please "
-                                       "report the scene)", c[bfd::CTR_GUARD]);
+            return wf_guard_error(c[bfd::CTR_GUARD], c[bfd::CTR_SURV_GUARD]);
+        }
+        if (launch->n_paths && !(launch->flags & BF_FLAG_MEGAKERNEL)) {
+            bf_status fst = check_film_count(c, lp.n_paths);
+            if (fst != BF_OK) return fst;
         }
     }
     return mark_last(scene, stream);
@@ -2022,11 +2099,12 @@ bf_status bf_scene_flush(bf_scene *scene, void *stream_, bf_stats *stats_out) {
         HIP_TRY(hipMemcpy(c, scene->counters, sizeof(c), hipMemcpyDeviceToHost));
         fill_stats(scene, c, n_paths, stats_out);
         stats_out->kernel_ms = scene->wf_ms[0] + scene->wf_ms[1] + scene->wf_ms[2];
-        if (c[bfd::CTR_GUARD]) {
-            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
+        if (c[bfd::CTR_GUARD] || c[bfd::CTR_SURV_GUARD]) {
+            HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, 2 * sizeof(unsigned long long)));
             scene->wf_fb_pending = false;
-            return wf_guard_error(c[bfd::CTR_GUARD]);
+            return wf_guard_error(c[bfd::CTR_GUARD], c[bfd::CTR_SURV_GUARD]);
         }
+        return scene->roll.lp.count ? check_film_count(c, n_paths) : BF_OK;       // every path of every render of a COUNTED sequence
     }
     return BF_OK;
 }
@@ -2039,12 +2117,10 @@ bf_status bf_scene_sync(bf_scene *scene) {
     if (scene->has_last) HIP_TRY(hipEventSynchronize(scene->last_done));
     scene->wf_fb_pending = false;         // whatever feedback was in flight has landed; the next render re-learns from its own
     scene->roll.fb_call_iters = 0;
-    unsigned long long lost = 0;
-    HIP_TRY(hipMemcpy(&lost, scene->counters + bfd::CTR_GUARD, sizeof(lost), hipMemcpyDeviceToHost));
-    if (lost) {
-        HIP_TRY(hipMemset(scene->counters + bfd::CTR_GUARD, 0, sizeof(unsigned long long)));
-        return wf_guard_error(lost);
-    }
+    unsigned long long lost = 0, refused = 0;
+    bf_status gst = read_guards(scene, &lost, &refused);
+    if (gst != BF_OK) return gst;
+    if (lost || refused) return wf_guard_error(lost, refused);
     return BF_OK;
 }
 
@@ -2099,15 +2175,22 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r = [] {
         Rccl q;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names)      // a copy that is already in the process (torch's) first
-            if ((q.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
-        for (const char *n : names) {
-            if (q.lib) break;
-            q.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        // BF_RCCL_LIB names the library to load instead (a site build; the tests force the not-found path with it)
+        const char *forced = getenv("BF_RCCL_LIB");
+        const char *names[] = {forced && *forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const size_t n_names = forced && *forced ? 1 : 3;
+        for (size_t i = 0; i < n_names && !q.lib; ++i)      // a copy that is already in the process (torch's) first
+            q.lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+        std::string last;
+        for (size_t i = 0; i < n_names && !q.lib; ++i) {
+            q.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+            if (!q.lib) {
+                const char *e = dlerror();      // ONE call: dlerror() clears the message it returns
+                last = e ? e : "";
+            }
         }
         if (!q.lib) {
-            q.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            q.why = std::string(forced && *forced ? forced : "librccl.so") + " not found: " + last;
             return q;
         }
         q.comm_init_all = (decltype(q.comm_init_all)) dlsym(q.lib, "ncclCommInitAll");
@@ -2177,22 +2260,68 @@ bf_status bf_render_sharded_device(bf_scene *const *scenes, uint32_t n_devices, 
         devices[g] = scenes[g]->device;
     }
     if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out));
-    // every GPU's launches are enqueued before any of them is waited for (statistics wait per device, afterwards)
-    std::vector<bf_stats> per(stats_out ? n_devices : 0);
+    const bool rolling = (launch->flags & BF_FLAG_ROLLING) != 0u;
+    if (stats_out && rolling)
+        return fail(BF_ERR_INVALID, "BF_FLAG_ROLLING: a rolling render has no statistics of its own (bf_scene_flush reports the sequence's)");
+    // Every GPU's launches are enqueued before any of them is waited for — also when statistics are asked for: a render
+    // with stats_out is synchronous per device (it would make the GPUs take turns), so the shards are issued WITHOUT, each
+    // between two events on its own stream, and the counters are read per device once all of them are in flight.
+    std::vector<hipEvent_t> ev(stats_out ? 2 * (size_t) n_devices : 0, nullptr);
+    std::vector<uint64_t> shard_paths(n_devices, 0);
+    auto drop_events = [&]() {
+        for (hipEvent_t e : ev)
+            if (e) (void) hipEventDestroy(e);
+    };
     for (uint32_t g = 0; g < n_devices; ++g) {
         bf_launch lg = *launch;
         uint64_t off = 0, cnt = 0;
         bf_shard_range(launch->n_paths, g, n_devices, &off, &cnt);
         lg.n_paths = cnt;
         lg.path_offset = launch->path_offset + off;
+        shard_paths[g] = cnt;
         if (cnt == 0) continue;
-        // a render with statistics is synchronous: with them the devices take turns (diagnostics, not the fast path)
-        bf_status st = bf_render_device(scenes[g], &lg, hist_dev[g], nullptr, streams ? streams[g] : nullptr, stats_out ? &per[g] : nullptr);
-        if (st != BF_OK) return st;
+        hipStream_t sg = reinterpret_cast<hipStream_t>(streams ? streams[g] : nullptr);
+        if (stats_out) {
+            DeviceGuard on_device(devices[g]);
+            hipError_t he = hipEventCreate(&ev[2 * g]);
+            if (he == hipSuccess) he = hipEventCreate(&ev[2 * g + 1]);
+            if (he == hipSuccess) he = hipEventRecord(ev[2 * g], sg);
+            if (he != hipSuccess) {
+                drop_events();
+                return fail(BF_ERR_DEVICE, "bf_render_sharded_device: device %d: %s", devices[g], hipGetErrorString(he));
+            }
+        }
+        if (stats_out) lg.flags |= BF_FLAG_COUNT;      // (the counters are read below, once every device is in flight)
+        bf_status st = bf_render_device(scenes[g], &lg, hist_dev[g], nullptr, sg, nullptr);
+        if (st == BF_OK && stats_out) {
+            DeviceGuard on_device(devices[g]);
+            if (hipEventRecord(ev[2 * g + 1], sg) != hipSuccess) st = fail(BF_ERR_DEVICE, "bf_render_sharded_device: hipEventRecord failed");
+        }
+        if (st != BF_OK) {
+            drop_events();
+            return st;
+        }
     }
+    bf_status rst = BF_OK;
+    // a rolling render's histogram is complete only after bf_scene_flush: the caller reduces then (bf_allreduce_device);
+    // a communicator of one: the sum is the histogram itself
+    if (!rolling && n_devices > 1) rst = bf_allreduce_device(devices.data(), n_devices, hist_dev, bf_launch_channels(launch), streams);
     if (stats_out) {
-        for (uint32_t g = 0; g < n_devices; ++g) {
-            const bf_stats &p = per[g];
+        unsigned long long lost = 0, refused = 0;
+        for (uint32_t g = 0; g < n_devices && rst == BF_OK; ++g) {
+            if (shard_paths[g] == 0) continue;
+            BF_ENTER(scenes[g]);                 // (this handle's device; the counters are the handle's)
+            hipError_t he = hipEventSynchronize(ev[2 * g + 1]);
+            unsigned long long c[bfd::CTR_COUNT];
+            if (he == hipSuccess) he = hipMemcpy(c, scenes[g]->counters, sizeof(c), hipMemcpyDeviceToHost);
+            float ms = 0.f;
+            if (he == hipSuccess) he = hipEventElapsedTime(&ms, ev[2 * g], ev[2 * g + 1]);
+            if (he != hipSuccess) {
+                rst = fail(BF_ERR_DEVICE, "bf_render_sharded_device: device %d: %s", devices[g], hipGetErrorString(he));
+                break;
+            }
+            bf_stats p;
+            fill_stats(scenes[g], c, shard_paths[g], &p);
             stats_out->n_paths += p.n_paths;
             stats_out->n_rays_closest += p.n_rays_closest;
             stats_out->n_rays_shadow += p.n_rays_shadow;
@@ -2203,16 +2332,20 @@ bf_status bf_render_sharded_device(bf_scene *const *scenes, uint32_t n_devices, 
             stats_out->n_rays_tail += p.n_rays_tail;
             stats_out->n_rays_traced += p.n_rays_traced;
             stats_out->n_nodes_lds += p.n_nodes_lds;
-            stats_out->kernel_ms = std::max(stats_out->kernel_ms, p.kernel_ms);      // the devices run side by side
-            stats_out->trace_ms = std::max(stats_out->trace_ms, p.trace_ms);
-            stats_out->shade_ms = std::max(stats_out->shade_ms, p.shade_ms);
-            stats_out->tail_ms = std::max(stats_out->tail_ms, p.tail_ms);
+            stats_out->kernel_variant = p.kernel_variant;
+            // the devices run side by side: the slowest one's span (the per-kernel times need a synchronous render: 0 here)
+            stats_out->kernel_ms = std::max(stats_out->kernel_ms, ms);
+            if (c[bfd::CTR_GUARD] || c[bfd::CTR_SURV_GUARD]) {
+                lost += c[bfd::CTR_GUARD];
+                refused += c[bfd::CTR_SURV_GUARD];
+                (void) hipMemset(scenes[g]->counters + bfd::CTR_GUARD, 0, 2 * sizeof(unsigned long long));
+                scenes[g]->wf_fb_pending = false;
+            }
         }
+        drop_events();
+        if (rst == BF_OK && (lost || refused)) rst = wf_guard_error(lost, refused);
     }
-    // a rolling render's histogram is complete only after bf_scene_flush: the caller reduces then (bf_allreduce_device)
-    if (launch->flags & BF_FLAG_ROLLING) return BF_OK;
-    if (n_devices == 1) return BF_OK;          // a communicator of one: the sum is the histogram itself
-    return bf_allreduce_device(devices.data(), n_devices, hist_dev, bf_launch_channels(launch), streams);
+    return rst;
 }
 
 bf_status bf_render_sharded(bf_scene *const *scenes, uint32_t n_devices, const bf_launch *launch, float *hist_out, bf_stats *stats_out) {
@@ -2263,6 +2396,7 @@ static bf_status render_host(const bf_scene *scene, const bf_launch *launch, con
     if (n_renders == 0) return fail(BF_ERR_INVALID, "bf_render_batch: n_renders is 0");
     const uint64_t nchan = (uint64_t) bf_launch_channels(launch) * n_renders, n_rec = launch->n_paths * n_renders;
     if (nchan == 0) return fail(BF_ERR_INVALID, "unknown mode");
+    DeviceGuard on_device(scene->device);      // the staging buffers live where the kernels run, whatever the caller's current device
     float *d_hist = nullptr;
     bf_path_record *d_rec = nullptr;
     HIP_TRY(hipMalloc((void **) &d_hist, nchan * sizeof(float)));
@@ -2302,6 +2436,7 @@ static bf_status trace_common(const bf_scene *scene, uint64_t n, const float *ra
                               float *out_si = nullptr) {
     if (!scene || (n && !rays)) return fail(BF_ERR_INVALID, "null argument");
     if (n == 0) return BF_OK;
+    DeviceGuard on_device(scene->device);
     float *d_rays = nullptr, *d_t = nullptr, *d_uv = nullptr, *d_si = nullptr;
     uint32_t *d_prim = nullptr, *d_shape = nullptr;
     uint8_t *d_hit = nullptr;

@@ -14,6 +14,7 @@
 //   rects, shapes, materials, emitters : small tables (scenes hold a handful)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/beifong_hip.h"
@@ -41,6 +42,10 @@ struct DRect {
     uint32_t material;    // of the carrying shape
     int32_t emitter;      // of the carrying shape, or -1
 };
+
+static_assert(sizeof(DRect) == 156 && offsetof(DRect, s) == 96 && offsetof(DRect, n) == 120 && offsetof(DRect, shape) == 140 &&
+                  offsetof(DRect, material) == 148 && offsetof(DRect, emitter) == 152,
+              "make_si reads the LDS copy of a rectangle by dword index");
 
 struct DShape {
     uint32_t type, material;
@@ -132,7 +137,17 @@ struct DScene {
     uint32_t n_wnodes;
     uint32_t wrows_log;       // log2 of the most rows a gang may have: 16 * rows * depth stack entries must fit kWideStack
     const DSensor *sensor;    // device copy (kept out of the kernel arguments: 44 dwords of scalar registers)
+    // LDS copies of the tables a vertex reads through a PER-LANE index (its material; the rectangle it hit): wf_shade and the
+    // tail kernel copy them behind their histogram when the scene is small enough (tab_cache, set by the host, reserves
+    // kTabBytes of dynamic LDS) and switch tab_on in their own copy of this struct (bf_device_core.h: load_tables_lds)
+    uint32_t n_materials;
+    uint32_t tab_cache;       // host: 1 = n_materials <= kTabMaxMaterials and n_rects <= kTabMaxRects
+    uint32_t tab_on;          // device only: the tables are in LDS at byte offsets lds_mat / lds_rect of the dynamic segment
+    uint32_t lds_mat, lds_rect;
 };
+constexpr uint32_t kTabMaxMaterials = 16, kTabMaxRects = 8;
+constexpr uint32_t kRectDwords = sizeof(DRect) / 4;       // 39: an odd stride, lanes at different rectangles fall into different banks
+constexpr uint32_t kTabBytes = (kTabMaxMaterials * 48u + kTabMaxRects * (uint32_t) sizeof(DRect) + 15u) & ~15u;
 
 // The scene's SMALL TABLES (rectangles, shapes, materials, emitters, the sensor record, the rolling ring) are read through
 // constant-address-space pointers: the loads are invariant for the compiler, and one whose address is wave-uniform — the
@@ -198,6 +213,9 @@ struct DLaunch {
     uint32_t has_records;           // rolling sequence: some render of it writes per-path records (DRoll::records)
     uint32_t lean;                  // 1: scene and launch fit the lean profile: the kernels' kLean variants
     uint32_t wide;                  // 1: the sensor's reconstruction filter is wider than a pixel (DSensor::filt_n != 0): the kernels' kWide variants
+    uint32_t count;                 // 1: somebody will read the statistics counters (BF_FLAG_STATS, or a render with stats_out): wf_shade and
+                                    // the tail add theirs up — ten same-line atomics per WAVE, ~15 us each per launch at the end of a
+                                    // persistent grid whose waves all finish together; 0: only the live count the host steers by
 };
 
 // device counters (uint64 each)
@@ -213,7 +231,11 @@ enum {
     CTR_SHADE_STORES,      // path-state rows wf_shade wrote back
     CTR_SHADE_SHADOW,      // shadow requests wf_shade queued for wf_trace
     CTR_SHADE_RAYS,        // rays generated by wf_shade (each one tests the rectangles and the root node's boxes)
+    CTR_FILM,              // paths binned (film_put calls): == the paths supplied once a render / sequence has ended, else paths were lost
+    // the STICKY words (never cleared by a render, reported once): keep them last
     CTR_GUARD,             // rays dropped by wf_trace's iteration guard (a bug if ever non-zero: bf_render reports BF_ERR_DEVICE)
+    CTR_SURV_GUARD,        // survivor batches a launch of a rolling sequence tried to claim beyond the area's size (surv_take: the
+                           // claim is refused, so nothing is lost, and reported: the sizing rule of bf_api.cpp: wf_setup was violated)
     CTR_COUNT
 };
 

@@ -157,10 +157,20 @@ BF_DEV int pick_child(float4 ch, uint32_t key) {
 // case of a four-wide tree is three per level — in a per-thread HBM column (DScene::spill, entry
 // k at spill[k * spill_stride]).  SPILL = false: the host guarantees BVH4::stack_need <= N_LDS
 // (bf_bvh.h) and the overflow path is compiled out.
+// pop(): BF_FLAT_POP = 1 (default) reads the entry through ONE flat load on a selected pointer; 0 branches between an LDS and a
+// global load.  The branch looked like the obvious win (a flat load is a vector-memory instruction and waits for both
+// counters) and measured 1.3 % SLOWER in wf_trace (3.85 -> 3.90 ms per C2 step, profiles/r04_flat_ops_ab.txt): the extra
+// divergence costs more than the flat path, so the select stays.
+#ifndef BF_FLAT_POP
+#define BF_FLAT_POP 1
+#endif
 template <int N_LDS, bool SPILL>
 struct LaneStack {
-    int *lds;
-    int *spill;
+    // The two homes of an entry are named by address space: with generic pointers the compiler turns pop()'s choice into a
+    // select of two pointers and ONE flat_load — a vector-memory instruction (the busiest unit of the traversal kernels) that
+    // also waits for every outstanding store (round 4: every pop of wf_trace in rounds 1-3 was one).
+    __attribute__((address_space(3))) int *lds;
+    __attribute__((address_space(1))) int *spill;
     uint32_t spill_stride;
     int sp;
     BF_DEV void push(int v) {
@@ -172,15 +182,20 @@ struct LaneStack {
     }
     BF_DEV int pop() {
         --sp;
-        return (!SPILL || sp < N_LDS) ? lds[sp * kBlock] : spill[(size_t) (sp - N_LDS) * spill_stride];
+#if BF_FLAT_POP
+        return (!SPILL || sp < N_LDS) ? ((int *) lds)[sp * kBlock] : ((int *) spill)[(size_t) (sp - N_LDS) * spill_stride];
+#else
+        if (!SPILL || sp < N_LDS) return lds[sp * kBlock];
+        return spill[(size_t) (sp - N_LDS) * spill_stride];
+#endif
     }
     BF_DEV int pop_or_none() { return sp ? pop() : kNoNode; }
 };
 template <int N_LDS, bool SPILL>
 BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
     LaneStack<N_LDS, SPILL> st;
-    st.lds = lds_column;
-    st.spill = sc.spill + ((size_t) blockIdx.x * kBlock + threadIdx.x);
+    st.lds = (__attribute__((address_space(3))) int *) lds_column;
+    st.spill = (__attribute__((address_space(1))) int *) (sc.spill + ((size_t) blockIdx.x * kBlock + threadIdx.x));
     st.spill_stride = sc.spill_stride;
     st.sp = 0;
     return st;
@@ -222,6 +237,7 @@ BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid,
 constexpr uint32_t kTopStride = 9;
 typedef float bf_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const bf_f4 *lds_f4_ptr;
+typedef __attribute__((address_space(3))) const float *lds_f_ptr;
 typedef const BF_CAS bf_f4 *c_f4_ptr;      // constant address space: a wave-uniform address loads through the scalar cache
 BF_DEV float4 to_float4(bf_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 BF_DEV void load_top_nodes(const float4 *__restrict__ nodes, uint32_t n_top, float4 *top, uint32_t tid, uint32_t n_threads) {
@@ -428,8 +444,8 @@ BF_DEV void traverse_quad(const DScene &sc, bool active, bool any, V3 o, V3 d, f
     V3 id, oid, ohi;
     ray_inverse_shift(o, d, sh, id, oid, ohi);
     LaneStack<kStackDepth, SPILL> st;
-    st.lds = lds_leader_column;
-    st.spill = sc.spill + ((size_t) blockIdx.x * kBlock + (threadIdx.x & ~3u));
+    st.lds = (__attribute__((address_space(3))) int *) lds_leader_column;
+    st.spill = (__attribute__((address_space(1))) int *) (sc.spill + ((size_t) blockIdx.x * kBlock + (threadIdx.x & ~3u)));
     st.spill_stride = sc.spill_stride;
     st.sp = 0;
     while (__ballot(node != kNoNode)) {
@@ -712,17 +728,28 @@ template <bool FULL = false, int V = 0> BF_DEV void make_si(const DScene &sc, V3
     si.t = h.t;
     V3 dp_du;
     if (h.slot < 0) {
-        CRect &rc = c_rects(sc)[-h.slot - 1];
-        si.shape = rc.shape;
-        si.material = rc.material;
-        si.emitter = rc.emitter;
         si.p = fmadd3(d, h.t, o);
-        si.sh.n = mk(rc.n[0], rc.n[1], rc.n[2]);
-        dp_du = mk(rc.s[0], rc.s[1], rc.s[2]);
-        if (FULL) {
-            geom->n = si.sh.n;
-            geom->dp_du = dp_du;
-            geom->dp_dv = mk(rc.t[0], rc.t[1], rc.t[2]);
+        if (!FULL && sc.tab_on) {
+            // the rectangle's record from the workgroup's LDS copy (per-lane index): DRect dwords 24.. = s, t, n, 35 = shape, 37 = material, 38 = emitter
+            extern __shared__ __align__(16) unsigned char s_dyn[];
+            const lds_f_ptr r = (lds_f_ptr) (s_dyn + sc.lds_rect) + kRectDwords * (uint32_t) (-h.slot - 1);
+            si.shape = __float_as_uint(r[35]);
+            si.material = __float_as_uint(r[37]);
+            si.emitter = __float_as_int(r[38]);
+            si.sh.n = mk(r[30], r[31], r[32]);
+            dp_du = mk(r[24], r[25], r[26]);
+        } else {
+            CRect &rc = c_rects(sc)[-h.slot - 1];
+            si.shape = rc.shape;
+            si.material = rc.material;
+            si.emitter = rc.emitter;
+            si.sh.n = mk(rc.n[0], rc.n[1], rc.n[2]);
+            dp_du = mk(rc.s[0], rc.s[1], rc.s[2]);
+            if (FULL) {
+                geom->n = si.sh.n;
+                geom->dp_du = dp_du;
+                geom->dp_dv = mk(rc.t[0], rc.t[1], rc.t[2]);
+            }
         }
     } else {
         const float4 *tp = sc.tris + kTriStride * (size_t) h.slot;
@@ -787,9 +814,30 @@ struct Microfacet {
 // A shaded vertex reads its material ONCE, whole (three 16-byte loads issued together as soon as the hit's record names it,
 // one wait at the first use) instead of field by field where the BSDF code happens to need one (a dozen dependent
 // round trips per vertex through a per-lane address).  Device table: DMaterial, bf_material padded to 48 bytes.
+// The copy comes from the workgroup's LDS tables when the scene fits them (DScene::tab_on: ~100 cycles instead of an L2
+// round trip through a per-lane address), else from the device table.
+BF_DEV void load_tables_lds(DScene &sc, uint32_t byte_off, uint32_t tid) {      // whole workgroup; the caller synchronises
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    sc.tab_on = 0u;
+    if (!sc.tab_cache) return;
+    float *dst = reinterpret_cast<float *>(s_dyn + byte_off);
+    const float *gm = reinterpret_cast<const float *>(sc.materials), *gr = reinterpret_cast<const float *>(sc.rects);
+    for (uint32_t i = tid; i < sc.n_materials * 12u; i += kBlock) dst[i] = gm[i];
+    for (uint32_t i = tid; i < sc.n_rects * kRectDwords; i += kBlock) dst[kTabMaxMaterials * 12u + i] = gr[i];
+    sc.lds_mat = byte_off;
+    sc.lds_rect = byte_off + kTabMaxMaterials * 48u;
+    sc.tab_on = 1u;
+}
 BF_DEV bf_material load_material(const DScene &sc, uint32_t index) {
-    const c_f4_ptr mp = (c_f4_ptr) (uintptr_t) (sc.materials + index);
-    const bf_f4 a = mp[0], b = mp[1], c = mp[2];
+    bf_f4 a, b, c;
+    if (sc.tab_on) {
+        extern __shared__ __align__(16) unsigned char s_dyn[];
+        const lds_f4_ptr mp = (lds_f4_ptr) (s_dyn + sc.lds_mat) + 3u * index;
+        a = mp[0], b = mp[1], c = mp[2];
+    } else {
+        const c_f4_ptr mp = (c_f4_ptr) (uintptr_t) (sc.materials + index);
+        a = mp[0], b = mp[1], c = mp[2];
+    }
     bf_material m;
     m.type = __float_as_uint(a.x);
     m.twosided = __float_as_uint(a.y);

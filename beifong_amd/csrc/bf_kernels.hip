@@ -45,7 +45,7 @@ __device__ unsigned long long g_tail_prof[8192 * 24];
 #define BF_PROF_STAMP(var)
 #endif
 template <bool STATS, bool RESUME, bool SPILL, int TW = BF_TAIL_WAVES, int VX = 0>
-__global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DScene sc, DLaunch lp, float *__restrict__ g_hist,
+__global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DScene sc_arg, DLaunch lp, float *__restrict__ g_hist,
                                                            bf_path_record *__restrict__ records,
                                                            unsigned long long *__restrict__ counters, WF wf, uint32_t wf_it) {
     constexpr int kRX = 2 | VX;       // mode class decided at run time; VX: kWide (the filtered put) or kLean (bf_device.h: kernel variant word)
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const bool lds_hist = lp.lds_hist != 0;
-    if (lp.lds_floats) {
+    DScene sc = sc_arg;
+    load_tables_lds(sc, (uint32_t) (sizeof(int) * kStackDepth * kBlock) + ((4u * lp.lds_floats + 15u) & ~15u), (uint32_t) tid);
+    if (lp.lds_floats || sc.tab_on) {
         for (uint32_t i = tid; i < lp.lds_floats; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     s.dlambda = 0.f;
     s.rmint = 0.f;
     s.rmaxt = 0.f;
-    FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
+    FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
     uint32_t c_closest = 0, c_shadow = 0, c_nodes = 0, c_wnodes = 0, c_tris = 0, c_bounces = 0;
     // wave-local pool of path indices (uniform across the wave)
     uint64_t pool_next = 0, pool_end = 0;
@@ -443,9 +445,10 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     film_flush<kRX>(lp, acc, s_hist, g_hist, lds_hist, tid);
     // statistics: wave-reduce then one atomic per counter per wave
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_nodes = c_nodes, v_tris = c_tris,
-                       v_invalid = acc.invalid, v_bounces = c_bounces, v_wnodes = c_wnodes;
+                       v_invalid = acc.invalid, v_bounces = c_bounces, v_wnodes = c_wnodes, v_film = acc.n_put;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v_film += __shfl_down(v_film, off);
         v_wnodes += __shfl_down(v_wnodes, off);
         v_closest += __shfl_down(v_closest, off);
         v_shadow += __shfl_down(v_shadow, off);
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         v_invalid += __shfl_down(v_invalid, off);
         v_bounces += __shfl_down(v_bounces, off);
     }
-    if (lane == 0) {
+    if (lane == 0 && lp.count) {
         atomicAdd(&counters[CTR_CLOSEST], v_closest);
         atomicAdd(&counters[CTR_SHADOW], v_shadow);
         if (RESUME) atomicAdd(&counters[CTR_TAIL_RAYS], v_closest + v_shadow);
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
         if (RESUME) atomicAdd(&counters[CTR_TAIL_BOUNCES], v_bounces);
         atomicAdd(&counters[CTR_INVALID], v_invalid);
         atomicAdd(&counters[CTR_BOUNCES], v_bounces);
+        if (v_film) atomicAdd(&counters[CTR_FILM], v_film);
     }
 }
 

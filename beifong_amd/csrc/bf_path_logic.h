@@ -520,7 +520,10 @@ BF_DEV void path_phasor(float length, float lambda_nm, float &re, float &im) {
 // the BSDF sample kills the path (path.cpp:171-173) the function returns true
 // with kFlagTermPending set and an empty ray interval: the film write has to
 // wait for the shadow ray of this very iteration.
-#ifdef BF_TAIL_PROF
+#if defined(BF_TAIL_PROF) || defined(BF_SHADE_PROF)
+#define BF_VERTEX_PROF 1
+#endif
+#ifdef BF_VERTEX_PROF
 struct ShadeProf {
     unsigned long long si, head, nee, bsdf;
 };
@@ -573,7 +576,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
         emitter = si.emitter;
         mat = load_material(sc, si.material);      // issued here, waited for where NEE / BSDF sampling first read it
     }
-#ifdef BF_TAIL_PROF
+#ifdef BF_VERTEX_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     BF_SHADEPROF_STAMP(spf_t1);
@@ -717,7 +720,7 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
     s.prev_p = si.p;
     s.bs_pdf = bs.pdf;
     ++s.n_rays;
-#ifdef BF_TAIL_PROF
+#ifdef BF_VERTEX_PROF
     if (spf) {
         const unsigned long long spf_t4 = __builtin_amdgcn_s_memtime();
         spf->si += spf_t1 - spf_t0;
@@ -732,11 +735,32 @@ BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, cons
 // ---------------------------------------------------------------------------
 // film / ADC
 // ---------------------------------------------------------------------------
+// The two destinations are named by address space: through generic pointers the compiler merges both branches into ONE
+// flat_atomic_add_f32 on a selected pointer — a vector-memory instruction that finds out per lane whether it addresses LDS
+// (round 4: every histogram sample of rounds 1-3 went that way, 20 % of wf_shade's cycles).
+typedef __attribute__((address_space(3))) float *lds_float_ptr;
+typedef __attribute__((address_space(1))) float *glb_float_ptr;
+BF_DEV void lds_add(float *p, float v) {          // ds_add_f32
+    (void) __hip_atomic_fetch_add((lds_float_ptr) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+BF_DEV void glb_add(float *p, float v) {          // global_atomic_add_f32
+    (void) __hip_atomic_fetch_add((glb_float_ptr) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifndef BF_FLAT_HIST
+#define BF_FLAT_HIST 0
+#endif
 BF_DEV void hist_add(float *s_hist, float *g_hist, bool lds, uint32_t idx, float v) {
+#if BF_FLAT_HIST
     if (lds)
-        atomicAdd(&s_hist[idx], v);     // ds_add_f32
+        atomicAdd(&s_hist[idx], v);
     else
-        atomicAdd(&g_hist[idx], v);     // global_atomic_add_f32
+        atomicAdd(&g_hist[idx], v);
+#else
+    if (lds)
+        lds_add(s_hist + idx, v);
+    else
+        glb_add(g_hist + idx, v);
+#endif
 }
 // Where the samples of render `render` go: plain launch = the histogram; batched launch = block `render` of it (LDS and
 // global alike); rolling sequence = the render's own histogram (DRoll::hist), privatised in LDS only for the newest
@@ -763,6 +787,7 @@ BF_DEV HistDst hist_dst(const DLaunch &lp, uint32_t render, float *s_hist, float
 struct FilmAcc {
     float X, Y, Z, A, W;    // base channels of the 1x1 film (render modes)
     uint32_t invalid;
+    uint32_t n_put;         // paths binned by this lane (CTR_FILM: the loud "no path was lost" check of the host)
 };
 
 // ImageBlock::put / SignalBlock::put, the branch for reconstruction filters wider than a pixel (imageblock.cpp:115-165,
@@ -863,6 +888,9 @@ template <int RX = 2>
 BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
                      FilmAcc &acc, bf_path_record *records) {
     const bool valid = (s.flags & kFlagValid) != 0;
+#ifndef BF_NO_FILM_CTR
+    ++acc.n_put;
+#endif
     float rec_L, rec_aux;
     float *const s_base = s_hist + lp.base_off;                               // rolling launches: base-channel table (DLaunch::base_off)
     const HistDst hd = hist_dst(lp, s.render, s_hist, g_hist, lds_hist);      // this render's block of the histogram
@@ -1087,12 +1115,16 @@ BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, fl
         rec_i -= (uint64_t) s.render * lp.batch_paths;
     }
     if (records) {
-        bf_path_record r;
-        r.L = rec_L;
-        r.aux = rec_aux;
-        r.valid = valid ? 1u : 0u;
-        r.n_rays = s.n_rays;
-        records[rec_i] = r;
+        // bf_path_record {L, aux, valid, n_rays} as one 16-byte store through a global-address-space pointer (a rolling render's
+        // array comes out of its descriptor: a generic pointer would make this a flat store)
+        static_assert(sizeof(bf_path_record) == 16, "one 16-byte store per record");
+        typedef __attribute__((address_space(1))) bf_f4 *glb_f4_ptr;
+        bf_f4 r;
+        r.x = rec_L;
+        r.y = rec_aux;
+        r.z = __uint_as_float(valid ? 1u : 0u);
+        r.w = __uint_as_float(s.n_rays);
+        ((glb_f4_ptr) records)[rec_i] = r;
     }
 }
 
@@ -1127,13 +1159,13 @@ template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, fl
                 const float *sh = s_hist + (r - lp.roll_lo) * lp.n_chan;
                 for (uint32_t i = tid; i < lp.n_chan; i += kBlock) {
                     float v = sh[i];
-                    if (v != 0.f) atomicAdd(&gh[i], v);
+                    if (v != 0.f) glb_add(gh + i, v);
                 }
             }
         } else {
             for (uint32_t i = tid; i < lp.n_chan_all; i += kBlock) {
                 float v = s_hist[i];
-                if (v != 0.f) atomicAdd(&g_hist[i], v);
+                if (v != 0.f) glb_add(g_hist + i, v);
             }
         }
     }
@@ -1144,7 +1176,7 @@ template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, fl
         for (uint32_t i = tid; i < 5u * kRollBase; i += kBlock) {
             const float v = s_base[i];
             const uint32_t age = i / 5u;
-            if (v != 0.f && age <= lp.roll_newest) atomicAdd(&lp.roll[(lp.roll_newest - age) & (kRollRing - 1u)].hist[i - 5u * age], v);
+            if (v != 0.f && age <= lp.roll_newest) glb_add(lp.roll[(lp.roll_newest - age) & (kRollRing - 1u)].hist + (i - 5u * age), v);
         }
     }
 }

@@ -103,7 +103,9 @@ struct WF {
     // slot starts the new render's path on time and the wake launch stays one coherent generate pass.  Survivor slots
     // never regenerate.  Plain renders: n_main = n_slots, n_surv = 0.
     uint32_t n_main, n_surv;
-    uint32_t *surv_cursor;          // survivor batches claimed so far (device; one returning atomic per claim)
+    uint32_t *surv_cursor;          // [0] survivor batches claimed by the earlier launches of the sequence (where the next one starts
+                                    // looking); [1] claims of the current evicting launch (one returning atomic per claim; folded
+                                    // into [0] by the wake launch that follows: bf_wavefront.hip: surv_take)
     uint32_t wake_b0, wake_nb;      // wake launch: the batches that hold the slots due for the new render's paths: wake_nb batches from wake_b0, wrapping at n_main
     uint32_t tail_share;            // tail kernel: 1, 2 or 4 waves share every batch (16 paths per wave walk four lanes per ray from the first bounce)
     uint32_t surv_claims_max;       // claims one wave may make per launch: n_waves * max <= survivor batches, so no batch is claimed twice in a launch

@@ -90,6 +90,7 @@ BF_DEV bool presolve_ray(const DScene &sc, bool any, V3 o, V3 d, float mint, flo
 struct SurvAlloc {
     unsigned long long free;    // unclaimed free slots of the current batch (wave-uniform)
     uint32_t batch, claims;
+    uint32_t rot;               // claims of the sequence's earlier launches (surv_cursor[0], read once per kernel)
 };
 BF_DEV void surv_take(const WF &wf, int cur, SurvAlloc &sv, unsigned long long em, bool &evict, uint32_t &dst, int lane) {
     const uint32_t need = (uint32_t) __popcll(em), rank = (uint32_t) __popcll(em & ((1ull << lane) - 1ull));
@@ -98,10 +99,23 @@ BF_DEV void surv_take(const WF &wf, int cur, SurvAlloc &sv, unsigned long long e
     while (served < need) {
         if (sv.free == 0ull) {
             if (sv.claims >= wf.surv_claims_max || surv_b == 0u) break;
-            uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(wf.surv_cursor, 1u);
-            c = (uint32_t) __shfl((int) c, 0);
-            sv.batch = main_b + c % surv_b;
+            // claim number `nth` of THIS launch (one returning atomic) picks batch (rot + nth) mod surv_b: distinct batches for
+            // nth < surv_b whatever the order the waves arrive in.  rot = the claims of all earlier launches of the sequence
+            // (surv_cursor[0], constant during the launch: the wake launch that follows folds this launch's count into it), so a
+            // launch starts looking where the previous one stopped.
+            uint32_t nth = 0;
+            if (lane == 0) nth = atomicAdd(wf.surv_cursor + 1, 1u);
+            nth = (uint32_t) __shfl((int) nth, 0);
+            if (nth >= surv_b) {
+                // The launch has handed out every survivor batch once: the next one would be a batch ANOTHER wave of this launch
+                // holds, and two waves filling the same free slots lose paths silently (round 3, commit 129745c).  The sizing
+                // rule (surv_claims_max x waves <= batches) keeps this from happening; if it ever does, the claim is refused —
+                // the paths stay in their slots: slower, never wrong — and counted: the flush / sync of the handle fails.
+                if (lane == 0) atomicAdd(&wf.counters[CTR_SURV_GUARD], 1ull);
+                sv.claims = wf.surv_claims_max;
+                break;
+            }
+            sv.batch = main_b + (sv.rot + nth) % surv_b;
             sv.free = ~wf.m_alive[cur][sv.batch];
             ++sv.claims;
             continue;
@@ -141,31 +155,39 @@ BF_DEV void surv_take(const WF &wf, int cur, SurvAlloc &sv, unsigned long long e
 #define SLT(k)
 #endif
 template <int FIRST, int W, int RX>
-__global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
+__global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                       bf_path_record *__restrict__ records) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     float *s_hist = reinterpret_cast<float *>(s_raw);
     const int tid = threadIdx.x, lane = tid & 63;
+    DScene sc = sc_arg;
+    load_tables_lds(sc, (4u * lp.lds_floats + 15u) & ~15u, (uint32_t) tid);      // materials + rectangles behind the histogram
     constexpr bool WALK = FIRST == 0 || FIRST == 3;      // the launch walks the alive masks (else: whole batches of main slots)
     constexpr bool EVICT = FIRST == 3;                   // ... and moves long paths to the survivor area (own variant: the
                                                          // allocator's live values would cost wf_shade<0> its scratch-free build)
     const bool lds_hist = lp.lds_hist != 0;
-    if (lp.lds_floats) {
+    if (lp.lds_floats || sc.tab_on) {
         for (uint32_t i = tid; i < lp.lds_floats; i += kBlock) s_hist[i] = 0.f;
         __syncthreads();
     }
     const int cur = it & 1, nxt = cur ^ 1;
     const bool receive = mode_receive<RX>(lp);
+    if (FIRST == 2 && blockIdx.x == 0 && tid == 0) {
+        // the wake launch follows the evicting launch of its call (same stream): fold that launch's claims into the rotation
+        wf.surv_cursor[0] += wf.surv_cursor[1];
+        wf.surv_cursor[1] = 0u;
+    }
     // the first / wake launches start paths: main slots only (the survivor area never regenerates)
     // (the wake launch: only the batches whose slots are due — the other half of the main slots holds the previous render)
     const uint32_t n_batches = WALK ? wf.n_slots >> 6 : (FIRST == 2 ? wf.wake_nb : wf.n_main >> 6);
     unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
-    SurvAlloc sv = {0ull, 0u, 0u};
+    SurvAlloc sv = {0ull, 0u, 0u, EVICT ? wf.surv_cursor[0] : 0u};
 
-    FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u};
+    FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
     uint32_t c_closest = 0, c_shadow = 0, c_bounces = 0, c_live = 0, c_traced = 0, c_loads = 0, c_shq = 0;
 #ifdef BF_SHADE_PROF
-    const bool lpf = true;
+    const bool lpf = BF_SHADE_PROF >= 2;      // -DBF_SHADE_PROF=2: lane counts per section too (an atomic pair per entry: the cycle shares are then perturbed)
+    ShadeProf spf = {0, 0, 0, 0};
     unsigned long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cursor, load, vertex + film, generate, presolve, chain, store
     unsigned long long slt_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
             if (!settled && have_hit) {
                 have_hit = false;
 #ifdef BF_SHADE_PROF
-                cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces, true);
+                cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces, &spf, lpf);
 #else
                 cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces);
 #endif
@@ -353,9 +375,18 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         bool evict = false;
         uint32_t dst = slot;
         if (EVICT) {
-            evict = has && cont && slot < wf.n_main && s.path_i + wf.n_main < lp.n_paths;
+            // ... and only out of the batches THIS call's wake launch visits (the slots due for the new render's paths): a
+            // slot that has fallen behind (the survivor area was full when it was due: its path stayed in place) may sit in the
+            // other half of the main slots, and a slot vacated there would stay dead — its pending paths unrendered — until its
+            // half is woken again, or for good if the sequence is flushed first (round 4: found by the CTR_FILM check)
+            const uint32_t main_b = wf.n_main >> 6, b = slot >> 6;
+            const uint32_t rel = b >= wf.wake_b0 ? b - wf.wake_b0 : b + main_b - wf.wake_b0;
+            evict = has && cont && slot < wf.n_main && rel < wf.wake_nb && s.path_i + wf.n_main < lp.n_paths;
             const unsigned long long em = __ballot(evict);
             if (em) surv_take(wf, cur, sv, em, evict, dst, lane);
+            // the vacated slot's entry names the path that leaves it (the wake launch continues from there): the moved path may
+            // have started within this very visit and never been stored here
+            if (evict) wf.sd(slot) = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
         }
         if (has && cont) {
             if (!(s.flags & kFlagTermPending)) {
@@ -395,11 +426,26 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
 
     film_flush<RX>(lp, acc, s_hist, g_hist, lds_hist, tid);
 #ifdef BF_SHADE_PROF
-    if (lane == 0)
+    // (the stamps inside shade_vertex sit in divergent code: a lane holds the cycles of the sections IT went through; the
+    // wave's figure is the largest)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        spf.si = max(spf.si, (unsigned long long) __shfl_down((long long) spf.si, off));
+        spf.head = max(spf.head, (unsigned long long) __shfl_down((long long) spf.head, off));
+        spf.nee = max(spf.nee, (unsigned long long) __shfl_down((long long) spf.nee, off));
+        spf.bsdf = max(spf.bsdf, (unsigned long long) __shfl_down((long long) spf.bsdf, off));
+    }
+    if (lane == 0) {
         for (int k = 0; k < 8; ++k) atomicAdd(&g_lane_prof[24 + k], t_sec[k]);      // sections 24..31 of the wave-entry half: cycles
+        // inside "vertex + film": surface interaction (incl. the wait for the triangle), head, next-event estimation, BSDF sampling
+        atomicAdd(&g_lane_prof[kShadeProfSections + 24], spf.si);
+        atomicAdd(&g_lane_prof[kShadeProfSections + 25], spf.head);
+        atomicAdd(&g_lane_prof[kShadeProfSections + 26], spf.nee);
+        atomicAdd(&g_lane_prof[kShadeProfSections + 27], spf.bsdf);
+    }
 #endif
     unsigned long long v_closest = c_closest, v_shadow = c_shadow, v_invalid = acc.invalid, v_bounces = c_bounces;
-    uint32_t v_live = c_live;
+    uint32_t v_live = c_live, v_film = acc.n_put;
     unsigned long long v_traced = c_traced;
     uint32_t v_loads = c_loads, v_shq = c_shq;
 #pragma unroll
@@ -412,13 +458,23 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc, DLaunch lp, WF 
         v_invalid += __shfl_down(v_invalid, off);
         v_bounces += __shfl_down(v_bounces, off);
         v_live += __shfl_down(v_live, off);
+        v_film += __shfl_down(v_film, off);
     }
-    if (lane == 0) {
+    // the live count steers the host (never optional): one atomic per WORKGROUP
+    __shared__ uint32_t s_live[kBlock / 64];
+    if (lane == 0) s_live[tid >> 6] = v_live;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < kBlock / 64; ++k) t += s_live[k];
+        if (t) atomicAdd(&wf.n_live[it], t);
+    }
+    if (lane == 0 && lp.count) {
+        if (v_film) atomicAdd(&wf.counters[CTR_FILM], (unsigned long long) v_film);
         if (v_closest) atomicAdd(&wf.counters[CTR_CLOSEST], v_closest);
         if (v_shadow) atomicAdd(&wf.counters[CTR_SHADOW], v_shadow);
         if (v_invalid) atomicAdd(&wf.counters[CTR_INVALID], v_invalid);
         if (v_bounces) atomicAdd(&wf.counters[CTR_BOUNCES], v_bounces);
-        if (v_live) atomicAdd(&wf.n_live[it], v_live);      // one non-returning atomic per wave per launch
         if (v_traced) atomicAdd(&wf.counters[CTR_TRACED], v_traced);
         if (v_loads) atomicAdd(&wf.counters[CTR_SHADE_LOADS], (unsigned long long) v_loads);
         if (v_live) atomicAdd(&wf.counters[CTR_SHADE_STORES], (unsigned long long) v_live);

@@ -276,6 +276,11 @@ enum {
     BF_FLAG_ROLLING = 32u,     /* bf_render_device only: the render joins the handle's ROLLING SEQUENCE (below, bf_scene_flush) */
     BF_FLAG_TIMING = 64u,      /* rolling sequences: HIP events around every kernel launch; bf_scene_flush's statistics carry
                                   the per-kernel sums (trace_ms / shade_ms / tail_ms).  Set it on every render of the sequence. */
+    BF_FLAG_COUNT = 128u,      /* keep the ray / bounce / path counters of a render that returns no bf_stats of its own (a rolling
+                                  sequence whose flush will be asked for statistics, the shards of bf_render_sharded_device).
+                                  Implied by BF_FLAG_STATS and by a non-NULL stats_out; without any of them the counters stay
+                                  zero — adding them up costs every shading launch ~10 same-line atomics per wave.  Set it on
+                                  every render of a sequence. */
     BF_FLAG_DOPPLER = 8u       /* receive modes: the Doppler hook the reference carries commented out
                                   ("Took doppler out to test", pathtimefrequency.cpp:124-126,141-144,180-183):
                                   the path's wavelength is shifted by Shape::doppler(si) =

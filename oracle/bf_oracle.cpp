@@ -2526,6 +2526,14 @@ void bfo_coordinate_system(const float *n, float *s, float *t) {
     s[0] = a.x; s[1] = a.y; s[2] = a.z;
     t[0] = b.x; t[1] = b.y; t[2] = b.z;
 }
+/* Frame3f(n) — include/mitsuba/core/frame.h:23-26 (s, t = coordinate_system(n)) — then to_local / to_world (:33-41);
+ * out = s.xyz, t.xyz, to_local(v).xyz, to_world(v).xyz */
+void bfo_frame_from_normal(const float *n, const float *v, float *out) {
+    Frame f = frame_from_normal(V3{n[0], n[1], n[2]});
+    V3 a = f.to_local(V3{v[0], v[1], v[2]}), b = f.to_world(V3{v[0], v[1], v[2]});
+    const float r[12] = {f.s.x, f.s.y, f.s.z, f.t.x, f.t.y, f.t.z, a.x, a.y, a.z, b.x, b.y, b.z};
+    for (int k = 0; k < 12; ++k) out[k] = r[k];
+}
 float bfo_bsdf_eval(const bf_material *m, const float *wi, const float *wo) {
     return bsdf_eval(*m, V3{wi[0], wi[1], wi[2]}, V3{wo[0], wo[1], wo[2]});
 }

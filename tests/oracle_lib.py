@@ -54,6 +54,8 @@ def load_from(path):
         getattr(lib, name).argtypes = [C.c_float, C.c_float, vp]
     lib.bfo_square_to_uniform_cone.argtypes = [C.c_float, C.c_float, C.c_float, vp]
     lib.bfo_coordinate_system.argtypes = [vp, vp, vp]
+    lib.bfo_frame_from_normal.argtypes = [vp, vp, vp]
+    lib.bfo_frame_from_normal.restype = None
     lib.bfo_bsdf_eval.argtypes = [C.POINTER(capi.bf_material), vp, vp]
     lib.bfo_bsdf_eval.restype = C.c_float
     lib.bfo_bsdf_pdf.argtypes = [C.POINTER(capi.bf_material), vp, vp]

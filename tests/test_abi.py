@@ -61,3 +61,31 @@ def test_no_device_is_an_error_not_a_fallback():
     sd, _ = scenes.trans_rad(4)
     with pytest.raises(capi.BeifongError, match="no HIP device"):
         capi.Scene(sd)
+
+
+def test_missing_rccl_is_unsupported_not_a_crash():
+    """bf_allreduce_device when librccl cannot be loaded: BF_ERR_UNSUPPORTED with the loader's message (the
+    message was built from TWO dlerror() calls, the second of which returns NULL -> std::string(NULL) -> abort).  RCCL is
+    loaded once per process, so the forced not-found path (BF_RCCL_LIB) runs in a child process; no GPU is touched: the
+    call fails before any device work."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from beifong_amd import capi\n"
+        "lib = capi.load_library()\n"
+        "lib.bf_allreduce_device.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_void_p)]\n"
+        "lib.bf_allreduce_device.restype = C.c_int\n"
+        "devs = (C.c_int * 2)(0, 1)\n"
+        "buf = (C.c_float * 4)()\n"
+        "bufs = (C.c_void_p * 2)(C.addressof(buf), C.addressof(buf))\n"
+        "st = lib.bf_allreduce_device(devs, 2, bufs, 4, None)\n"
+        "print(st, lib.bf_last_error().decode())\n"
+    )
+    env = dict(os.environ, BF_RCCL_LIB="/nonexistent/librccl_missing.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    st, msg = r.stdout.strip().split(" ", 1)
+    assert int(st) == capi.BF_ERR_UNSUPPORTED, r.stdout
+    assert "librccl_missing.so" in msg and "not found" in msg

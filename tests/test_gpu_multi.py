@@ -74,8 +74,29 @@ def test_entry_points_run_on_the_handles_device(hiplib):
     sd, lp = scenes.bus_radar(n_tris=5000, n_paths=4096, bins=64, dr=0.4)
     g = capi.Scene(sd)
     before = torch.cuda.current_device()
-    g.render(lp)
+    h0, r0, _ = g.render(lp, records=True)
     assert torch.cuda.current_device() == before
+    if hiplib.bf_device_count() >= 2:
+        # a handle that lives on ANOTHER GPU than the caller's current one: the host-buffer entries (bf_render, bf_trace_*:
+        # staging buffers allocated before the kernels are launched) must allocate and run there too
+        capi.check(hiplib, hiplib.bf_set_device(1), "bf_set_device")
+        try:
+            g1 = capi.Scene(sd)
+        finally:
+            capi.check(hiplib, hiplib.bf_set_device(before), "bf_set_device")
+        assert g1.info().device == 1
+        h1, r1, _ = g1.render(lp, records=True)
+        assert torch.cuda.current_device() == before
+        assert np.array_equal(r1["L"].view(np.uint32), r0["L"].view(np.uint32)) and np.array_equal(r1["n_rays"], r0["n_rays"])
+        rays = np.zeros((64, 8), dtype=np.float32)
+        rays[:, 0:3] = (0.0, 0.0, 0.3)
+        rays[:, 3] = 1e-4
+        rays[:, 4:7] = (1.0, 0.0, -0.05)
+        rays[:, 7] = np.inf
+        t0 = g.trace_closest(rays)[0]
+        t1 = g1.trace_closest(rays)[0]
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+        assert torch.cuda.current_device() == before
 
 
 def test_host_layer_gpu_count_and_cli(hiplib, tmp_path):

@@ -122,6 +122,45 @@ def test_rolling_heavy_eviction_loses_no_path(hiplib, bins, iters, monkeypatch):
         _close_hist(h[k], hs, n, float(np.abs(rs["L"]).max()))
 
 
+def test_rolling_survivor_area_overrun_is_loud_and_loses_nothing(hiplib, monkeypatch):
+    """The invariant behind the regression above — the survivor batches ONE launch claims are distinct — is checked on the
+    device (surv_take: a per-launch claim count; CTR_SURV_GUARD).  BF_DEBUG_SURV_BATCHES shrinks the survivor area to 16
+    batches and switches the sizing rule off: the same heavy-eviction workload now asks for far more claims per launch than
+    the area has batches.  The claims beyond the area are REFUSED (those paths stay in their slots), so every path is still
+    the stand-alone render's, and the flush with statistics reports the violation as BF_ERR_DEVICE."""
+    monkeypatch.setenv("BF_ROLL_ITERS", "1")
+    monkeypatch.setenv("BF_DEBUG_SURV_BATCHES", "16")
+    n = 1 << 17
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=n, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    seeds = list(range(100, 106))
+    seq = _Sequence(g, lp, seeds)
+    seq.issue()
+    with pytest.raises(capi.BeifongError) as e:
+        g.flush(want_stats=True)
+    assert "survivor" in str(e.value)
+    g.sync()                                   # reported once: the sticky word is clear again
+    h, recs = seq.results()
+    assert [float(hk[4]) for hk in h] == [float(n)] * len(seeds)          # nothing lost
+    monkeypatch.delenv("BF_DEBUG_SURV_BATCHES")
+    g2 = capi.Scene(sd)
+    for k in (0, 3, 5):
+        hs, rs, _ = g2.render(_launch_like(lp, seeds[k]), records=True)
+        _same_records(recs[k], rs)
+
+
+def test_rolling_flush_statistics_count_every_path(hiplib):
+    """bf_scene_flush with statistics checks that every path of every render of the sequence was binned exactly once
+    (CTR_FILM == paths supplied); a healthy sequence passes and reports the sequence's totals."""
+    n = 1 << 15
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=n, bins=256, dr=0.1)
+    g = capi.Scene(sd)
+    seq = _Sequence(g, lp, [1, 2, 3, 4, 5], extra_flags=capi.BF_FLAG_COUNT)
+    seq.issue()
+    st = g.flush(want_stats=True)
+    assert st.n_paths == 5 * n and st.n_guard == 0 and st.n_rays_closest >= 5 * n
+
+
 def test_rolling_receive_sequence_and_second_sequence(hiplib):
     """gen-3 receive (the RX = 1 kernels) with I/Q; a second sequence on the same handle after the flush starts afresh."""
     sd, lp = scenes.bus_receive(n_tris=20000, n_paths=20000, t_bins=256, dr=0.1)

@@ -84,6 +84,87 @@ def test_coordinate_system_orthonormal(oracle):
         assert np.allclose(np.cross(s, t), n, atol=1e-6)
 
 
+def _coordinate_system(oracle, n):
+    n = np.asarray(n, f32)
+    s, t = np.zeros(3, f32), np.zeros(3, f32)
+    oracle.bfo_coordinate_system(n.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+    return s, t
+
+
+def test_coordinate_system_known_answer_and_duff_basis(oracle):
+    """src/libcore/tests/test_vector.py:7-38 as written: the SIGN convention of coordinate_system (vector.h:116-136), which
+    the orthonormality test above cannot see — ([sqrt(1/2), 0, sqrt(1/2)]) -> ([.7071, -0, -.7071], [-0, 1, 0]) — and
+    equality with the branchless basis of Duff et al. over a 10 x 10 grid of square_to_uniform_sphere directions
+    (warp.h:233-243: z = 1 - 2 v, r = sqrt(1 - z^2), (r cos 2 pi u, r sin 2 pi u, z))."""
+    def branchless_onb(n):
+        sign = np.copysign(1.0, n[2])
+        a = -1.0 / (sign + n[2])
+        b = n[0] * n[1] * a
+        return (np.array([1.0 + sign * n[0] * n[0] * a, sign * b, -sign * n[0]]), np.array([b, sign + n[1] * n[1] * a, -n[1]]))
+
+    r = np.sqrt(0.5)
+    s, t = _coordinate_system(oracle, [r, 0, r])
+    assert np.allclose(s, [0.70710678, -0.0, -0.70710678], atol=1e-6) and np.allclose(t, [-0.0, 1.0, 0.0], atol=1e-6)
+    s1, t1 = branchless_onb(np.array([r, 0, r]))
+    assert np.allclose(s1, [0.70710678, -0.0, -0.70710678], atol=1e-6) and np.allclose(t1, [-0.0, 1.0, 0.0], atol=1e-6)
+    for u in np.linspace(0, 1, 10):
+        for v in np.linspace(0, 1, 10):
+            z = 1.0 - 2.0 * v
+            rr = np.sqrt(max(0.0, 1.0 - z * z))
+            n = np.array([rr * np.cos(2 * np.pi * u), rr * np.sin(2 * np.pi * u), z])
+            if abs(z + 1.0) < 1e-9:
+                continue              # n = (0, 0, -1): a = -1 / 0 in BOTH forms (the reference's loop hits it too: inf / nan compare unequal there)
+            s1, t1 = branchless_onb(n)
+            s2, t2 = _coordinate_system(oracle, n)
+            assert np.allclose(s1, s2, atol=2e-6) and np.allclose(t1, t2, atol=2e-6), (n, s1, s2)
+
+
+def _frame(oracle, n, v):
+    n, v = np.asarray(n, f32), np.asarray(v, f32)
+    out = np.zeros(12, f32)
+    oracle.bfo_frame_from_normal(n.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return dict(s=out[0:3], t=out[3:6], to_local=out[6:9], to_world=out[9:12])
+
+
+def test_frame_known_answers(oracle):
+    """src/libcore/tests/test_frame.py:6-60 on the oracle's Frame (frame.h): Frame3f(n) completes n by coordinate_system —
+    Frame3f([0, 0, 1]) is the identity frame (:19-23, :55-60: it EQUALS Frame3f([1,0,0],[0,1,0],[0,0,1]), which fixes the
+    handedness) — and to_world(to_local(v)) = v for the frame around normalize(1, 2, 3) at theta = 30 and 95 degrees,
+    phi = 73 degrees (:29-47); cos_theta(v) = v.z of the local vector (:49)."""
+    f = _frame(oracle, [0, 0, 1], [0.25, -0.5, 2.0])
+    assert np.array_equal(f["s"], np.array([1, 0, 0], f32)) and np.array_equal(f["t"], np.array([0, 1, 0], f32))
+    assert np.array_equal(f["to_local"], np.array([0.25, -0.5, 2.0], f32)) and np.array_equal(f["to_world"], np.array([0.25, -0.5, 2.0], f32))
+    n = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    for theta in (30 * np.pi / 180, 95 * np.pi / 180):
+        phi = 73 * np.pi / 180
+        v = np.array([np.cos(phi) * np.sin(theta), np.sin(phi) * np.sin(theta), np.cos(theta)])
+        f = _frame(oracle, n, v)
+        # right-handed and orthonormal: t = n x s, s x t = n
+        assert np.allclose(np.cross(n, f["s"]), f["t"], atol=1e-6) and np.allclose(np.cross(f["s"], f["t"]), n, atol=1e-6)
+        back = _frame(oracle, n, f["to_local"])["to_world"]
+        assert np.allclose(back, v, atol=1e-6)
+        assert np.isclose(f["to_local"][2], np.dot(v, n), atol=1e-6)          # Frame3f::cos_theta of the local vector
+
+
+def test_surface_interaction_frame_and_wi():
+    """The part of src/librender/tests/test_interaction.py:6-108 that exists on the radar path: test01 pins the FIELDS of a
+    SurfaceInteraction (t, p, n, sh_frame, dp_du, dp_dv, wi — bf_ray_intersect returns exactly these), test02 pins
+    compute_uv_partials, which needs ray differentials and texture lookups — neither is on the path (constant spectra), so
+    it has no counterpart.  Pinned here on a mesh hit: wi = sh_frame.to_local(-d) (interaction.h:640), sh_frame
+    right-handed with n (initialize_sh_frame, :159-162), p = o + t d."""
+    v, f = meshgen.rectangle_obj()
+    o = OracleScene(scenes.single_mesh(v, f))
+    d = np.array([0.03, -0.02, 1.0])
+    d /= np.linalg.norm(d)
+    org = np.array([-0.3, -0.3, -10.0])
+    r = o.intersect_full([*org, capi_eps(), *d, np.inf])
+    assert np.allclose(r["p"], org + r["t"] * d, atol=1e-5) and abs(r["p"][2]) < 1e-5
+    s, t, n = r["sh_s"], r["sh_t"], r["sh_n"]
+    assert np.allclose(np.cross(n, s), t, atol=1e-6) and np.allclose(np.cross(s, t), n, atol=1e-6)
+    assert np.allclose(r["wi"], [np.dot(-d, s), np.dot(-d, t), np.dot(-d, n)], atol=1e-6)
+    assert r["wi"][2] < 0          # the ray arrives from below the geometric normal (+z): the BSDFs' one-sided test sees it
+
+
 def _rect_scene(to_world):
     sd = SceneDesc()
     m = sd.add_diffuse(0.5)

@@ -47,3 +47,8 @@ tn = ["cursor + gather", "state / hit load", "vertex + film_put", "generate_path
 print("wave cycles between stamps (s_memtime ticks), share of the total:")
 for k in range(7):
     print(f"  {tn[k]:20s} {t[k] / t[:7].sum():6.3f}")
+v = l[24:28]
+if v.sum():
+    print("inside vertex + film_put (largest lane of a wave; the rest of that share is film_put and lanes that end early):")
+    for k, nm in enumerate(["surface interaction (+ wait for the triangle / material)", "head (emitter, roulette)", "next-event estimation", "BSDF sampling + spawn"]):
+        print(f"  {nm:58s} {v[k] / t[:7].sum():6.3f}")
