@@ -146,6 +146,7 @@ struct bf_tunables {
     int wide_rows_log = -1;
     bool lean = true;                        // BF_LEAN=0: never use the kernels' lean variants (bf_device.h: kLean)
     bool tab_cache = true;                   // BF_TAB_CACHE=0: materials / rectangles stay in device memory (no LDS copies)
+    bool roll_join = true;                   // BF_ROLL_JOIN=0: bf_scene_update_endpoints flushes an open rolling sequence (round 3's behaviour)
     uint32_t debug_surv_batches = 0;         // BF_DEBUG_SURV_BATCHES (tests): size of the survivor area in batches, sizing rule off
 };
 static bf_tunables read_tunables() {
@@ -177,6 +178,7 @@ static bf_tunables read_tunables() {
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
     t.lean = num("BF_LEAN", 1) != 0;
     t.tab_cache = num("BF_TAB_CACHE", 1) != 0;
+    t.roll_join = num("BF_ROLL_JOIN", 1) != 0;
     t.debug_surv_batches = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_DEBUG_SURV_BATCHES", 0), 1 << 14));
     return t;
 }
@@ -242,10 +244,26 @@ struct bf_scene {
         uint32_t iters = 0;                      // bounce iterations per call (adapted from the live counts)
         uint32_t flush_iters = 0;                // planned bounce iterations of a flush before its tail (learned)
         uint32_t flush_live = 0;                 // slots alive at the flush's tail (learned: sizes its grid)
+        bool multi = false;                      // the endpoints moved between the renders of the sequence (kMulti kernels from then on)
         uint32_t fb_call_iters = 0;              // iterations of the call whose live counts are in flight to wf_feedback
         bool fb_is_flush = false;
     };
     mutable Roll roll;
+    // Endpoint-table versions of an open rolling sequence: bf_scene_update_endpoints writes the new tables into the next block of
+    // a pool instead of flushing the sequence (the renders issued so far keep reading theirs through the descriptor ring:
+    // bf_device.h: DRoll, kMulti); the home buffers (as created) hold the tables whenever no sequence is open.
+    struct TabLayout {
+        size_t o_rects = 0, o_shapes = 0, o_emit = 0, o_mat = 0, o_sensor = 0, stride = 0;
+    };
+    mutable TabLayout tab;
+    mutable char *tab_pool = nullptr;            // device: kRollRing blocks of tab.stride bytes (allocated on first use)
+    mutable uint32_t tab_next = 0;               // next free block
+    mutable bool tables_in_pool = false;         // d.rects ... d.sensor point into the pool
+    const bfd::DRect *home_rects = nullptr;
+    const bfd::DShape *home_shapes = nullptr;
+    const bfd::DEmitter *home_emitters = nullptr;
+    const bfd::DMaterial *home_materials = nullptr;
+    const bfd::DSensor *home_sensor = nullptr;
     mutable bfd::DRoll *roll_ring = nullptr;     // device [kRollRing]
     mutable float4 *roll_offsets = nullptr;      // device [kRollRing]: mesh offset of every render of the sequence
     // Launch plan learned from the previous render of the same shape (wf_render): how many bounce
@@ -371,6 +389,7 @@ bf_status bf_scene_destroy(bf_scene *s) {
     if (s->last_done) (void) hipEventDestroy(s->last_done);
     for (hipEvent_t e : s->wf_timing) (void) hipEventDestroy(e);
     if (s->counters) (void) hipFree(s->counters);
+    if (s->tab_pool) (void) hipFree(s->tab_pool);
     for (auto &st : s->stage) {
         if (st.ev) {
             (void) hipEventSynchronize(st.ev);
@@ -884,6 +903,11 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     std::vector<bfd::DSensor> sensor_vec(1, flat.sensor);
     UP(sensor_vec, sensor);
 #undef UP
+    sc->home_rects = sc->d.rects;
+    sc->home_shapes = sc->d.shapes;
+    sc->home_emitters = sc->d.emitters;
+    sc->home_materials = sc->d.materials;
+    sc->home_sensor = sc->d.sensor;
     sc->n_materials = desc->n_materials;
     sc->d.n_materials = desc->n_materials;
     sc->d.tab_cache = (sc->tun.tab_cache && desc->n_materials <= bfd::kTabMaxMaterials && rects.size() <= bfd::kTabMaxRects) ? 1u : 0u;
@@ -951,10 +975,19 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
                     (double) scene->origin_scale_built);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BF_ENTER(scene);
+    // The paths of an open rolling sequence belong to the endpoints as they are.  Round 3 finished them first (a flush: one
+    // tail per frame of a sweep whose radar turns — the loop the reference ships).  Now the update JOINS the sequence: the
+    // new tables go into the next block of the handle's pool, the renders issued so far keep reading theirs through the
+    // descriptor ring (kMulti kernels).  Phased arrays (their element tables are replaced in place), wide reconstruction
+    // filters (no kMulti | kWide kernels), another stream or a full pool fall back to the flush.
+    bool phased = f.sensor.type == BF_RECEIVER_PHASED || scene->sensor_array_dev != nullptr;
+    for (const auto &e : f.emitters) phased = phased || e.type == BF_TRANSMITTER_PHASED;
+    for (float *p : scene->array_dev) phased = phased || p != nullptr;
+    const bool join = scene->roll.open && scene->roll.stream == stream && !phased && scene->sensor_host.filt_n == 0u && f.sensor.filt_n == 0u &&
+                      scene->tab_next + 1u < bfd::kRollRing && scene->tun.roll_join;
     {
-        // the paths of an open rolling sequence belong to the endpoints as they are: finish them first
         bf_status ost = order_after_last(scene, stream);
-        if (ost == BF_OK) ost = close_sequence(scene, stream);
+        if (ost == BF_OK && !join) ost = close_sequence(scene, stream);
         if (ost != BF_OK) return ost;
     }
     {
@@ -971,6 +1004,27 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
         const size_t o_rects = 0, o_shapes = o_rects + up16(b_rects), o_emit = o_shapes + up16(b_shapes), o_mat = o_emit + up16(b_emit),
                      o_sensor = o_mat + up16(b_mat), total = o_sensor + up16(b_sensor);
+        // where the tables go: the home buffers, or — joining an open sequence — the next block of the pool (same layout as the
+        // staging slot)
+        char *dst_rects = (char *) scene->home_rects, *dst_shapes = (char *) scene->home_shapes, *dst_emit = (char *) scene->home_emitters,
+             *dst_mat = (char *) scene->home_materials, *dst_sensor = (char *) scene->home_sensor;
+        if (join) {
+            if (!scene->tab_pool) {
+                scene->tab.o_rects = o_rects;
+                scene->tab.o_shapes = o_shapes;
+                scene->tab.o_emit = o_emit;
+                scene->tab.o_mat = o_mat;
+                scene->tab.o_sensor = o_sensor;
+                scene->tab.stride = (total + 255) & ~size_t(255);
+                HIP_TRY(hipMalloc((void **) &scene->tab_pool, scene->tab.stride * bfd::kRollRing));
+            }
+            char *blk = scene->tab_pool + scene->tab.stride * scene->tab_next;
+            dst_rects = blk + o_rects;
+            dst_shapes = blk + o_shapes;
+            dst_emit = blk + o_emit;
+            dst_mat = blk + o_mat;
+            dst_sensor = blk + o_sensor;
+        }
         bf_scene::Stage *stg = nullptr;
         bf_status sst = stage_acquire(scene, total, &stg);
         if (sst != BF_OK) return sst;
@@ -985,13 +1039,27 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
             std::memcpy(h + o_mat + (size_t) i * sizeof(dm), &dm, sizeof(dm));
         }
         std::memcpy(h + o_sensor, &f.sensor, b_sensor);
-        if (b_rects) HIP_TRY(hipMemcpyAsync((void *) scene->d.rects, h + o_rects, b_rects, hipMemcpyHostToDevice, stream));
-        if (b_shapes) HIP_TRY(hipMemcpyAsync((void *) scene->d.shapes, h + o_shapes, b_shapes, hipMemcpyHostToDevice, stream));
-        if (b_emit) HIP_TRY(hipMemcpyAsync((void *) scene->d.emitters, h + o_emit, b_emit, hipMemcpyHostToDevice, stream));
-        if (b_mat) HIP_TRY(hipMemcpyAsync((void *) scene->d.materials, h + o_mat, b_mat, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync((void *) scene->d.sensor, h + o_sensor, b_sensor, hipMemcpyHostToDevice, stream));
+        if (join) {
+            HIP_TRY(hipMemcpyAsync(dst_rects, h, total, hipMemcpyHostToDevice, stream));      // one block, the staging slot's layout
+        } else {
+            if (b_rects) HIP_TRY(hipMemcpyAsync(dst_rects, h + o_rects, b_rects, hipMemcpyHostToDevice, stream));
+            if (b_shapes) HIP_TRY(hipMemcpyAsync(dst_shapes, h + o_shapes, b_shapes, hipMemcpyHostToDevice, stream));
+            if (b_emit) HIP_TRY(hipMemcpyAsync(dst_emit, h + o_emit, b_emit, hipMemcpyHostToDevice, stream));
+            if (b_mat) HIP_TRY(hipMemcpyAsync(dst_mat, h + o_mat, b_mat, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(dst_sensor, h + o_sensor, b_sensor, hipMemcpyHostToDevice, stream));
+        }
         sst = stage_release_after(stg, stream);
         if (sst != BF_OK) return sst;
+        scene->d.rects = b_rects ? (const bfd::DRect *) dst_rects : scene->d.rects;
+        scene->d.shapes = b_shapes ? (const bfd::DShape *) dst_shapes : scene->d.shapes;
+        scene->d.emitters = b_emit ? (const bfd::DEmitter *) dst_emit : scene->d.emitters;
+        scene->d.materials = b_mat ? (const bfd::DMaterial *) dst_mat : scene->d.materials;
+        scene->d.sensor = (const bfd::DSensor *) dst_sensor;
+        if (join) {
+            ++scene->tab_next;
+            scene->tables_in_pool = true;
+            scene->roll.multi = true;
+        }
     }
     scene->sensor_host = f.sensor;
     scene->film_w = desc->sensor.film_width;
@@ -1193,6 +1261,11 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
         if (e == hipSuccess) e = hipMemset(sc->counters, 0, sizeof(unsigned long long) * bfd::CTR_COUNT);
         if (e != hipSuccess) return fail_out(fail(BF_ERR_DEVICE, "bf_scene_clone: counters: %s", hipGetErrorString(e)));
     }
+    sc->home_rects = sc->d.rects;
+    sc->home_shapes = sc->d.shapes;
+    sc->home_emitters = sc->d.emitters;
+    sc->home_materials = sc->d.materials;
+    sc->home_sensor = sc->d.sensor;
     *out = sc;
     return BF_OK;
 }
@@ -1614,6 +1687,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.lp.box_slack = 0.f;
         r.lp.has_records = 0u;
         r.per_call = K;
+        r.multi = false;
         r.offsets = with_offsets;
         r.dmax = 0.f;
         r.count = 0;
@@ -1633,6 +1707,11 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
     const uint32_t k = r.count, newest = k + K - 1u;
     bfd::DLaunch &lp = r.lp;
     lp.n_paths = (uint64_t) (k + K) * lp.batch_paths;
+    if (r.multi) {                 // the endpoints moved since the sequence was opened: per-path tables from now on (general kernels)
+        lp.multi = 1u;
+        lp.lean = 0u;
+        scene->last_variant = 0u;
+    }
     lp.roll_newest = newest;
     lp.roll_lo = newest + 1u > r.window ? newest + 1u - r.window : 0u;
     lp.n_chan_all = (lp.roll_newest - lp.roll_lo + 1u) * lp.n_chan;
@@ -1668,6 +1747,15 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         d.path_offset = launch->path_offset;
         d.hist = hist_dev + (size_t) j * n_chan1;
         d.records = records_dev ? records_dev + (size_t) j * lp.batch_paths : nullptr;
+        d.rects = scene->d.rects;                 // the endpoint tables as they stand for THIS render (kMulti kernels)
+        d.shapes = scene->d.shapes;
+        d.emitters = scene->d.emitters;
+        d.materials = scene->d.materials;
+        d.sensor = scene->d.sensor;
+        d.c = scene->d.c;
+        d.lambda_min = scene->d.lambda_min;
+        d.lambda_max = scene->d.lambda_max;
+        d.pad = 0u;
         HIP_TRY(bfk_roll_set(scene->roll_ring, scene->roll_offsets, (k + j) & (bfd::kRollRing - 1u), &d,
                              with_offsets ? batch->mesh_offsets + 3 * j : nullptr, stream));
     }
@@ -1792,6 +1880,27 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
     scene->wf_iters += done_iters;
     scene->wf_trace_launches += done_iters;
     r.open = false;
+    if (scene->tables_in_pool) {
+        // the sequence's last table version becomes the handle's tables again (home buffers), behind the flush's kernels
+        const bf_scene::TabLayout &t = scene->tab;
+        const char *blk = (const char *) scene->d.rects - t.o_rects;
+        const uint32_t nr = scene->d.n_rects, ne = scene->d.n_emitters, ns = scene->info.n_shapes, nm = scene->n_materials;
+        if (nr) HIP_TRY(hipMemcpyAsync((void *) scene->home_rects, blk + t.o_rects, nr * sizeof(bfd::DRect), hipMemcpyDeviceToDevice, stream));
+        if (ns) HIP_TRY(hipMemcpyAsync((void *) scene->home_shapes, blk + t.o_shapes, ns * sizeof(bfd::DShape), hipMemcpyDeviceToDevice, stream));
+        if (ne) HIP_TRY(hipMemcpyAsync((void *) scene->home_emitters, blk + t.o_emit, ne * sizeof(bfd::DEmitter), hipMemcpyDeviceToDevice, stream));
+        if (nm) HIP_TRY(hipMemcpyAsync((void *) scene->home_materials, blk + t.o_mat, nm * sizeof(bfd::DMaterial), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((void *) scene->home_sensor, blk + t.o_sensor, sizeof(bfd::DSensor), hipMemcpyDeviceToDevice, stream));
+        bfd::DScene &d = const_cast<bf_scene *>(scene)->d;
+        d.rects = scene->home_rects;
+        d.shapes = scene->home_shapes;
+        d.emitters = scene->home_emitters;
+        d.materials = scene->home_materials;
+        d.sensor = scene->home_sensor;
+        scene->tables_in_pool = false;
+        scene->tab_next = 0;
+    }
+    r.multi = false;
+    lp.multi = 0u;
     if (sync_timing) return wf_collect_timing(scene, stream);
     return BF_OK;
 }

@@ -84,7 +84,11 @@ struct DEmitter {
 //             modes) or the omnidirectional receiver (receive modes), the 1 x 1 film, no time-resolved mode, no phase bins, no
 //             Doppler hook, no mix_resample.  The code for everything outside the profile is compiled out: wf_shade 168 -> 159
 //             VGPRs, a quarter fewer scalar spills, -4.5 % of its time on C2 (profiles/r03_lean_variant_ab.txt).
-constexpr int kModeMask = 3, kWide = 4, kLean = 8;
+//   kMulti    a rolling sequence whose ENDPOINTS moved between its renders (bf_scene_update_endpoints joined it: DLaunch::multi):
+//             every path reads the rectangle / shape / emitter / material / sensor tables of ITS render through the
+//             sequence's descriptor ring (DRoll) — per-lane pointers, so those reads are vector loads — instead of the
+//             launch's kernel arguments
+constexpr int kModeMask = 3, kWide = 4, kLean = 8, kMulti = 16;
 // rare<V>(c): a condition the lean profile guarantees to be false
 template <int V> __device__ __forceinline__ constexpr bool rare(bool c) { return (V & kLean) ? false : c; }
 
@@ -174,7 +178,18 @@ struct DRoll {
     uint64_t seed, path_offset;
     float *hist;                // this render's histogram (device)
     bf_path_record *records;    // this render's per-path records (device) or nullptr
+    // the endpoint tables and physics the render was issued with (kMulti kernels: the radar turns between the frames of a
+    // sweep — python_scripts/animated_trans_rad.py:307-384, Receive.ipynb cell 30 — while its earlier frames' long paths
+    // are still in flight)
+    const DRect *rects;
+    const DShape *shapes;
+    const DEmitter *emitters;
+    const DMaterial *materials;
+    const DSensor *sensor;
+    float c, lambda_min, lambda_max;
+    uint32_t pad;
 };
+static_assert(sizeof(DRoll) == 88, "descriptor ring entry");
 constexpr uint32_t kRollRing = 256;    // renders per sequence (descriptor ring; the host flushes a longer one in between)
 constexpr uint32_t kRollWindow = 4;    // newest renders whose histogram blocks a workgroup privatises in LDS; older ones take global atomics
 constexpr uint32_t kRollBase = 32;     // newest renders whose five BASE channels (X, Y, Z, alpha, weight: one address each per render, so
@@ -213,6 +228,7 @@ struct DLaunch {
     uint32_t has_records;           // rolling sequence: some render of it writes per-path records (DRoll::records)
     uint32_t lean;                  // 1: scene and launch fit the lean profile: the kernels' kLean variants
     uint32_t wide;                  // 1: the sensor's reconstruction filter is wider than a pixel (DSensor::filt_n != 0): the kernels' kWide variants
+    uint32_t multi;                 // 1: the rolling sequence carries more than one version of the endpoint tables: the kernels' kMulti variants
     uint32_t count;                 // 1: somebody will read the statistics counters (BF_FLAG_STATS, or a render with stats_out): wf_shade and
                                     // the tail add theirs up — ten same-line atomics per WAVE, ~15 us each per launch at the end of a
                                     // persistent grid whose waves all finish together; 0: only the live count the host steers by

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     const int lane = tid & 63;
     const bool lds_hist = lp.lds_hist != 0;
     DScene sc = sc_arg;
+    if (VX & kMulti) sc.tab_cache = 0u;
     load_tables_lds(sc, (uint32_t) (sizeof(int) * kStackDepth * kBlock) + ((4u * lp.lds_floats + 15u) & ~15u), (uint32_t) tid);
     if (lp.lds_floats || sc.tab_on) {
         for (uint32_t i = tid; i < lp.lds_floats; i += kBlock) s_hist[i] = 0.f;
@@ -208,10 +209,12 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
                 const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
                 const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
                 const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
-                const Shift jshift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
+                const uint32_t jrender = (uint32_t) __shfl((int) s.render, src);
+                const Shift jshift = path_shift(lp, jrender);
+                const DScene scj = path_scene<kRX>(sc, lp, jrender);      // (kMulti: the rectangles of the job's render)
                 Hit qbest;
                 bool qfound;
-                traverse_row16<STATS>(sc, rlog, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
+                traverse_row16<STATS>(scj, rlog, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
                                       job_any ? smaxt : cmaxt, s_stack, qbest, qfound, c_wnodes, c_tris, jshift
 #ifdef BF_TAIL_PROF
                                       , pf_row
@@ -258,10 +261,12 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             const V3 so = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
             const V3 sd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
             const float smint = __shfl(sh.mint, src), smaxt = __shfl(sh.maxt, src);
-            const Shift jshift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
+            const uint32_t jrender = (uint32_t) __shfl((int) s.render, src);
+            const Shift jshift = path_shift(lp, jrender);
+            const DScene scj = path_scene<kRX>(sc, lp, jrender);
             Hit qbest;
             bool qfound;
-            traverse_quad<STATS, SPILL>(sc, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
+            traverse_quad<STATS, SPILL>(scj, job_active, job_any, job_any ? so : co, job_any ? sd : cd, job_any ? smint : cmint,
                                         job_any ? smaxt : cmaxt, s_stack + (tid & ~3), qbest, qfound, c_nodes, c_tris, jshift);
             const unsigned long long below = (1ull << lane) - 1ull;
             // deliver: closest hits to their lanes, occlusion verdicts to the requesters
@@ -299,7 +304,9 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             V3 ho = mk(__shfl(sh.o.x, src), __shfl(sh.o.y, src), __shfl(sh.o.z, src));
             V3 hd = mk(__shfl(sh.d.x, src), __shfl(sh.d.y, src), __shfl(sh.d.z, src));
             const float hmint = __shfl(sh.mint, src), hmaxt = __shfl(sh.maxt, src);
-            const Shift own_shift = path_shift(lp, s.render), helper_shift = path_shift(lp, (uint32_t) __shfl((int) s.render, src));
+            const uint32_t hrender = (uint32_t) __shfl((int) s.render, src);
+            const Shift own_shift = path_shift(lp, s.render), helper_shift = path_shift(lp, hrender);
+            const DScene sc_own = path_scene<kRX>(sc, lp, s.render), sc_first = path_scene<kRX>(sc, lp, trace_closest ? s.render : hrender);
             // first walk: closest-hit rays, delegated shadow rays (on their helpers), and the own shadow
             // ray of a lane that has no closest-hit ray to trace
             const bool own_first = sh.want && !delegated && !trace_closest;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
                 V3 o1 = trace_closest ? s.ro : ho, d1 = trace_closest ? s.rd : hd;
                 float mint1 = trace_closest ? s.rmint : hmint, maxt1 = trace_closest ? s.rmaxt : hmaxt;
                 Hit h1;
-                r1 = traverse_dyn<STATS, SPILL>(sc, any1, o1, d1, mint1, maxt1, stack, h1, c_nodes, c_tris,
+                r1 = traverse_dyn<STATS, SPILL>(sc_first, any1, o1, d1, mint1, maxt1, stack, h1, c_nodes, c_tris,
                                                 trace_closest ? own_shift : helper_shift);
                 if (trace_closest) {
                     hit = h1;
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             if (__ballot(own_second)) {
                 if (own_second) {
                     Hit tmp;
-                    occluded = traverse<true, STATS, SPILL>(sc, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris, own_shift);
+                    occluded = traverse<true, STATS, SPILL>(sc_own, sh.o, sh.d, sh.mint, sh.maxt, stack, tmp, c_nodes, c_tris, own_shift);
                     ++c_shadow;
                 }
             }
@@ -337,7 +344,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
             sh.want = false;
         } else if (__ballot(trace_closest)) {
             if (trace_closest) {
-                traverse<false, STATS, SPILL>(sc, s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris, path_shift(lp, s.render));
+                traverse<false, STATS, SPILL>(path_scene<kRX>(sc, lp, s.render), s.ro, s.rd, s.rmint, s.rmaxt, stack, hit, c_nodes, c_tris,
+                                              path_shift(lp, s.render));
                 ++c_closest;
             }
         }
@@ -586,7 +594,10 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
     unsigned long long *counters = wf->counters;
     const bool two = tail_waves == 2;
 #define BF_TAIL_LAUNCH(S, P)                                                                                                           \
-    if (lp->wide)                                                                                                                      \
+    if (lp->multi)                                                                                                                     \
+        hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, bfd::kMulti>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc, \
+                           *lp, g_hist, records, counters, *wf, it);                                                                  \
+    else if (lp->wide)                                                                                                                      \
         hipLaunchKernelGGL((bfd::bf_render_kernel<S, true, P, 3, bfd::kWide>), dim3(grid), dim3(bfd::kBlock), lds_bytes, stream, *sc,  \
                            *lp, g_hist, records, counters, *wf, it);                                                                  \
     else if (lp->lean && !two)                                                                                                         \

@@ -91,6 +91,24 @@ BF_DEV float shape_doppler(const DScene &sc, const SI &si, float lambda_nm) {
     V3 q = xf_point(c_shapes(sc)[si.shape].velocity, to_local(si.sh, si.p));
     return 2.f * dot(si.wi, q) / sc.c * lambda_nm;
 }
+// The scene a path of render `render` sees.  Plain launches and sequences whose endpoints stand still: the launch's own
+// (wave-uniform: the tables are read through the scalar cache).  kMulti: the table pointers and physics of the path's render out
+// of the descriptor ring — a per-lane record, so everything read through them is a vector load.
+template <int V> BF_DEV DScene path_scene(const DScene &sc, const DLaunch &lp, uint32_t render) {
+    if (!(V & kMulti)) return sc;
+    DScene r = sc;
+    const BF_CAS DRoll &e = as_const(lp.roll)[render & (kRollRing - 1u)];
+    r.rects = e.rects;
+    r.shapes = e.shapes;
+    r.emitters = e.emitters;
+    r.materials = e.materials;
+    r.sensor = e.sensor;
+    r.c = e.c;
+    r.lambda_min = e.lambda_min;
+    r.lambda_max = e.lambda_max;
+    r.tab_on = 0u;                 // (the workgroup's LDS copies hold one version)
+    return r;
+}
 // the mesh shift of the path's render (batched launches with moving meshes; off otherwise)
 BF_DEV Shift path_shift(const DLaunch &lp, uint32_t render) { return make_shift(lp.batch_offsets, render, lp.box_slack); }
 
@@ -416,7 +434,7 @@ template <int RX> BF_DEV bool mode_receive(const DLaunch &lp) { return (RX & kMo
 // ---------------------------------------------------------------------------
 // path generation
 // ---------------------------------------------------------------------------
-template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch &lp, uint64_t path_i, PathState &s) {
+template <int RX = 2> BF_DEV void generate_path(const DScene &sc0, const DLaunch &lp, uint64_t path_i, PathState &s) {
     const bool receive = mode_receive<RX>(lp);
     s.path_i = path_i;
     s.render = 0u;
@@ -433,6 +451,7 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc, const DLaunch 
             seed = lp.batch_seeds[s.render];
         }
     }
+    const DScene sc = path_scene<RX>(sc0, lp, s.render);
     // per-path stream: sampler->seed(base_seed + path) (sampler.cpp:83-96)
     pcg_seed(s.rng, seed + path_offset + path_i);
     float fx = next_1d(s.rng), fy = next_1d(s.rng);
@@ -554,9 +573,10 @@ static __device__ unsigned long long g_lane_prof[2 * kShadeProfSections];      /
 #define SLP(sec, cond)
 #endif
 template <int RX = 2>
-BF_DEV bool shade_vertex(const DScene &sc, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
+BF_DEV bool shade_vertex(const DScene &sc0, const DLaunch &lp, PathState &s, const Hit &hit, ShadowReq &sh,
                          uint32_t &c_bounces BF_SHADEPROF_ARG BF_LANEPROF_ARG) {
     BF_SHADEPROF_STAMP(spf_t0);
+    const DScene sc = path_scene<RX>(sc0, lp, s.render);
     const bool receive = mode_receive<RX>(lp);
     const bool is_range = !receive && lp.mode == BF_MODE_RANGE, is_time = rare<RX>(!receive && lp.mode == BF_MODE_TIME);
     const bool iq = receive && lp.iq != 0u;
@@ -885,8 +905,9 @@ BF_DEV void film_position(const DLaunch &lp, const PathState &s, uint32_t &px, u
 }
 
 template <int RX = 2>
-BF_DEV void film_put(const DScene &sc, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
+BF_DEV void film_put(const DScene &sc0, const DLaunch &lp, const PathState &s, float *s_hist, float *g_hist, bool lds_hist,
                      FilmAcc &acc, bf_path_record *records) {
+    const DScene sc = path_scene<RX>(sc0, lp, s.render);
     const bool valid = (s.flags & kFlagValid) != 0;
 #ifndef BF_NO_FILM_CTR
     ++acc.n_put;
@@ -1150,6 +1171,9 @@ template <int RX = 2> BF_DEV void film_flush(const DLaunch &lp, FilmAcc &acc, fl
             hist_add(hd.s, hd.g, hd.lds, 4, acc.W);
         }
     }
+#ifdef BF_NO_FLUSH      // developer timing probe: what the flush of the LDS histograms costs (the histograms stay empty)
+    return;
+#endif
     if (lds_hist) {
         __syncthreads();
         if (lp.roll) {

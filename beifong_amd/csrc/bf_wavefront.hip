@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
     float *s_hist = reinterpret_cast<float *>(s_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     DScene sc = sc_arg;
+    if (RX & kMulti) sc.tab_cache = 0u;      // several versions of the tables in flight (path_scene): no LDS copy of one of them
     load_tables_lds(sc, (4u * lp.lds_floats + 15u) & ~15u, (uint32_t) tid);      // materials + rectangles behind the histogram
     constexpr bool WALK = FIRST == 0 || FIRST == 3;      // the launch walks the alive masks (else: whole batches of main slots)
     constexpr bool EVICT = FIRST == 3;                   // ... and moves long paths to the survivor area (own variant: the
@@ -326,12 +327,13 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
                 tracing = cont && !(s.flags & kFlagTermPending);
                 shadowing = cont && sh.want;
                 const Shift shf = path_shift(lp, s.render);
+                const DScene scp = path_scene<RX>(sc, lp, s.render);      // (kMulti: the rectangles of the path's own render)
                 SLP(7, shadowing);
                 SLP(8, tracing);
                 if (shadowing) {
                     Hit tmp;
                     bool found;
-                    if (!presolve_ray(sc, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found, shf)) {
+                    if (!presolve_ray(scp, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found, shf)) {
                         // Scene::sample_emitter_direction zeroes the VALUE of an occluded sample (scene.cpp:220-224) and
                         // the integrator still adds mis * throughput * bsdf * 0: a NaN / inf BSDF value survives that
                         // product.  c * 0 is that term (+-0 for every finite c).
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
                 }
                 if (tracing) {
                     bool found;
-                    tracing = presolve_ray(sc, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found, shf);
+                    tracing = presolve_ray(scp, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found, shf);
                 }
             }
             SLT(4);
@@ -718,7 +720,16 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 #define BF_SHADE_LAUNCH_LEAN(F)                          \
     if (rx) BF_SHADE_LAUNCH_RX(F, 3, 1 | bfd::kLean);    \
     else BF_SHADE_LAUNCH_RX(F, 3, 0 | bfd::kLean)
-    if (lp->lean && !lp->wide && (first || waves == 3)) {
+#define BF_SHADE_LAUNCH_MULTI(F)                         \
+    if (rx) BF_SHADE_LAUNCH_RX(F, 3, 1 | bfd::kMulti);   \
+    else BF_SHADE_LAUNCH_RX(F, 3, 0 | bfd::kMulti)
+    if (lp->multi) {
+        // the sequence's endpoints moved between its renders: per-path tables (bf_device.h: kMulti; general kernels, box filter)
+        if (first == 3) { BF_SHADE_LAUNCH_MULTI(3); }
+        else if (first == 2) { BF_SHADE_LAUNCH_MULTI(2); }
+        else if (first) { BF_SHADE_LAUNCH_MULTI(1); }
+        else { BF_SHADE_LAUNCH_MULTI(0); }
+    } else if (lp->lean && !lp->wide && (first || waves == 3)) {
         // scene and launch fit the lean profile (bf_device.h: kLean; three waves per SIMD only)
         if (first == 3) { BF_SHADE_LAUNCH_LEAN(3); }
         else if (first == 2) { BF_SHADE_LAUNCH_LEAN(2); }
@@ -747,6 +758,7 @@ extern "C" hipError_t bfk_wf_shade(const bfd::DScene *sc, const bfd::DLaunch *lp
 #undef BF_SHADE_LAUNCH
 #undef BF_SHADE_LAUNCH_WIDE
 #undef BF_SHADE_LAUNCH_LEAN
+#undef BF_SHADE_LAUNCH_MULTI
 #undef BF_SHADE_LAUNCH_RX
     return hipGetLastError();
 }

@@ -110,7 +110,7 @@ def multi_mesh_radar(n_paths=4096 << 10, bins=4096, dr=0.01, seed=3, scale=1.0):
 
 
 def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmitter="wigner", receiver="omnidirectional",
-                signaltype="pulse", lambda_band_nm=None):
+                signaltype="pulse", lambda_band_nm=None, radar_yaw_deg=0.0, mesh=None):
     """C2-recv: C2 geometry through gen-3 receive():
     wignertransmitter (pulse tau = 2 dr / c, prf = 1/T) on the TX aperture,
     omnidirectional receiver on a coincident RX aperture, ADC t_bins x 1 with
@@ -120,7 +120,8 @@ def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmit
         sd.physics.lambda_min_nm, sd.physics.lambda_max_nm = lambda_band_nm
     c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
     d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
-    aperture = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
+    # radar_yaw_deg: the radar turned about the vertical axis (the sweep loops of Receive.ipynb cell 30 rebuild TX / RX per angle)
+    aperture = T.translate([0, 0, 0.3]) * T.rotate([0, 0, 1], radar_yaw_deg) * d0 * T.scale([20e-3, 50e-3, 1])
     tx_mat = sd.add_diffuse(0.0)        # transmitter shape: rho = 0 (shape.cpp:89-98)
     rx_mat = sd.add_diffuse(0.5)
     txa = sd.add_rectangle(aperture, tx_mat)
@@ -138,7 +139,7 @@ def bus_receive(n_tris=200_000, n_paths=64, t_bins=256, dr=0.1, seed=1, transmit
                     freq_ext=c / (lmin * 1e-9) - c / (lmax * 1e-9))
     _ground(sd)
     car = sd.add_roughconductor(alpha=0.1, twosided=True, specular_reflectance=1.0)
-    v, f = meshgen.bus(n_tris, seed=1)
+    v, f = mesh if mesh is not None else meshgen.bus(n_tris, seed=1)
     sd.add_mesh(meshgen.place(v, yaw_deg=-20.0, translate=(10.0, 3.0, 1.7)), f, car)
     sd.finalize()
     launch = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, n_paths, seed=seed, bins=t_bins, bins_y=1)

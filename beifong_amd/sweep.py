@@ -29,11 +29,13 @@ def geometry_key(sd):
     return tuple(key)
 
 
-def render_sweep(frames, n_streams=4, lib=None, device=None):
+def render_sweep(frames, n_streams=4, lib=None, device=None, rolling=True):
     """Render `frames` — an iterable of (SceneDesc, bf_launch) — and return float32[n_frames, channels].
 
     All frames must produce the same number of channels.  Frames are independent renders; their
-    order in the output is the input order."""
+    order in the output is the input order.  rolling (round 4): the frames a handle renders form ONE rolling
+    sequence — an endpoint update between two frames joins it (bf_scene_update_endpoints) — flushed once at the end,
+    so a sweep whose radar turns per frame (animated_trans_rad.py:307-384) pays one tail per handle, not one per frame."""
     import torch
     lib = lib or capi.load_library()
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -57,8 +59,17 @@ def render_sweep(frames, n_streams=4, lib=None, device=None):
                 keys[j] = key
                 stats["created"] += 1
             h = torch.zeros(handles[j].channels(lp), dtype=torch.float32, device=dev)
+            multi_pixel = lp.spp and lp.film_width and lp.film_height
+            if rolling and not multi_pixel and not (lp.flags & capi.BF_FLAG_MEGAKERNEL):
+                lr = capi.bf_launch()
+                C.memmove(C.byref(lr), C.byref(lp), C.sizeof(capi.bf_launch))
+                lr.flags |= capi.BF_FLAG_ROLLING
+                lp = lr
             handles[j].render_device(lp, h.data_ptr(), stream=streams[j].cuda_stream)
             hists.append(h)
+    for j, hd in enumerate(handles):
+        if hd is not None:
+            hd.flush(stream=streams[j].cuda_stream)
     for s in streams:
         s.synchronize()
     out = np.stack([h.cpu().numpy() for h in hists]) if hists else np.zeros((0, 0), np.float32)

@@ -386,7 +386,14 @@ bf_status bf_scene_destroy(bf_scene *scene);
  * Stream-ordered: renders enqueued on `stream` afterwards see the new
  * endpoints; renders of this scene on other streams must have completed.
  * Fails with BF_ERR_UNSUPPORTED if an endpoint moves further from the origin
- * than the bound the BVH boxes were padded for (recreate the scene then). */
+ * than the bound the BVH boxes were padded for (recreate the scene then).
+ * An open rolling sequence (BF_FLAG_ROLLING, below) on the same stream is NOT
+ * finished first: the update joins it — the renders issued so far keep the
+ * endpoints they were issued with (every path reads the tables of its own
+ * render), the ones issued afterwards see the new ones — so a sweep whose
+ * radar turns every frame is one sequence with one tail.  Scenes with phased
+ * arrays or a reconstruction filter wider than a pixel, another stream, or
+ * the 255th update of a sequence flush it instead (same results). */
 bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, void *stream);
 
 /* Rigidly translate ALL mesh triangles of the scene to `offset` (metres, relative
@@ -439,8 +446,9 @@ bf_status bf_render_device(const bf_scene *scene, const bf_launch *launch,
  * Rules: the renders of a sequence share mode, n_paths (at most the handle's pool, 2^24), bins, depth limits and flags;
  * they may differ in seed, path_offset, hist_dev and records_dev (one histogram / record array PER RENDER, all of which
  * must stay valid until the flush has completed).  stats_out must be NULL.  A render that does not fit the open sequence
- * (or the 256th of a sequence), a plain or batched render, bf_scene_update_endpoints, bf_scene_translate_meshes and
- * bf_scene_clone flush the sequence first, so no call ever sees another scene than the one it was issued for;
+ * (or the 256th of a sequence), a plain or batched render, bf_scene_translate_meshes and bf_scene_clone flush the
+ * sequence first (bf_scene_update_endpoints joins it where it can: see there), so no path ever sees another scene than
+ * the one its render was issued for;
  * bf_scene_destroy abandons it.  Renders without the flag behave exactly as before. */
 bf_status bf_scene_flush(bf_scene *scene, void *stream, bf_stats *stats_out);
 

@@ -241,7 +241,9 @@ def test_everything_else_flushes_an_open_sequence(hiplib):
 
     run(1, lambda: g.render(_launch_like(lp, 77)))
     sd2, _ = scenes.bus_receive(n_tris=20000, n_paths=8192, t_bins=256, dr=0.1)
-    run(2, lambda: g.update_endpoints(sd2))
+    # (round 4: an endpoint update JOINS the open sequence instead of finishing it — test_rolling_sequence_across_endpoint_updates —
+    # unless BF_ROLL_JOIN=0 or the scene cannot: here the explicit flush ends it)
+    run(2, lambda: (g.update_endpoints(sd2), g.flush()))
     run(3, lambda: g.translate_meshes((0.0, 0.0, 0.0)))
     run(4, lambda: g.clone())
     # a render of another shape opens a new sequence behind the flushed one
@@ -257,6 +259,82 @@ def test_everything_else_flushes_an_open_sequence(hiplib):
     _, rs, _ = g.render(_launch_like(lp_b, 2), records=True)
     _same_records(rb[0], rs)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode,iters", [("range", ""), ("range", "1"), ("receive", ""), ("receive_iq", "1")])
+def test_rolling_sequence_across_endpoint_updates(hiplib, mode, iters, monkeypatch):
+    """The loop the reference ships (python_scripts/animated_trans_rad.py:307-384: 73 frames, Receive.ipynb cell 30: 256 angles):
+    the radar TURNS between frames.  bf_scene_update_endpoints joins the open rolling sequence — the new endpoint tables
+    become the next version in the handle's pool, every path reads the tables of ITS frame through the descriptor ring
+    (kMulti kernels) — so the whole sweep is ONE sequence with ONE tail.  Every per-path record of every frame equals the
+    oracle's on the scene REBUILT for that frame; histograms equal stand-alone renders of fresh scenes; after the flush the
+    handle renders with the last frame's endpoints.  BF_ROLL_ITERS=1 keeps many paths of earlier frames alive while later
+    frames start (versions mixed inside the waves, the survivor area and the flush's tail)."""
+    import torch
+    if iters:
+        monkeypatch.setenv("BF_ROLL_ITERS", iters)
+    n = 1 << 15
+    yaws = [0.0, 6.0, 12.0, -9.0, 3.0]
+    if mode == "range":
+        mesh = scenes.bus_mesh(20000)
+        frames = [scenes.bus_radar(n_paths=n, bins=256, dr=0.1, radar_yaw_deg=y, mesh=mesh) for y in yaws]
+    else:
+        from beifong_amd import meshgen
+        mesh = meshgen.bus(20000, seed=1)
+        frames = [scenes.bus_receive(n_paths=n, t_bins=256, dr=0.1, radar_yaw_deg=y, mesh=mesh) for y in yaws]
+        if mode == "receive_iq":
+            for _, l in frames:
+                l.mode = capi.BF_MODE_RECEIVE_IQ
+    sd0, lp0 = frames[0]
+    g = capi.Scene(sd0)
+    K, nch = len(frames), g.channels(lp0)
+    hist = torch.zeros((K, nch), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((K, n, 4), dtype=torch.int32, device="cuda")
+    for k, (sd, lp) in enumerate(frames):
+        if k:
+            g.update_endpoints(sd)
+        l = _launch_like(lp, 1000 + k, flags=capi.BF_FLAG_ROLLING | capi.BF_FLAG_COUNT)
+        g.render_device(l, hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
+    st = g.flush(want_stats=True)
+    assert st.n_paths == K * n and st.n_launches_tail <= 1          # ONE sequence: the updates did not flush it
+    torch.cuda.synchronize()
+    h = hist.cpu().numpy()
+    r = rec.cpu().numpy().view(np.uint32).reshape(K, -1, 4)
+    for k, (sd, lp) in enumerate(frames):
+        recs = np.ascontiguousarray(r[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+        l1 = _launch_like(lp, 1000 + k)
+        _, ro, _ = OracleScene(sd).render(l1, records=True, threads=8)          # the scene REBUILT for frame k
+        _same_records(recs, ro)
+        hs, rs, _ = capi.Scene(sd).render(l1, records=True)                      # a fresh handle, stand-alone
+        _same_records(recs, rs)
+        _close_hist(h[k], hs, n, float(np.abs(rs["L"]).max()))
+    # the handle's tables are the last frame's again (home buffers): a plain render sees them
+    _, rl, _ = g.render(_launch_like(frames[-1][1], 77), records=True)
+    _, rf, _ = capi.Scene(frames[-1][0]).render(_launch_like(frames[-1][1], 77), records=True)
+    _same_records(rl, rf)
+
+
+def test_endpoint_update_flushes_when_it_cannot_join(hiplib, monkeypatch):
+    """BF_ROLL_JOIN=0 (round 3's behaviour) and scenes that cannot carry table versions (phased arrays: their element
+    tables are replaced in place) finish the open sequence at the update: same results, one tail per frame."""
+    import torch
+    monkeypatch.setenv("BF_ROLL_JOIN", "0")
+    n = 1 << 14
+    mesh = scenes.bus_mesh(20000)
+    frames = [scenes.bus_radar(n_paths=n, bins=256, dr=0.1, radar_yaw_deg=y, mesh=mesh) for y in (0.0, 8.0, -8.0)]
+    g = capi.Scene(frames[0][0])
+    hist = torch.zeros((3, g.channels(frames[0][1])), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((3, n, 4), dtype=torch.int32, device="cuda")
+    for k, (sd, lp) in enumerate(frames):
+        if k:
+            g.update_endpoints(sd)
+        g.render_device(_launch_like(lp, 5 + k, flags=capi.BF_FLAG_ROLLING), hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
+    g.flush()
+    torch.cuda.synchronize()
+    r = rec.cpu().numpy().view(np.uint32).reshape(3, -1, 4)
+    for k, (sd, lp) in enumerate(frames):
+        _, rs, _ = capi.Scene(sd).render(_launch_like(lp, 5 + k), records=True)
+        _same_records(np.ascontiguousarray(r[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1), rs)
 
 
 def test_rolling_rejects_what_cannot_roll(hiplib):
