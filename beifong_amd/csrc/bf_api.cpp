@@ -146,6 +146,8 @@ struct bf_tunables {
     int wide_rows_log = -1;
     bool lean = true;                        // BF_LEAN=0: never use the kernels' lean variants (bf_device.h: kLean)
     bool tab_cache = true;                   // BF_TAB_CACHE=0: materials / rectangles stay in device memory (no LDS copies)
+    bool shade_split = false;                // BF_SHADE_SPLIT=1: wf_shade walks the alive masks twice: slots without a real hit first, real hits second (measured: no net gain)
+    uint32_t chain_min = 16;                 // BF_CHAIN_MIN: resolved real hits chain only while at least this many lanes hold one (0: always)
     bool roll_join = true;                   // BF_ROLL_JOIN=0: bf_scene_update_endpoints flushes an open rolling sequence (round 3's behaviour)
     uint32_t debug_surv_batches = 0;         // BF_DEBUG_SURV_BATCHES (tests): size of the survivor area in batches, sizing rule off
 };
@@ -178,6 +180,8 @@ static bf_tunables read_tunables() {
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
     t.lean = num("BF_LEAN", 1) != 0;
     t.tab_cache = num("BF_TAB_CACHE", 1) != 0;
+    t.shade_split = num("BF_SHADE_SPLIT", 0) != 0;
+    t.chain_min = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_CHAIN_MIN", 16), 64));
     t.roll_join = num("BF_ROLL_JOIN", 1) != 0;
     t.debug_surv_batches = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_DEBUG_SURV_BATCHES", 0), 1 << 14));
     return t;
@@ -439,6 +443,7 @@ static bf_status stage_release_after(bf_scene::Stage *st, hipStream_t stream) {
 }
 
 static int32_t bfd_no_node() { return INT32_MIN; }
+static constexpr size_t kTriPad = 4;      // float4 rows of padding behind the triangle array (bf_wavefront.hip: the if-if step of wf_trace)
 static_assert(bf::kTopNodes == bfd::kTopNodes, "the builder's breadth-first prefix is what wf_trace caches");
 static_assert(bfd::CTR_GUARD + 2 == bfd::CTR_COUNT && bfd::CTR_SURV_GUARD + 1 == bfd::CTR_COUNT,
               "the two sticky guard words are the last counters: renders clear the ones before them");
@@ -796,7 +801,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     if (sc->tun.wide_rows_log >= 0) wide_rlog = std::min<uint32_t>(wide_rlog, (uint32_t) sc->tun.wide_rows_log);
     for (int k = 0; k < 3 && !btris.empty(); ++k)
         sc->origin_scale_built = std::max({sc->origin_scale_built, std::fabs(bvh.lo[k]), std::fabs(bvh.hi[k])});
-    std::vector<float4> tri_data(bfd::kTriStride * btris.size(), make_float4(0, 0, 0, 0)), nrm_data;
+    // (+ kTriPad rows behind the last triangle: wf_trace's if-if step reads seven rows from a leaf's first triangle)
+    std::vector<float4> tri_data(bfd::kTriStride * btris.size() + (btris.empty() ? 0 : kTriPad), make_float4(0, 0, 0, 0)), nrm_data;
     if (any_normals) nrm_data.resize(3 * btris.size());
     std::vector<float4> uv_data;
     if (flat.any_uvs) uv_data.assign(btris.size(), make_float4(0, 0, 0, 0));
@@ -1086,7 +1092,7 @@ bf_status bf_scene_translate_meshes(bf_scene *scene, const float offset[3], void
         if (ost == BF_OK) ost = close_sequence(scene, stream);
         if (ost != BF_OK) return ost;
     }
-    const size_t tri_bytes = (size_t) scene->d.n_tris * bfd::kTriStride * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
+    const size_t tri_bytes = ((size_t) scene->d.n_tris * bfd::kTriStride + kTriPad) * sizeof(float4), node_bytes = (size_t) scene->d.n_nodes * 8 * sizeof(float4);
     const size_t wnode_bytes = scene->d.wnodes ? (size_t) scene->d.n_wnodes * 32 * sizeof(float4) : 0;
     const bool shared = scene->geom_token.use_count() > 1 && !scene->geom_private;
     // all-or-nothing allocation: the handle's pointers change only once every copy exists (a failed hipMalloc half way
@@ -1200,7 +1206,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     if (src->tris0 || src->geom_private) {
         // `src` has been translated (in place, or into its own copies): the clone takes a snapshot of the geometry
         // src renders now as ITS geometry "as created"; normals / texture coordinates stay shared
-        const size_t tri_bytes = (size_t) src->d.n_tris * bfd::kTriStride * sizeof(float4), node_bytes = (size_t) src->d.n_nodes * 8 * sizeof(float4);
+        const size_t tri_bytes = ((size_t) src->d.n_tris * bfd::kTriStride + kTriPad) * sizeof(float4), node_bytes = (size_t) src->d.n_nodes * 8 * sizeof(float4);
         const size_t wnode_bytes = src->d.wnodes ? (size_t) src->d.n_wnodes * 32 * sizeof(float4) : 0;
         if ((st = dup(src->d.tris, tri_bytes, (const void **) &sc->d.tris)) != BF_OK) return fail_out(st);
         if ((st = dup(src->d.nodes, node_bytes, (const void **) &sc->d.nodes)) != BF_OK) return fail_out(st);
@@ -1313,7 +1319,7 @@ static bf_status wf_ensure(const bf_scene *scene, uint32_t capacity) {
     HIP_TRY(alloc((void **) &wf.render_, n * 4));
     HIP_TRY(alloc((void **) &wf.dop_, n * 4));
 #endif
-    HIP_TRY(alloc((void **) &scene->wf_masks, 6 * nb * sizeof(unsigned long long)));
+    HIP_TRY(alloc((void **) &scene->wf_masks, 8 * nb * sizeof(unsigned long long)));
     HIP_TRY(alloc((void **) &wf.n_live, (bfd::kWfMaxIter + 2) * sizeof(uint32_t)));
     HIP_TRY(alloc((void **) &scene->roll_ring, bfd::kRollRing * sizeof(bfd::DRoll)));
     HIP_TRY(alloc((void **) &scene->roll_offsets, bfd::kRollRing * sizeof(float4)));
@@ -1423,9 +1429,10 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     wf.box_slack = lp.box_slack;
     const size_t nb = wf.n_slots / 64;
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
-        wf.m_alive[b] = scene->wf_masks + (3 * b + 0) * nb;
-        wf.m_trace[b] = scene->wf_masks + (3 * b + 1) * nb;
-        wf.m_shadow[b] = scene->wf_masks + (3 * b + 2) * nb;
+        wf.m_alive[b] = scene->wf_masks + (4 * b + 0) * nb;
+        wf.m_trace[b] = scene->wf_masks + (4 * b + 1) * nb;
+        wf.m_shadow[b] = scene->wf_masks + (4 * b + 2) * nb;
+        wf.m_hit[b] = scene->wf_masks + (4 * b + 3) * nb;
     }
     c.scene = scene;
     c.lp = &lp;
@@ -1434,7 +1441,9 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.stream = stream;
     c.count_nodes = count_nodes;
     c.timed = timed;
-    c.mask_bytes = 3 * nb * sizeof(unsigned long long);
+    c.mask_bytes = 4 * nb * sizeof(unsigned long long);
+    wf.hit_split = scene->tun.shade_split ? 1u : 0u;
+    wf.chain_min = scene->tun.chain_min;
     c.lds_shade = ((sizeof(float) * lp.lds_floats + 15) & ~size_t(15)) + (scene->d.tab_cache ? bfd::kTabBytes : 0u);      // histogram | tables
     c.lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + c.lds_shade;
     // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs
@@ -1457,7 +1466,7 @@ static bf_status wf_iteration(const WfCtx &c, uint32_t it, int first) {
     const bf_scene *scene = c.scene;
     const bfd::WF &wf = scene->wf;
     const int nxt = (it & 1) ^ 1;
-    HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, c.mask_bytes, c.stream));     // alive, trace, shadow are contiguous
+    HIP_TRY(hipMemsetAsync(wf.m_alive[nxt], 0, c.mask_bytes, c.stream));     // alive, trace, shadow, hit are contiguous
     if (first != 1) {
         // first launch of a rolling call (first == 2): the evicting variant — long paths make room for the new render's
         HIP_TRY(wf_tic(c, 1));

@@ -190,6 +190,30 @@ struct LaneStack {
 #endif
     }
     BF_DEV int pop_or_none() { return sp ? pop() : kNoNode; }
+    // up to three entries a, b, c in that order (pa implies pb implies pc: the caller's entries are sorted, the absent ones
+    // first).  The common case — all three would still land in the LDS part — is three predicated LDS writes at computed
+    // offsets; push() one by one (a branch on the entry's home each) only near the spill boundary.
+    BF_DEV void push3(int a, bool pa, int b, bool pb, int c, bool pc) {
+        const int n = (pa ? 1 : 0) + (pb ? 1 : 0) + (pc ? 1 : 0);
+        if (sp + 3 <= N_LDS) {
+            // three UNCONDITIONAL writes: an absent entry goes to the slot above the new top (sp + n <= N_LDS - 1 when one is
+            // absent), which holds nothing
+            const int top = sp + n;
+            lds[(pc ? top - 1 : top) * kBlock] = c;
+            lds[(pb ? top - 2 : top) * kBlock] = b;
+            lds[(pa ? top - 3 : top) * kBlock] = a;
+            sp = top;
+        } else if (!SPILL) {
+            if (pc) lds[(sp + n - 1) * kBlock] = c;
+            if (pb) lds[(sp + n - 2) * kBlock] = b;
+            if (pa) lds[(sp + n - 3) * kBlock] = a;
+            sp += n;
+        } else {
+            if (pa) push(a);
+            if (pb) push(b);
+            if (pc) push(c);
+        }
+    }
 };
 template <int N_LDS, bool SPILL>
 BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
@@ -201,6 +225,9 @@ BF_DEV LaneStack<N_LDS, SPILL> make_stack(const DScene &sc, int *lds_column) {
     return st;
 }
 
+#ifndef BF_NODE_SORT_PAIRS
+#define BF_NODE_SORT_PAIRS 1
+#endif
 // Visit internal node `node`: test its (up to) four child boxes against the ray segment
 // [mint, tmax], push the hit children far-to-near and return the nearest one (or the next
 // stack entry, or kNoNode when the traversal is finished).
@@ -212,7 +239,31 @@ BF_DEV int node4_decide(const float4 lx, const float4 ly, const float4 lz, const
     const bool h1 = slab_fma(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, id, oid, ohi, mint, tmax, t1);
     const bool h2 = slab_fma(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, id, oid, ohi, mint, tmax, t2) && __float_as_int(ch.z) != kNoNode;
     const bool h3 = slab_fma(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, id, oid, ohi, mint, tmax, t3) && __float_as_int(ch.w) != kNoNode;
-    const uint32_t k0 = child_key(h0, t0, 0u), k1 = child_key(h1, t1, 1u), k2 = child_key(h2, t2, 2u), k3 = child_key(h3, t3, 3u);
+    uint32_t k0 = child_key(h0, t0, 0u), k1 = child_key(h1, t1, 1u), k2 = child_key(h2, t2, 2u), k3 = child_key(h3, t3, 3u);
+#if BF_NODE_SORT_PAIRS
+    // 5-comparator sorting network on (key, child) PAIRS: the children come out in traversal order (no selects by slot
+    // afterwards), the three far ones go onto the stack with predicated writes (LaneStack::push3)
+    int c0 = __float_as_int(ch.x), c1 = __float_as_int(ch.y), c2 = __float_as_int(ch.z), c3 = __float_as_int(ch.w);
+#define BF_CSWAP(ka, ca, kb, cb)                   \
+    {                                              \
+        const bool sw = ka > kb;                   \
+        const uint32_t kl = sw ? kb : ka, kh = sw ? ka : kb; \
+        const int cl = sw ? cb : ca, chh = sw ? ca : cb;     \
+        ka = kl;                                   \
+        ca = cl;                                   \
+        kb = kh;                                   \
+        cb = chh;                                  \
+    }
+    BF_CSWAP(k0, c0, k1, c1)
+    BF_CSWAP(k2, c2, k3, c3)
+    BF_CSWAP(k0, c0, k2, c2)
+    BF_CSWAP(k1, c1, k3, c3)
+    BF_CSWAP(k1, c1, k2, c2)
+#undef BF_CSWAP
+    st.push3(c3, k3 < kMissKey, c2, k2 < kMissKey, c1, k1 < kMissKey);
+    if (k0 < kMissKey) return c0;
+    return st.pop_or_none();
+#else
     // 5-comparator sorting network
     const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
     const uint32_t lo = min(a, c), x = max(a, c), y = min(b, d), hi = max(b, d);
@@ -222,6 +273,7 @@ BF_DEV int node4_decide(const float4 lx, const float4 ly, const float4 lz, const
     if (m1 < kMissKey) st.push(pick_child(ch, m1));
     if (lo < kMissKey) return pick_child(ch, lo);
     return st.pop_or_none();
+#endif
 }
 template <class Stack>
 BF_DEV int node4_step(const float4 *__restrict__ nodes, int node, V3 id, V3 oid, V3 ohi, float mint, float tmax, Stack &st) {

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     bool regen_ok = true;          // RESUME: the adopted slot is a main slot (survivor-area slots of a rolling sequence never regenerate)
     MaskCursor rcur;
     rcur.masks = nullptr;
+    rcur.masks2 = nullptr;
+    rcur.sel = 0u;
     rcur.b = rcur.b_end = rcur.base = rcur.k = 0;
     rcur.stride = 1u;
     rcur.sub = ~0ull;

@@ -148,6 +148,8 @@ BF_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
 // strided gather, one 8-byte word per cache line — the masks are a few MB per launch, the state rows GBs).
 struct MaskCursor {
     const unsigned long long *masks;
+    const unsigned long long *masks2;   // optional: the walk covers masks & masks2 (sel = 1) or masks & ~masks2 (sel = 2)
+    uint32_t sel;
     uint32_t b, b_end;          // current batch / number of batches (wave-uniform)
     unsigned long long m;       // unconsumed bits of batch b (wave-uniform)
     uint32_t base, stride;      // this wave's first batch / distance between its batches (the number of waves sharing the array)
@@ -163,6 +165,7 @@ BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
 BF_DEV void cursor_fetch(MaskCursor &c, int lane) {
     const uint32_t idx = c.base + (c.k * 64u + (uint32_t) lane) * c.stride;
     c.w = idx < c.b_end ? (c.masks[idx] & c.sub) : 0ull;
+    if (c.sel && idx < c.b_end) c.w &= c.sel == 1u ? c.masks2[idx] : ~c.masks2[idx];
     c.nz = __ballot(c.w != 0ull);
 }
 // position the cursor on the wave's next non-empty batch (or at the end)
@@ -186,7 +189,9 @@ BF_DEV void cursor_seek(MaskCursor &c, int lane) {
 }
 // `share` (1, 2 or 4): that many consecutive waves serve the same batches, each one its own 64 / share slots of every batch
 BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t wave_id, uint32_t n_waves, uint32_t n_batches, int lane,
-                        uint32_t share = 1u) {
+                        uint32_t share = 1u, const unsigned long long *masks2 = nullptr, uint32_t sel = 0u) {
+    c.masks2 = masks2;
+    c.sel = masks2 ? sel : 0u;
     c.sub = ~0ull;
     if (share > 1u) {
         const uint32_t width = 64u / share, q = wave_id % share;

@@ -88,6 +88,13 @@ struct WF {
     unsigned long long *m_alive[2];
     unsigned long long *m_trace[2];
     unsigned long long *m_shadow[2];
+    // hit : the slot's pending vertex is a REAL hit (its closest-hit ray found a surface) — a packing hint, never a condition:
+    //       wf_shade walks the alive slots WITHOUT the bit first (rays that left the scene, paths whose film write is due: a few
+    //       instructions each) and then the ones WITH it, so that the expensive part of a vertex runs with full waves
+    unsigned long long *m_hit[2];
+    uint32_t hit_split;             // 1: two passes as above; 0: one walk of the alive masks (BF_SHADE_SPLIT=0)
+    uint32_t chain_min;             // a chained round shades resolved REAL hits only while at least this many lanes hold one (the
+                                    // others are stored and picked up — packed — by the next launch); 0: always chain
     uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
     // the first / wake launches start paths: main slots only (the survivor area never regenerates)
     // (the wake launch: only the batches whose slots are due — the other half of the main slots holds the previous render)
     const uint32_t n_batches = WALK ? wf.n_slots >> 6 : (FIRST == 2 ? wf.wake_nb : wf.n_main >> 6);
-    unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt];
+    unsigned long long *m_alive = wf.m_alive[nxt], *m_trace = wf.m_trace[nxt], *m_shadow = wf.m_shadow[nxt], *m_hit = wf.m_hit[nxt];
     SurvAlloc sv = {0ull, 0u, 0u, EVICT ? wf.surv_cursor[0] : 0u};
 
     FilmAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
@@ -196,10 +196,13 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
     // interleaved share of the batches per wave (MaskCursor; the first / wake launches: batches wave_id, wave_id + n_waves, ...)
     const uint32_t n_waves = gridDim.x * (kBlock / 64), wave_id = blockIdx.x * (kBlock / 64) + (tid >> 6);
     MaskCursor cur_alive;
-    if (WALK) cursor_init(cur_alive, wf.m_alive[cur], wave_id, n_waves, n_batches, lane);
+    // two walks of the alive masks (WF::m_hit): first the slots whose pending vertex is no real hit, then the real hits
+    const uint32_t n_pass = (WALK && wf.hit_split) ? 2u : 1u;
     uint32_t first_b = wave_id;
     const bool rolling = lp.roll != nullptr;
 
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+    if (WALK) cursor_init(cur_alive, wf.m_alive[cur], wave_id, n_waves, n_batches, lane, 1u, n_pass == 2u ? wf.m_hit[cur] : nullptr, pass ? 1u : 2u);
     while (true) {
         // ---- gather up to 64 live slots of the segment into the lanes -----------
         uint32_t slot = 0, got;
@@ -351,7 +354,11 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
             SLT(4);
             // ---- chain or settle ----------------------------------------------------------------
             const bool resolved = !settled && cont && !tracing && !shadowing;
-            const bool chain = resolved && round + 1u < wf.shade_chain;
+            // a resolved REAL hit chains only in company (WF::chain_min): a handful of lanes would run the whole vertex at a
+            // fraction of the wave; stored instead, they are shaded packed by the next launch's second pass
+            const bool real_hit = !(s.flags & kFlagTermPending) && hit.t != BF_INF;
+            const bool lonely = wf.chain_min != 0u && (uint32_t) __popcll(__ballot(resolved && real_hit)) < wf.chain_min;
+            const bool chain = resolved && round + 1u < wf.shade_chain && !(lonely && real_hit);
             if (!__any(chain)) break;
             SLP(9, chain && (s.flags & kFlagTermPending));
             SLP(17 + min(round, 2u), chain);
@@ -415,15 +422,20 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
         publish_masks(m_alive, aligned, FIRST == 2, batch0, slot, has, cont && !evict);
         publish_masks(m_trace, aligned, FIRST == 2, batch0, slot, has, tracing && !evict);
         publish_masks(m_shadow, aligned, FIRST == 2, batch0, slot, has, shadowing && !evict);
+        // the hit is final and real (answered by presolve_ray; wf_trace sets the bit for the rays it answers)
+        const bool hit_known = cont && !tracing && !(s.flags & kFlagTermPending) && hit.t != BF_INF;
+        if (wf.hit_split) publish_masks(m_hit, aligned, FIRST == 2, batch0, slot, has, hit_known && !evict);
         if (evict) {                 // the moved path's bits go to its new slot (the batch's owner ORs its own in as well)
             const unsigned long long bit = 1ull << (dst & 63u);
             atomicOr(&m_alive[dst >> 6], bit);
             if (tracing) atomicOr(&m_trace[dst >> 6], bit);
             if (shadowing) atomicOr(&m_shadow[dst >> 6], bit);
+            if (wf.hit_split && hit_known) atomicOr(&m_hit[dst >> 6], bit);
         }
         c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
         c_shq += shadowing ? 1u : 0u;
         SLT(6);
+    }
     }
 
     film_flush<RX>(lp, acc, s_hist, g_hist, lds_hist, tid);
@@ -503,6 +515,14 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
 // spill to a per-thread column in HBM.  16 KiB of LDS per workgroup instead of
 // 32 lifts the kernel from 5 to 8 waves/SIMD.
 constexpr int kLdsStack = 16;
+// BF_TRACE_IFIF = 1: the "if-if" form of the traversal loop (one step for every lane per iteration, node and triangle fetches in
+// flight together) instead of "while-while".  Built in round 4 as the structural experiment on this kernel, parity-green (216 GPU
+// tests) and 20 % SLOWER (C2 wf_trace 3.79 -> 4.54 ms per step, C5 9.15 -> 10.25, profiles/r04_trace_ifif_ab.txt): every lane
+// runs the node AND the leaf code every iteration and the unified loads move more bytes through the texture pipeline, which
+// is this kernel's busiest unit — so it stays off.
+#ifndef BF_TRACE_IFIF
+#define BF_TRACE_IFIF 0
+#endif
 constexpr uint32_t kTraceGuard = 1u << 24;      // wf_trace: inner-loop iterations between two refills (see the guard below)
 
 template <bool STATS, int W, bool SHIFT, bool QUANT>
@@ -616,6 +636,67 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                 has = false;
                 break;
             }
+#if BF_TRACE_IFIF
+            if (!QUANT) {
+                // "if-if": ONE step for every lane that holds a ray — a lane at an internal node fetches the node (LDS copy
+                // or memory), a lane at a leaf its (one or two) triangles, into the same registers; the wave waits ONCE for
+                // both kinds, then the node lanes decide and the leaf lanes intersect.  Every lane advances every iteration
+                // and node and triangle fetches are in flight together (round 4: the kernel waits on dependent fetches with
+                // 45 % of its lanes busy — in the while-while form below a lane at a leaf idles through the others' node steps)
+                const bool at_node = has && node >= 0, at_leaf = has && node < 0 && node != kNoNode;
+                // ONE generic pointer per lane — node record in memory, node record in the LDS copy of the tree's top, or the
+                // leaf's first triangle — and the same seven loads for all of them (flat loads: a branch per source would give
+                // every source its own destination registers, and the moves that merge them wait for the loads inside
+                // their branch)
+                const uint32_t enc = ~(uint32_t) node;
+                const uint32_t l_first = enc >> 3, l_cnt = (enc & 7u) + 1u;
+                const float4 *qp = sc.tris + kTriStride * l_first;
+                if (at_node) qp = node < n_top ? (const float4 *) (s_top + kTopStride * (uint32_t) node) : sc.nodes + 8u * (uint32_t) node;
+                // (unconditional: a leaf lane reads past its one or two triangles — the triangle array carries 64 bytes of padding
+                // for the last one, bf_api.cpp — and a lane without a ray re-reads the root: straight-line loads are issued back
+                // to back and waited for once)
+                if (!at_node && !at_leaf) qp = sc.tris;
+                const float4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3], q4 = qp[4], q5 = qp[5];
+                float4 q6 = qp[6];
+                // (keeps the child references' load up here with the others: the compiler would sink it into the node branch — a
+                // second dependent round trip per node step)
+                asm volatile("" : "+v"(q6.x), "+v"(q6.y), "+v"(q6.z), "+v"(q6.w));
+                if (at_node) {
+                    if (STATS) {
+                        ++c_nodes;
+                        c_top += node < n_top ? 1u : 0u;
+                    }
+                    node = node4_decide(q0, q1, q2, q3, q4, q5, q6, id, oid, SHIFT ? ohi : oid, mint, any ? maxt : __builtin_fminf(maxt, best.t), st);
+                } else if (at_leaf) {
+                    float t, u, v;
+                    found = false;
+                    if (STATS) c_tris += min(l_cnt, 2u);
+                    if (tri_intersect(shifted(mk(q0.x, q0.y, q0.z), shf), shifted(mk(q1.x, q1.y, q1.z), shf), shifted(mk(q2.x, q2.y, q2.z), shf), o, d,
+                                      mint, maxt, t, u, v)) {
+                        found = any;
+                        consider(best, t, u, v, __float_as_uint(q0.w), (int32_t) l_first);
+                    }
+                    if (l_cnt > 1u && !found &&
+                        tri_intersect(shifted(mk(q3.x, q3.y, q3.z), shf), shifted(mk(q4.x, q4.y, q4.z), shf), shifted(mk(q5.x, q5.y, q5.z), shf), o, d,
+                                      mint, maxt, t, u, v)) {
+                        found = any;
+                        consider(best, t, u, v, __float_as_uint(q3.w), (int32_t) (l_first + 1u));
+                    }
+                    for (uint32_t i = 2; i < l_cnt && !found; ++i) {          // (the builder's leaves hold at most two triangles)
+                        const float4 *tp = sc.tris + kTriStride * (l_first + i);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        if (STATS) ++c_tris;
+                        if (tri_intersect(shifted(mk(a.x, a.y, a.z), shf), shifted(mk(b.x, b.y, b.z), shf), shifted(mk(c.x, c.y, c.z), shf), o, d, mint,
+                                          maxt, t, u, v)) {
+                            found = any;
+                            consider(best, t, u, v, __float_as_uint(a.w), (int32_t) (l_first + i));
+                        }
+                    }
+                    node = found ? kNoNode : st.pop_or_none();
+                }
+            } else
+#endif
+            {
             // (a) descend through internal nodes; a lane that reaches a leaf (node < 0) waits.
             // Stop descending once fewer than kStragglers lanes are still at internal nodes:
             // they resume after the others' leaves have been intersected.
@@ -643,6 +724,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                               : leaf_intersect<STATS>(sc, node, any, o, d, mint, maxt, best, c_tris);
                 node = found ? kNoNode : st.pop_or_none();
             }
+            }
             // (c) retire finished rays
             if (has && node == kNoNode) {
                 if (any) {
@@ -664,6 +746,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_trace(DScene sc, WF wf, uint32_t
                     }
                 } else {
                     wf.hit(job) = make_float4(best.t, best.u, best.v, __int_as_float(best.slot));
+                    if (wf.hit_split && best.t != BF_INF) atomicOr(&wf.m_hit[nxt][job >> 6], 1ull << (job & 63u));
                 }
                 has = false;
             }
