@@ -2250,6 +2250,42 @@ bf_status bfdbg_preload_guard(bf_scene *scene, unsigned long long n) {
     return BF_OK;
 }
 
+/* developer probe (tools/fetch_probe.py): `reps` launches of the gather pattern `mode` over a table of 2^log2_rows 16-byte rows
+   (a second buffer of the same size is streamed in between, so every launch starts with a cold L2); returns the mean ms */
+extern "C" hipError_t bfk_gather_probe(int mode, const float4 *table, uint32_t n_rows, float4 *out, hipStream_t stream);
+bf_status bfdbg_gather_probe(int mode, uint32_t log2_rows, uint32_t reps, float *ms_out) {
+    if (mode < 0 || mode > 2 || log2_rows < 10 || log2_rows > 28 || reps == 0) return fail(BF_ERR_INVALID, "bfdbg_gather_probe: bad arguments");
+    const uint32_t n = 1u << log2_rows;
+    float4 *table = nullptr, *flush = nullptr, *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **) &table, (size_t) n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **) &flush, (size_t) n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **) &out, 1024 * 16);
+    if (e == hipSuccess) e = hipMemset(table, 0, (size_t) n * 16);
+    if (e == hipSuccess) e = hipMemset(flush, 0, (size_t) n * 16);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float total = 0.f;
+    for (uint32_t r = 0; r < reps && e == hipSuccess; ++r) {
+        e = hipMemsetAsync(flush, (int) (r & 1u), (size_t) n * 16, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+        if (e == hipSuccess) e = bfk_gather_probe(mode, table, n, out, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        total += ms;
+    }
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    (void) hipFree(table);
+    (void) hipFree(flush);
+    (void) hipFree(out);
+    if (e != hipSuccess) return fail(BF_ERR_DEVICE, "bfdbg_gather_probe: %s", hipGetErrorString(e));
+    if (ms_out) *ms_out = total / (float) reps;
+    return BF_OK;
+}
+
 /* test hook: take (1) / release (0) the handle's busy flag, as a call of another host thread would hold it */
 bf_status bfdbg_hold_busy(bf_scene *scene, int on) {
     if (!scene) return fail(BF_ERR_INVALID, "null argument");

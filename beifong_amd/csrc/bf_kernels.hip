@@ -623,6 +623,33 @@ extern "C" hipError_t bfk_launch_tail(const bfd::DScene *sc, const bfd::DLaunch 
 }
 
 namespace bfd {
+// Developer probe (tools/fetch_probe.py, profiles/README.md): what rocprofv3's FETCH_SIZE reports for the access patterns of
+// this engine, on a table of known size that is read exactly once per launch.
+//   MODE 0: streaming — thread g loads row g (16 B per lane, coalesced): every 128-byte line fully used by one wave
+//   MODE 1: scattered rows — thread g loads row perm(g) (a bijection: an odd multiplier modulo the row count): every row
+//           once, the eight rows of a line by eight different waves at different times (wf_trace's node / triangle fetches)
+//   MODE 2: one 16-byte row per 128-byte line — thread g loads row 8 perm(g): 1/8 of the table's lines, each touched once
+template <int MODE> __global__ void bf_gather_probe(const float4 *__restrict__ table, uint32_t n_rows, float4 *__restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = MODE == 2 ? n_rows / 8u : n_rows;
+    if (g >= n) return;
+    uint32_t row = g;
+    if (MODE >= 1) row = (g * 2654435761u) & (n - 1u);      // n is a power of two, the multiplier odd: a permutation
+    if (MODE == 2) row *= 8u;
+    const float4 v = table[row];
+    if (v.x == 12345.678f) out[g & 1023u] = v;      // (never true: keeps the load)
+}
+}  // namespace bfd
+extern "C" hipError_t bfk_gather_probe(int mode, const float4 *table, uint32_t n_rows, float4 *out, hipStream_t stream) {
+    const uint32_t n = mode == 2 ? n_rows / 8u : n_rows;
+    const dim3 grid((n + 255u) / 256u), block(256);
+    if (mode == 0) hipLaunchKernelGGL(bfd::bf_gather_probe<0>, grid, block, 0, stream, table, n_rows, out);
+    else if (mode == 1) hipLaunchKernelGGL(bfd::bf_gather_probe<1>, grid, block, 0, stream, table, n_rows, out);
+    else hipLaunchKernelGGL(bfd::bf_gather_probe<2>, grid, block, 0, stream, table, n_rows, out);
+    return hipGetLastError();
+}
+
+namespace bfd {
 // one descriptor of a rolling sequence's ring (kernel arguments are captured at launch: no staging buffer to keep alive)
 __global__ void bf_roll_set_kernel(DRoll *ring, float4 *offsets, uint32_t idx, DRoll d, float4 off) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -326,6 +326,33 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
+    # (D) the same steps as STAND-ALONE renders (every render its own tail; 8 handles in flight: round 2's scheme, what
+    #     `--rolling 0` times): the figure a caller gets who cannot let consecutive renders share a sequence (the
+    #     headline is the rolling sequence's; both belong on one line).  Untimed region of its own, after the timed one.
+    standalone = None
+    if rolling and not w.sweep and world == 1 and not args.no_iso:
+        sa_n = 8
+        sa_handles = handles + [first.clone() for _ in range(max(0, sa_n - n_streams))]
+        sa_streams = streams + [torch.cuda.Stream(dev) for _ in range(max(0, sa_n - n_streams))]
+        ks = min(args.steps, 16)
+
+        def sa_pass(n):
+            for i in range(n):
+                j = i % sa_n
+                with torch.cuda.stream(sa_streams[j]):
+                    sa_handles[j].render_device(w.launch(i, 0), hists[i % n_rows].data_ptr(), stream=sa_streams[j].cuda_stream)
+            for s_ in sa_streams:
+                s_.synchronize()
+
+        sa_pass(2 * sa_n)                      # pools, launch plans (the first render of a shape is synchronous)
+        hists.zero_()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        sa_pass(ks)
+        standalone = {"steps": ks, "handles": sa_n, "ms_per_step": (time.perf_counter() - t1) / ks * 1e3}
+        for h_ in sa_handles[n_streams:]:
+            h_.close()
+
     rays = cnt["n_rays_closest"] + cnt["n_rays_shadow"]
     paths = cnt["n_paths"]
     tot = torch.tensor([dt, float(rays), float(paths)], dtype=torch.float64, device=dev)
@@ -430,18 +457,22 @@ def main():
                 "bound": "hbm",
                 "scope": "whole path: traversal bytes of ALL rays of a step (V_n S_n + V_t S_t + S_q, SURVEY 8d; node visits served from "
                          "wf_trace's LDS copy of the top of the tree are not priced) / ms_per_step",
-                "kernel": kernels[0]["kernel"],
+                "kernel": kernels[0]["kernel"],                       # the dominant kernel (largest share of the GPU time) ...
+                "kernel_frac": kernels[0]["frac"],                    # ... and ITS fraction of the HBM peak (kernels[0], repeated here)
+                "kernel_share_of_gpu_time": kernels[0]["share_of_gpu_time"],
                 "achieved": round(whole, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(whole / HBM_PEAK_GBS, 5),
+                "frac": round(whole / HBM_PEAK_GBS, 5),               # the WHOLE PATH (scope above), not one kernel
                 "frac_serial": round(whole_serial / HBM_PEAK_GBS, 5),
                 "frac_with_lds_served_nodes": round(whole_with_lds / HBM_PEAK_GBS, 5),
                 "frac_by_counter_traffic": (round(traffic_step / step_s / 1e9 / HBM_PEAK_GBS, 5) if traffic_step else None),
                 "traffic": (round(traffic_step) if traffic_step else None),
-                "traffic_note": "HBM bytes per step / per launch: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes, "
-                                "profiles/r03_pmc_traffic.json (tools/profile_r03.sh), stamped with a hash of beifong_amd/csrc: null when "
-                                "the kernels, the workload shape or the scheduling (rolling, streams) differ from the profiled run",
+                "traffic_note": "L2 fabric-side bytes per step / per launch (Infinity-Cache hits INCLUDED: the counters sit between L2 and "
+                                "the fabric, so this is L2-miss traffic, an upper bound of HBM traffic): rocprofv3 --pmc FETCH_SIZE (x the "
+                                "correction factor measured for these kernels' access pattern, profiles/README.md) + WRITE_SIZE, separate "
+                                "passes, profiles/r04_pmc_traffic.json (tools/profile_r04.sh), stamped with a hash of beifong_amd/csrc: null "
+                                "when the kernels, the workload shape or the scheduling (rolling, streams) differ from the profiled run",
                 "bytes_per_ray": round(b_traversal_all / rays, 1),
                 "nodes_per_ray": round((n4_trace + n4_tail + n16_tail) / rays, 2),
                 "tris_per_ray": round(cnt["n_tris_tested"] / rays, 2),
@@ -465,6 +496,13 @@ def main():
                 out["config"]["isolated_step_ms"] = round(iso["kernel_ms"] / iso["n"], 3)
                 out["config"]["isolated_tail_ms"] = round(iso["tail_ms"] / iso["n"], 3)
             out["config"]["tail_ms_per_step"] = round(tim["tail_ms"] / K, 3)
+        if standalone:
+            # stand-alone renders of the same steps (round 2's scheme): like-for-like with a caller's one-render-per-call loop
+            sa_ms = standalone["ms_per_step"]
+            out["value_standalone"] = round(rays / K / (sa_ms / 1e3) / 1e6, 2)
+            out["standalone"] = {"ms_per_step": round(sa_ms, 4), "steps": standalone["steps"], "handles": standalone["handles"],
+                                 "note": "the same steps as stand-alone renders (own tail each, %d handles in flight); `value` is the rolling "
+                                         "sequence of %d steps with ONE tail per handle, flushed inside the timed region" % (standalone["handles"], K)}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, args)
         print(json.dumps(out), flush=True)
@@ -486,10 +524,10 @@ def csrc_hash():
 
 def pmc_traffic(w, args, rolling, n_streams):
     """HBM bytes per launch of each kernel from the committed PMC summary of the same workload shape (PMC counters cannot
-    be read from inside this process: separate rocprofv3 --pmc passes, tools/profile_r03.sh).  The summary carries a hash
+    be read from inside this process: separate rocprofv3 --pmc passes, tools/profile_r04.sh).  The summary carries a hash
     of beifong_amd/csrc: a kernel change makes it stale and the entry null, not silently wrong."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             pt = json.load(f)
         e = pt.get(w.cfg)
         if pt.get("csrc_sha16") != csrc_hash() or not e or e.get("paths") != w.paths or args.tris not in (0, 200_000):

@@ -1,8 +1,12 @@
 """Per-kernel HBM traffic of the bench configs from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-tools/profile_r03.sh -> the JSON bench.py reads as `roofline.kernels[].traffic` (profiles/r03_pmc_traffic.json), stamped
+tools/profile_r04.sh -> the JSON bench.py reads as `roofline.kernels[].traffic` (profiles/r04_pmc_traffic.json), stamped
 with a hash of beifong_amd/csrc (bench.py: csrc_hash) so that a kernel change makes it stale instead of silently wrong.
-Units and corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; on gfx950 FETCH_SIZE reports half the
-bytes of wide (16 B per lane) loads -> x 2; WRITE_SIZE is exact."""
+Units and corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB and sit on the L2's fabric side (Infinity-Cache hits
+are counted: this is L2-miss traffic, an upper bound of HBM traffic).  FETCH_SIZE = read requests x 64 B while every request
+fills a 128-byte line: x 2.  Calibrated in round 4 for THIS engine's access pattern (tools/fetch_probe.py, profiles/
+r04_fetch_size_calibration.txt): a streaming read, a scattered 16-byte-per-lane gather of every row of a 64 MiB table and
+one row per line all report exactly one request (64 B counted, no 32-byte requests) per L2 miss, so the factor of the
+streaming case applies to the scattered gathers of wf_trace / wf_shade too.  WRITE_SIZE is exact."""
 import collections
 import glob
 import json
