@@ -141,7 +141,7 @@ struct bf_tunables {
     int tail_share = -1;                     // BF_TAIL_SHARE: waves per batch in a stand-alone render's tail (-1: by pool size)
     bool allow_plan = true;                  // BF_WF_SYNC=1 turns launch plans off
     uint32_t roll_iters = 0;                 // BF_ROLL_ITERS: bounce iterations per call of a rolling sequence (0: adaptive)
-    uint32_t roll_live = 3u << 19;           // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive
+    uint32_t roll_live = 0;                  // BF_ROLL_LIVE: a rolling call stops iterating once at most this many slots are alive (0: max(1.5 x 2^20, main slots / 4))
     bool no_wide = false, quant = false;
     int wide_rows_log = -1;
     bool lean = true;                        // BF_LEAN=0: never use the kernels' lean variants (bf_device.h: kLean)
@@ -174,7 +174,7 @@ static bf_tunables read_tunables() {
     t.tail_share = (int) num("BF_TAIL_SHARE", -1);
     t.allow_plan = num("BF_WF_SYNC", 0) == 0;
     t.roll_iters = (uint32_t) std::max<long long>(0, std::min<long long>(32, num("BF_ROLL_ITERS", 0)));
-    t.roll_live = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_ROLL_LIVE", 3ll << 19), 1ll << 30));
+    t.roll_live = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_ROLL_LIVE", 0), 1ll << 30));
     t.no_wide = getenv("BF_NO_WIDE_BVH") != nullptr;
     t.quant = num("BF_QUANT_BVH", 0) != 0;
     t.wide_rows_log = (int) num("BF_WIDE_ROWS_LOG", -1);
@@ -1781,7 +1781,12 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         if (n && !r.fb_is_flush && !scene->tun.roll_iters) {
             const uint32_t *nl = scene->wf_feedback;
             uint32_t k = 0;
-            while (k < n && nl[k] > scene->tun.roll_live) ++k;
+            // round 4: with the shading launches' fixed costs gone (the statistics atomics) a launch over a FULL pool is what
+            // pays: a call of a big render stops after its first iteration as long as at most a quarter of the main slots
+            // is alive (C2 / C5: one iteration per call instead of three: wf_trace 3.80 -> 3.27 ms per step, profiles/
+            // r04_roll_iterations.txt); what is still alive two calls later moves to the survivor area as before
+            const uint32_t live_max = scene->tun.roll_live ? scene->tun.roll_live : std::max<uint32_t>(3u << 19, scene->wf.n_main / 4u);
+            while (k < n && nl[k] > live_max) ++k;
             r.iters = std::min<uint32_t>(k < n ? k + 1u : n + 1u, 16u);
         }
         r.fb_call_iters = 0;
