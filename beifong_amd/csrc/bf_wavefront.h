@@ -22,7 +22,7 @@ namespace bfd {
 
 constexpr uint32_t kWfMaxIter = 4096;   // ring of per-bounce live counters
 constexpr uint32_t kShadeChain = 8;        // wf_shade: vertices per visit while rays resolve early (C5: 8 beats 3 by 4 %, C2-C4 indifferent; profiles/r02_chain_sweep.txt)
-constexpr uint32_t kTraceRefill = 44;      // wf_trace refills idle lanes once at most this many still hold a ray
+constexpr uint32_t kTraceRefill = 32;      // wf_trace refills idle lanes once at most this many still hold a ray (44 until round 4: -2 % at 32, profiles/r04_knob_resweep.txt)
 constexpr uint32_t kTraceStragglers = 12;  // ... and postpones node steps of fewer lanes than this while leaves wait
 constexpr uint32_t kTraceBlocksPerCU = 8;
 constexpr uint32_t kTailSmallPool = 1u << 22;   // pools below this never fill the chip: earlier hand-over to the tail (bf_api.cpp: wf_tail_threshold)

@@ -178,6 +178,55 @@ if len(sys.argv) > 2 and sys.argv[2] == "rolling":
         sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 20, t_bins=1024, dr=0.03, seed=4, lambda_band_nm=(8.6e6 * 0.999, 8.6e6 * 1.001))
         lp.mode = capi.BF_MODE_RECEIVE_IQ
         check_rolling(f"C2-recv I/Q, soak seed {seed}", sd, lp, seeds[:4])
+    # round 4: a sweep whose RADAR TURNS every frame as ONE rolling sequence (bf_scene_update_endpoints joins it): every per-path
+    # record of every frame against the oracle on the scene rebuilt for that frame
+    def check_turning(name, builder, n, yaws, mode=None, env=None):
+        global fails
+        frames = [builder(y) for y in yaws]
+        if mode is not None:
+            for _, l in frames:
+                l.mode = mode
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        g = capi.Scene(frames[0][0])
+        for k in (env or {}):
+            os.environ.pop(k)
+        K = len(frames)
+        hist = torch.zeros((K, g.channels(frames[0][1])), dtype=torch.float32, device="cuda")
+        rec = torch.zeros((K, n, 4), dtype=torch.int32, device="cuda")
+        for k, (sd, lp) in enumerate(frames):
+            if k:
+                g.update_endpoints(sd)
+            g.render_device(_launch_like(lp, 4000 + k, flags=capi.BF_FLAG_ROLLING | capi.BF_FLAG_COUNT), hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
+        st = g.flush(want_stats=True)
+        torch.cuda.synchronize()
+        r = rec.cpu().numpy().view(np.uint32).reshape(K, -1, 4)
+        bad_total, rays = 0, 0
+        for k, (sd, lp) in enumerate(frames):
+            rk = np.ascontiguousarray(r[k]).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+            _, ro, so = OracleScene(sd).render(_launch_like(lp, 4000 + k), records=True, threads=16)
+            rays += so.n_rays_closest + so.n_rays_shadow
+            bad_total += sum(int((rk[key].view(np.uint32) != ro[key].view(np.uint32)).sum()) for key in ("L", "aux"))
+            bad_total += int((rk["n_rays"] != ro["n_rays"]).sum()) + int((rk["valid"] != ro["valid"]).sum())
+        ok = bad_total == 0 and rays == st.n_rays_closest + st.n_rays_shadow and st.n_guard == 0 and st.n_launches_tail <= 1
+        fails += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} {name:46s} {K} frames x {n} paths (radar turned per frame, ONE sequence: {st.n_launches_tail} tail), rays "
+              f"{st.n_rays_closest + st.n_rays_shadow} (oracle {rays}), mismatching records {bad_total}", flush=True)
+        g.close()
+        torch.cuda.empty_cache()
+
+    from beifong_amd import meshgen
+    bus = scenes.bus_mesh(200_000)
+    bus_rx = meshgen.bus(200_000, seed=1)
+    for seed in range(n_seeds):
+        yaws = [float(y) for y in np.linspace(-20.0, 20.0, 6) + seed]
+        n = 1 << 20
+        check_turning(f"C2 turning radar, soak seed {seed}", lambda y: scenes.bus_radar(n_paths=n, bins=256, dr=0.1, radar_yaw_deg=y, mesh=bus), n, yaws)
+        check_turning(f"C2 turning radar, one iteration per call, seed {seed}", lambda y: scenes.bus_radar(n_paths=n, bins=256, dr=0.1, radar_yaw_deg=y, mesh=bus),
+                      n, yaws, env={"BF_ROLL_ITERS": "1"})
+        check_turning(f"C2-recv I/Q turning radar, soak seed {seed}",
+                      lambda y: scenes.bus_receive(n_paths=n, t_bins=1024, dr=0.03, radar_yaw_deg=y, mesh=bus_rx, lambda_band_nm=(8.6e6 * 0.999, 8.6e6 * 1.001)),
+                      n, yaws, mode=capi.BF_MODE_RECEIVE_IQ)
     print("FAILED" if fails else "all cases bit-exact")
     sys.exit(1 if fails else 0)
 
