@@ -503,7 +503,7 @@ def main():
             out["standalone"] = {"ms_per_step": round(sa_ms, 4), "steps": standalone["steps"], "handles": standalone["handles"],
                                  "note": "the same steps as stand-alone renders (own tail each, %d handles in flight); `value` is the rolling "
                                          "sequence of %d steps with ONE tail per handle, flushed inside the timed region" % (standalone["handles"], K)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # (rank 0 at N = 1 only: the task's contract; an N > 1 run is not kept waiting for it)
             out["cpu_baseline"] = cpu_baseline(w, args)
         print(json.dumps(out), flush=True)
     if world > 1:
