@@ -148,6 +148,7 @@ struct bf_tunables {
     bool tab_cache = true;                   // BF_TAB_CACHE=0: materials / rectangles stay in device memory (no LDS copies)
     bool shade_split = false;                // BF_SHADE_SPLIT=1: wf_shade walks the alive masks twice: slots without a real hit first, real hits second (measured: no net gain)
     uint32_t chain_min = 16;                 // BF_CHAIN_MIN: resolved real hits chain only while at least this many lanes hold one (0: always)
+    uint32_t rf_min = 16, rf_th = 44, rf_tm = 24;      // BF_RF_MIN / BF_RF_TH / BF_RF_TM: wf_shade's lane refill and phase vote (bf_wavefront.h)
     bool roll_join = true;                   // BF_ROLL_JOIN=0: bf_scene_update_endpoints flushes an open rolling sequence (round 3's behaviour)
     uint32_t debug_surv_batches = 0;         // BF_DEBUG_SURV_BATCHES (tests): size of the survivor area in batches, sizing rule off
 };
@@ -182,6 +183,9 @@ static bf_tunables read_tunables() {
     t.tab_cache = num("BF_TAB_CACHE", 1) != 0;
     t.shade_split = num("BF_SHADE_SPLIT", 0) != 0;
     t.chain_min = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_CHAIN_MIN", 16), 64));
+    t.rf_min = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_RF_MIN", 16), 64));
+    t.rf_th = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_RF_TH", 44), 64));
+    t.rf_tm = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_RF_TM", 24), 64));
     t.roll_join = num("BF_ROLL_JOIN", 1) != 0;
     t.debug_surv_batches = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_DEBUG_SURV_BATCHES", 0), 1 << 14));
     return t;
@@ -1444,6 +1448,9 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     c.mask_bytes = 4 * nb * sizeof(unsigned long long);
     wf.hit_split = scene->tun.shade_split ? 1u : 0u;
     wf.chain_min = scene->tun.chain_min;
+    wf.rf_min = scene->tun.rf_min;
+    wf.rf_th = scene->tun.rf_th;
+    wf.rf_tm = scene->tun.rf_tm;
     c.lds_shade = ((sizeof(float) * lp.lds_floats + 15) & ~size_t(15)) + (scene->d.tab_cache ? bfd::kTabBytes : 0u);      // histogram | tables
     c.lds_tail = sizeof(int) * bfd::kStackDepth * bfd::kBlock + c.lds_shade;
     // persistent grids: shade is register-heavy (3 workgroups per CU at 168 VGPRs), trace runs

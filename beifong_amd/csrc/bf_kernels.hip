@@ -96,6 +96,8 @@ __global__ __launch_bounds__(kBlock, RESUME ? TW : 3) void bf_render_kernel(DSce
     rcur.sel = 0u;
     rcur.b = rcur.b_end = rcur.base = rcur.k = 0;
     rcur.stride = 1u;
+    rcur.rot = rcur.inv = rcur.pb = 0u;
+    rcur.mod = 0xffffffffu;
     rcur.sub = ~0ull;
     rcur.m = rcur.w = rcur.nz = 0ull;
     if (RESUME) {

@@ -157,6 +157,10 @@ struct MaskCursor {
     unsigned long long sub;     // slots of a batch this wave serves (all ones, or a 32- / 16-slot share: the tail's spreading)
     unsigned long long w;       // this lane's word of the chunk, & sub
     unsigned long long nz;      // wave-uniform: chunk words that are non-zero and not consumed yet
+    // the sources of the generating launches (wf_shade<1>, <2> with lane refill): the walk covers `b_end` batches starting at
+    // physical batch `rot` (wrapping at `mod`), of the complemented words (inv: slots WITHOUT a live path) or — masks == nullptr —
+    // of every slot.  Plain cursors: rot = 0, inv = 0, pb == b.
+    uint32_t rot, mod, inv, pb;
 };
 BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
     unsigned lo = (unsigned) __shfl((int) (unsigned) v, src), hi = (unsigned) __shfl((int) (unsigned) (v >> 32), src);
@@ -164,8 +168,15 @@ BF_DEV unsigned long long wave_read_u64(unsigned long long v, int src) {
 }
 BF_DEV void cursor_fetch(MaskCursor &c, int lane) {
     const uint32_t idx = c.base + (c.k * 64u + (uint32_t) lane) * c.stride;
-    c.w = idx < c.b_end ? (c.masks[idx] & c.sub) : 0ull;
-    if (c.sel && idx < c.b_end) c.w &= c.sel == 1u ? c.masks2[idx] : ~c.masks2[idx];
+    uint32_t p = idx + c.rot;
+    if (p >= c.mod) p -= c.mod;
+    c.w = 0ull;
+    if (idx < c.b_end) {
+        c.w = c.masks ? c.masks[p] : ~0ull;
+        if (c.inv) c.w = ~c.w;
+        c.w &= c.sub;
+        if (c.sel) c.w &= c.sel == 1u ? c.masks2[p] : ~c.masks2[p];
+    }
     c.nz = __ballot(c.w != 0ull);
 }
 // position the cursor on the wave's next non-empty batch (or at the end)
@@ -175,6 +186,8 @@ BF_DEV void cursor_seek(MaskCursor &c, int lane) {
             const int j = __ffsll((unsigned long long) c.nz) - 1;
             c.nz &= c.nz - 1ull;
             c.b = c.base + (c.k * 64u + (uint32_t) j) * c.stride;
+            c.pb = c.b + c.rot;
+            if (c.pb >= c.mod) c.pb -= c.mod;
             c.m = wave_read_u64(c.w, j);
             return;
         }
@@ -189,7 +202,12 @@ BF_DEV void cursor_seek(MaskCursor &c, int lane) {
 }
 // `share` (1, 2 or 4): that many consecutive waves serve the same batches, each one its own 64 / share slots of every batch
 BF_DEV void cursor_init(MaskCursor &c, const unsigned long long *masks, uint32_t wave_id, uint32_t n_waves, uint32_t n_batches, int lane,
-                        uint32_t share = 1u, const unsigned long long *masks2 = nullptr, uint32_t sel = 0u) {
+                        uint32_t share = 1u, const unsigned long long *masks2 = nullptr, uint32_t sel = 0u, uint32_t rot = 0u,
+                        uint32_t mod = 0xffffffffu, uint32_t inv = 0u) {
+    c.rot = rot;
+    c.mod = mod;
+    c.inv = inv;
+    c.pb = 0u;
     c.masks2 = masks2;
     c.sel = masks2 ? sel : 0u;
     c.sub = ~0ull;
@@ -229,7 +247,7 @@ BF_DEV uint32_t cursor_take(MaskCursor &c, uint32_t want, bool requesting, uint3
         }
         uint32_t cnt = (uint32_t) __popcll(c.m);
         uint32_t take = min(want - taken, cnt);
-        if (requesting && rank >= taken && rank < taken + take) slot = c.b * 64u + nth_set_bit(c.m, rank - taken);
+        if (requesting && rank >= taken && rank < taken + take) slot = c.pb * 64u + nth_set_bit(c.m, rank - taken);
         if (take == cnt) {
             c.m = 0ull;
         } else {

@@ -95,6 +95,9 @@ struct WF {
     uint32_t hit_split;             // 1: two passes as above; 0: one walk of the alive masks (BF_SHADE_SPLIT=0)
     uint32_t chain_min;             // a chained round shades resolved REAL hits only while at least this many lanes hold one (the
                                     // others are stored and picked up — packed — by the next launch); 0: always chain
+    // wf_shade with lane refill (bf_wavefront.hip, BF_SHADE_REFILL): settled lanes are written back and replaced once rf_min of a wave's
+    // lanes are out of work; a pass over the real hits runs once rf_th lanes hold one, or fewer than rf_tm lanes hold cheap work
+    uint32_t rf_min, rf_th, rf_tm;
     uint32_t *n_live;               // [kWfMaxIter + 2] live slots after shading bounce `it`
     unsigned long long *counters;   // CTR_* (bf_device.h)
     uint32_t trace_refill, trace_stragglers;   // wf_trace scheduling thresholds (see bf_wavefront.hip)

@@ -43,6 +43,38 @@ BF_DEV void publish_masks(unsigned long long *m_out, bool aligned, bool merge, u
     }
 }
 
+// Lane-refill form of wf_shade (BF_SHADE_REFILL): the lanes of a wave hold slots of several batches and settle at different
+// times, so the bits of one settle event are gathered per batch — transposed from lane order to slot order through 64 bytes of
+// LDS — and OR-ed into the (pre-zeroed) words by ONE lane: three atomics per batch and event instead of three per slot.  Pools
+// so sparse that every lane holds a different batch fall back to one atomic per lane after kPublishGroups batches.
+// bits: 1 alive, 2 trace, 4 shadow.
+constexpr uint32_t kPublishGroups = 4;
+BF_DEV void publish_grouped(volatile unsigned char *tr, int lane, bool settle, uint32_t slot, uint32_t bits, unsigned long long *m_alive,
+                            unsigned long long *m_trace, unsigned long long *m_shadow) {
+    unsigned long long todo = __ballot(settle && bits != 0u);
+    for (uint32_t n = 0; todo != 0ull && n < kPublishGroups; ++n) {
+        const int j = __ffsll(todo) - 1;
+        const uint32_t b = (uint32_t) __shfl((int) (slot >> 6), j);
+        const bool mine = settle && bits != 0u && (slot >> 6) == b;
+        tr[lane] = 0;
+        if (mine) tr[slot & 63u] = (unsigned char) bits;
+        const uint32_t f = tr[lane];
+        const unsigned long long a = __ballot((f & 1u) != 0u), t = __ballot((f & 2u) != 0u), q = __ballot((f & 4u) != 0u);
+        if (lane == 0) {
+            if (a) atomicOr(&m_alive[b], a);
+            if (t) atomicOr(&m_trace[b], t);
+            if (q) atomicOr(&m_shadow[b], q);
+        }
+        todo &= ~__ballot(mine);
+    }
+    if ((todo >> lane) & 1ull) {
+        const unsigned long long bit = 1ull << (slot & 63u);
+        if (bits & 1u) atomicOr(&m_alive[slot >> 6], bit);
+        if (bits & 2u) atomicOr(&m_trace[slot >> 6], bit);
+        if (bits & 4u) atomicOr(&m_shadow[slot >> 6], bit);
+    }
+}
+
 // Early resolution of a freshly spawned ray, done by the shading lane itself
 // while the whole wave is active: the analytic rectangles (rectangle.cpp:229-263)
 // are tested here, and if the ray misses all child boxes of the BVH root no
@@ -154,6 +186,10 @@ BF_DEV void surv_take(const WF &wf, int cur, SurvAlloc &sv, unsigned long long e
 #else
 #define SLT(k)
 #endif
+// BF_SHADE_REFILL = 1: wf_shade with lane refill and phase voting (below); 0: one visit per 64 slots with chained rounds.
+#ifndef BF_SHADE_REFILL
+#define BF_SHADE_REFILL 0
+#endif
 template <int FIRST, int W, int RX>
 __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp, WF wf, uint32_t it, float *__restrict__ g_hist,
                                                       bf_path_record *__restrict__ records) {
@@ -201,6 +237,239 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
     uint32_t first_b = wave_id;
     const bool rolling = lp.roll != nullptr;
 
+#if BF_SHADE_REFILL
+    // ---- lane refill + phase voting --------------------------------------------------------------------------------------
+    // A lane keeps a slot only while its path's next step needs no trace launch; the moment it settles (state written back, or the
+    // slot out of paths) it takes the wave's next slot.  What a lane has pending is one of: a REAL hit to shade (the expensive
+    // vertex: surface interaction, next-event estimation, BSDF sample), or cheap work (a ray that left the scene, a film write, the
+    // slot's next path to start).  Each loop iteration the wave votes and runs ONE kind for all the lanes that hold it; the others
+    // keep their registers and wait, so both kinds run with most of the wave instead of a decaying subset (tools/shade_profile.py:
+    // 31 lanes per expensive-section entry, 22 per film write before this form).  Per-path results do not depend on the schedule.
+    (void) n_pass;
+    (void) first_b;
+    (void) m_hit;
+    __shared__ unsigned char s_tr[kBlock];
+    volatile unsigned char *tr = s_tr + (tid & ~63);
+    if (WALK)
+        cursor_init(cur_alive, wf.m_alive[cur], wave_id, n_waves, n_batches, lane);
+    else if (FIRST == 2)      // the due slots WITHOUT a live path (as of now: wf_shade<3> of this iteration has run)
+        cursor_init(cur_alive, m_alive, wave_id, n_waves, wf.wake_nb, lane, 1u, nullptr, 0u, wf.wake_b0, wf.n_main >> 6, 1u);
+    else
+        cursor_init(cur_alive, nullptr, wave_id, n_waves, wf.n_main >> 6, lane);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    bool has = false, have_hit = false, need_film = false, need_gen = false, touched = false;
+    uint32_t slot = 0, rounds = 0, guard = 0;
+    PathState s;
+    s.render = 0u;
+    s.flags = 0u;
+    s.path_i = 0ull;
+    ShadowReq sh;
+    sh.want = false;
+    Hit hit;
+    hit.t = BF_INF;
+    hit.u = hit.v = 0.f;
+    hit.prim = 0;
+    hit.slot = 0;
+    bool done = false;              // the lane's outcome for the launch is final: written back at the next exchange
+    uint32_t out_bits = 0u;         // ... with these mask bits (1 alive, 2 trace, 4 shadow; 0: the slot has run out of paths)
+    const uint32_t rf_min = wf.rf_min, rf_th = wf.rf_th, rf_tm = wf.rf_tm;
+    while (true) {
+        const bool pend_any = has && !done;
+        const unsigned long long xm = __ballot(!pend_any);             // lanes without work: settled or free
+        // ---- exchange: settled lanes write back, then every free lane takes the wave's next slot ---------------------
+        // (lazily: once rf_min lanes are out of work, or nothing else is left to do — one store / publish / load round
+        // trip for many lanes instead of one per loop iteration)
+        if ((uint32_t) __popcll(xm) >= rf_min || xm == ~0ull) {
+            if (__any(done)) {
+                const bool keep = done && out_bits != 0u;          // a live path goes back to its slot (or to the survivor area)
+                const bool tracing = (out_bits & 2u) != 0u, shadowing = (out_bits & 4u) != 0u;
+                bool evict = false;
+                uint32_t dst = slot;
+                SLP(20, keep);
+                if (EVICT) {
+                    // only out of the batches THIS call's wake launch visits (see the batch-visit form below)
+                    const uint32_t main_b = wf.n_main >> 6, b = slot >> 6;
+                    const uint32_t rel = b >= wf.wake_b0 ? b - wf.wake_b0 : b + main_b - wf.wake_b0;
+                    evict = keep && slot < wf.n_main && rel < wf.wake_nb && s.path_i + wf.n_main < lp.n_paths;
+                    const unsigned long long em = __ballot(evict);
+                    if (em) surv_take(wf, cur, sv, em, evict, dst, lane);
+                    if (evict) wf.sd(slot) = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
+                }
+                if (keep) {
+                    if (!(s.flags & kFlagTermPending)) {
+                        // resolved rays carry their final hit; the others start wf_trace from the rectangle hit
+                        wf.hit(dst) = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
+                        wf.hit_prim(dst) = hit.prim;
+                    }
+                    store_state(wf, dst, receive, s);
+                    ++c_live;
+                    if (shadowing) {
+                        wf.sh0(dst) = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint);
+                        wf.sh1(dst) = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt);
+                        wf.sh2(dst) = sh.c;
+                        if (receive && lp.iq) wf.sh3(dst) = sh.c_im;
+                    }
+                    c_traced += (tracing ? 1u : 0u) + (shadowing ? 1u : 0u);
+                    c_shq += shadowing ? 1u : 0u;
+                } else if (done && rolling && touched) {
+                    // the slot has run out of paths for now: remember the last one it rendered (the wake launch of the
+                    // sequence's next call continues from there)
+                    wf.sd(slot) = make_uint4(0u, 0u, (uint32_t) s.path_i, (uint32_t) (s.path_i >> 32));
+                }
+                publish_grouped(tr, lane, keep && !evict, slot, out_bits, m_alive, m_trace, m_shadow);
+                if (evict) {                 // the moved path's bits go to its new slot (the batch's owner ORs its own in as well)
+                    const unsigned long long bit = 1ull << (dst & 63u);
+                    atomicOr(&m_alive[dst >> 6], bit);
+                    if (tracing) atomicOr(&m_trace[dst >> 6], bit);
+                    if (shadowing) atomicOr(&m_shadow[dst >> 6], bit);
+                }
+                if (done) {
+                    done = false;
+                    has = false;
+                    sh.want = false;
+                    out_bits = 0u;
+                }
+            }
+            SLT(5);
+            if (!cursor_empty(cur_alive)) {
+                cursor_skip_empty(cur_alive, lane);
+                const unsigned long long fm = __ballot(!has);
+                const uint32_t rank = (uint32_t) __popcll(fm & lt_mask);
+                uint32_t ns = 0;
+                const uint32_t got = cursor_take(cur_alive, (uint32_t) __popcll(fm), !has, rank, ns, lane);
+                const bool fresh = !has && rank < got;
+                SLP(0, fresh);
+                SLT(0);
+                if (fresh) {
+                    slot = ns;
+                    has = true;
+                    rounds = 0u;
+                    sh.want = false;
+                    have_hit = need_film = need_gen = false;
+                    touched = FIRST != 2;
+                    if (!WALK) {
+                        need_gen = true;
+                        s.render = 0u;
+                        s.flags = 0u;
+                        // the path BEFORE the one this slot starts now (see the batch-visit form below)
+                        s.path_i = (uint64_t) slot - (uint64_t) wf.n_main;
+                        if (FIRST == 2) {
+                            const uint4 d = wf.sd(slot);
+                            s.path_i = ((uint64_t) d.w << 32) | d.z;
+                        }
+                    } else {
+                        load_state(wf, slot, receive, s);
+                        ++c_loads;
+                        if (s.flags & kFlagTermPending) {
+                            need_film = true;      // ended after last bounce's BSDF sample; its NEE shadow ray has resolved by now
+                        } else {
+                            float4 hq = wf.hit(slot);
+                            hit.t = hq.x;
+                            hit.u = hq.y;
+                            hit.v = hq.z;
+                            hit.slot = __float_as_int(hq.w);
+                            have_hit = true;
+                        }
+                    }
+                }
+                SLT(1);
+            }
+        }
+        // ---- vote ---------------------------------------------------------------------------------------------------------
+        const bool pend_h = has && !done && have_hit && hit.t != BF_INF;
+        const bool pend_m = has && !done && !pend_h;           // (a lane with a slot that is not settled always has something pending)
+        const uint32_t n_h = (uint32_t) __popcll(__ballot(pend_h)), n_m = (uint32_t) __popcll(__ballot(pend_m));
+        if (n_h + n_m == 0u) break;                            // every lane free and the source exhausted
+        if (++guard > (1u << 26)) {                            // (no schedule comes near this: a loud end instead of a hung GPU)
+            if (lane == 0) atomicAdd(&wf.counters[CTR_GUARD], 1ull);
+            break;
+        }
+        // real hits run once enough of them wait (or too little else is pending); cheap work runs in between and feeds them
+        const bool run_h = n_h != 0u && (n_h >= rf_th || n_m < rf_tm);
+        const bool go = run_h ? pend_h : pend_m;
+        bool cont = false;
+        // ---- vertex: the real hits (run_h) or the rays that left the scene ---------------------------------------------------
+        SLP(2, go && have_hit);
+        if (go && have_hit) {
+            have_hit = false;
+#ifdef BF_SHADE_PROF
+            cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces, &spf, lpf);
+#else
+            cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces);
+#endif
+            if (!cont)
+                need_film = true;
+            else if (!(s.flags & kFlagTermPending))
+                ++c_closest;
+            if (sh.want) ++c_shadow;
+        }
+        SLT(2);
+        // ---- film write and the slot's next path: cheap passes only (a path that ends in an expensive pass waits for one) ------
+        const bool go_m = go && !run_h;
+        SLP(5, go_m && need_film);
+        if (go_m && need_film) {
+            need_film = false;
+            film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);
+            need_gen = true;
+        }
+        SLP(6, go_m && need_gen);
+        bool fin = false;
+        if (go_m && need_gen) {
+            // regeneration: slot i renders paths i, i + n_main, i + 2 n_main, ... (static assignment: no device-wide counter)
+            need_gen = false;
+            const uint64_t path_i = s.path_i + wf.n_main;
+            if (slot < wf.n_main && path_i < lp.n_paths) {
+                touched = true;
+                generate_path<RX>(sc, lp, path_i, s);
+                sh.want = false;
+                ++c_closest;
+                cont = true;
+            } else {
+                fin = true;
+            }
+        }
+        SLT(3);
+        // ---- early resolution of the new rays ---------------------------------------------------------------------------------
+        bool tracing = false, shadowing = false;
+        if (go) {
+            tracing = cont && !(s.flags & kFlagTermPending);
+            shadowing = cont && sh.want;
+            const Shift shf = path_shift(lp, s.render);
+            const DScene scp = path_scene<RX>(sc, lp, s.render);
+            SLP(7, shadowing);
+            SLP(8, tracing);
+            if (shadowing) {
+                Hit tmp;
+                bool found;
+                if (!presolve_ray(scp, true, sh.o, sh.d, sh.mint, sh.maxt, tmp, found, shf)) {
+                    s.result += found ? sh.c * 0.f : sh.c;      // (c * 0: see the batch-visit form)
+                    if (receive && lp.iq) s.phase += found ? sh.c_im * 0.f : sh.c_im;
+                    shadowing = false;
+                }
+                sh.want = shadowing;
+            }
+            if (tracing) {
+                bool found;
+                tracing = presolve_ray(scp, false, s.ro, s.rd, s.rmint, s.rmaxt, hit, found, shf);
+            }
+        }
+        SLT(4);
+        // ---- keep the slot (both rays answered: the next vertex is known) or settle ------------------------------------------
+        const bool resolved = go && cont && !tracing && !shadowing;
+        const bool chain = resolved && rounds + 1u < wf.shade_chain;
+        if (go) ++rounds;
+        if (chain) {
+            if (s.flags & kFlagTermPending)
+                need_film = true;         // ended at its last BSDF sample and its NEE ray is answered: bin it in a cheap pass
+            else
+                have_hit = true;          // `hit` is the final answer of the continuation ray
+        }
+        if (go && !chain && (cont || fin)) {      // (neither: the path ended in an expensive pass, its film write is pending)
+            done = true;
+            out_bits = cont ? (1u | (tracing ? 2u : 0u) | (shadowing ? 4u : 0u)) : 0u;
+        }
+    }
+#else
     for (uint32_t pass = 0; pass < n_pass; ++pass) {
     if (WALK) cursor_init(cur_alive, wf.m_alive[cur], wave_id, n_waves, n_batches, lane, 1u, n_pass == 2u ? wf.m_hit[cur] : nullptr, pass ? 1u : 2u);
     while (true) {
@@ -437,6 +706,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
         SLT(6);
     }
     }
+#endif
 
     film_flush<RX>(lp, acc, s_hist, g_hist, lds_hist, tid);
 #ifdef BF_SHADE_PROF
