@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kBlock, W) void wf_shade(DScene sc_arg, DLaunch lp,
 #else
                 cont = shade_vertex<RX>(sc, lp, s, hit, sh, c_bounces);
 #endif
+                SLT(7);
                 SLP(5, !cont);
                 if (!cont) {
                     film_put<RX>(sc, lp, s, s_hist, g_hist, lds_hist, acc, records);

@@ -43,12 +43,12 @@ for k in sorted(names):
     if w[k]:
         print(f"{names[k]:38s} {int(w[k]):12d} {int(l[k]):12d} {l[k] / w[k]:11.1f}")
 t = w[24:32]
-tn = ["cursor + gather", "state / hit load", "vertex + film_put", "generate_path", "presolve", "chain bookkeeping", "store + masks", "-"]
+tn = ["cursor + gather", "state / hit load", "film_put after a vertex", "generate_path", "presolve", "chain bookkeeping", "store + masks", "shade_vertex"]
 print("wave cycles between stamps (s_memtime ticks), share of the total:")
-for k in range(7):
-    print(f"  {tn[k]:20s} {t[k] / t[:7].sum():6.3f}")
+for k in range(8):
+    print(f"  {tn[k]:24s} {t[k] / t[:8].sum():6.3f}")
 v = l[24:28]
 if v.sum():
     print("inside vertex + film_put (largest lane of a wave; the rest of that share is film_put and lanes that end early):")
     for k, nm in enumerate(["surface interaction (+ wait for the triangle / material)", "head (emitter, roulette)", "next-event estimation", "BSDF sampling + spawn"]):
-        print(f"  {nm:58s} {v[k] / t[:7].sum():6.3f}")
+        print(f"  {nm:58s} {v[k] / t[:8].sum():6.3f}")
