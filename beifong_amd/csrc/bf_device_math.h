@@ -46,18 +46,45 @@ BF_DEV float safe_sqrt(float x) { return __builtin_sqrtf(__builtin_fmaxf(x, 0.f)
 BF_HD float bf_bits_to_float(uint32_t u) { return __builtin_bit_cast(float, u); }
 BF_HD uint32_t bf_float_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+#ifdef BF_ESTRIN_PROBE
+// TIMING PROBE ONLY (tools/r04_estrin_probe.sh; never the product, never compared with the oracle): the polynomials of exp / log /
+// asin / erf evaluated in Estrin form (depth log2 n instead of n) to MEASURE what re-association would buy a lone path's bounce.
+template <int N> BF_HD float bf_estrin(const float *c, float x) {          // c[0] + c[1] x + ... + c[N-1] x^(N-1)
+    if constexpr (N == 1) {
+        return c[0];
+    } else if constexpr (N == 2) {
+        return __builtin_fmaf(c[1], x, c[0]);
+    } else {
+        constexpr int H = N > 8 ? 8 : (N > 4 ? 4 : 2);
+        float xh = x * x;
+        if constexpr (H >= 4) xh = xh * xh;
+        if constexpr (H >= 8) xh = xh * xh;
+        return __builtin_fmaf(bf_estrin<N - H>(c + H, x), xh, bf_estrin<H>(c, x));
+    }
+}
+#define BF_POLY(var, x, ...)                                  \
+    do {                                                      \
+        const float bf_c_[] = {__VA_ARGS__};                  \
+        var = bf_estrin<sizeof(bf_c_) / sizeof(float)>(bf_c_, x); \
+    } while (0)
+#endif
 BF_HD float bf_exp(float x) {
     if (!(x >= -87.0f)) return (x != x) ? x : 0.f;           // results below FLT_MIN are flushed to 0
     if (x > 88.72283905f) return __builtin_huge_valf();
     float n = __builtin_rintf(x * 1.44269504088896341f);
     float r = __builtin_fmaf(n, -0.693359375f, x);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
+#ifdef BF_ESTRIN_PROBE
+    float p;
+    BF_POLY(p, r, 5.0000001201e-1f, 1.6666665459e-1f, 4.1665795894e-2f, 8.3334519073e-3f, 1.3981999507e-3f, 1.9875691500e-4f);
+#else
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
     p = __builtin_fmaf(p, r, 8.3334519073e-3f);
     p = __builtin_fmaf(p, r, 4.1665795894e-2f);
     p = __builtin_fmaf(p, r, 1.6666665459e-1f);
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+#endif
     p = __builtin_fmaf(p, r * r, r);
     p = p + 1.f;
     int ni = (int) n;
@@ -86,6 +113,10 @@ BF_HD float bf_log(float x) {
         m = m - 1.f;
     }
     float z = m * m;
+#ifdef BF_ESTRIN_PROBE
+    float y;
+    BF_POLY(y, m, 3.3333331174e-1f, -2.4999993993e-1f, 2.0000714765e-1f, -1.6668057665e-1f, 1.4249322787e-1f, -1.2420140846e-1f, 1.1676998740e-1f, -1.1514610310e-1f, 7.0376836292e-2f);
+#else
     float y = 7.0376836292e-2f;
     y = __builtin_fmaf(y, m, -1.1514610310e-1f);
     y = __builtin_fmaf(y, m, 1.1676998740e-1f);
@@ -95,6 +126,7 @@ BF_HD float bf_log(float x) {
     y = __builtin_fmaf(y, m, 2.0000714765e-1f);
     y = __builtin_fmaf(y, m, -2.4999993993e-1f);
     y = __builtin_fmaf(y, m, 3.3333331174e-1f);
+#endif
     y = (y * m) * z;
     float fe = (float) e;
     y = __builtin_fmaf(fe, -2.12194440e-4f, y);
@@ -161,11 +193,16 @@ BF_HD float bf_asin_core(float a) {               // a in [0, 1]
         x = a;
         z = x * x;
     }
+#ifdef BF_ESTRIN_PROBE
+    float p;
+    BF_POLY(p, z, 1.6666752422e-1f, 7.4953002686e-2f, 4.5470025998e-2f, 2.4181311049e-2f, 4.2163199048e-2f);
+#else
     float p = 4.2163199048e-2f;
     p = __builtin_fmaf(p, z, 2.4181311049e-2f);
     p = __builtin_fmaf(p, z, 4.5470025998e-2f);
     p = __builtin_fmaf(p, z, 7.4953002686e-2f);
     p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+#endif
     p = __builtin_fmaf(p * z, x, x);
     if (flag) p = 1.5707963267948966f - (p + p);
     return p;
@@ -184,6 +221,10 @@ BF_HD float bf_erf(float x) {
     float r;
     if (a < 0.8f) {
         float z = x * x;
+#ifdef BF_ESTRIN_PROBE
+        float p;
+        BF_POLY(p, z, 1.128379167e+00f, -3.761263888e-01f, 1.128379095e-01f, -2.686608035e-02f, 5.223417615e-03f, -8.529368140e-04f, 1.169606002e-04f, -1.128872449e-05f);
+#else
         float p = -1.128872449e-05f;
         p = __builtin_fmaf(p, z, 1.169606002e-04f);
         p = __builtin_fmaf(p, z, -8.529368140e-04f);
@@ -192,9 +233,14 @@ BF_HD float bf_erf(float x) {
         p = __builtin_fmaf(p, z, 1.128379095e-01f);
         p = __builtin_fmaf(p, z, -3.761263888e-01f);
         p = __builtin_fmaf(p, z, 1.128379167e+00f);
+#endif
         return p * x;
     } else if (a < 1.6f) {
         float t = a - 1.2f;
+#ifdef BF_ESTRIN_PROBE
+        float p;
+        BF_POLY(p, t, 9.103139784e-01f, 2.673443467e-01f, -3.208132755e-01f, 1.675358269e-01f, 6.419227034e-03f, -5.334181702e-02f, 1.957314866e-02f, 5.989846125e-03f, -5.621837162e-03f, 3.210465009e-04f);
+#else
         float p = 3.210465009e-04f;
         p = __builtin_fmaf(p, t, -5.621837162e-03f);
         p = __builtin_fmaf(p, t, 5.989846125e-03f);
@@ -205,9 +251,14 @@ BF_HD float bf_erf(float x) {
         p = __builtin_fmaf(p, t, -3.208132755e-01f);
         p = __builtin_fmaf(p, t, 2.673443467e-01f);
         p = __builtin_fmaf(p, t, 9.103139784e-01f);
+#endif
         r = p;
     } else if (a < 4.0f) {
         float t = a - 2.8f;
+#ifdef BF_ESTRIN_PROBE
+        float p;
+        BF_POLY(p, t, -9.497846531e+00f, -5.921730786e+00f, -9.526015505e-01f, -8.600132565e-03f, 1.626972312e-03f, -3.038591482e-04f, 5.432784894e-05f, -9.056785943e-06f, 1.344892106e-06f, -1.412586080e-07f, 1.378729715e-09f);
+#else
         float p = 1.378729715e-09f;
         p = __builtin_fmaf(p, t, -1.412586080e-07f);
         p = __builtin_fmaf(p, t, 1.344892106e-06f);
@@ -219,6 +270,7 @@ BF_HD float bf_erf(float x) {
         p = __builtin_fmaf(p, t, -9.526015505e-01f);
         p = __builtin_fmaf(p, t, -5.921730786e+00f);
         p = __builtin_fmaf(p, t, -9.497846531e+00f);
+#endif
         r = 1.f - bf_exp(p);
     } else {
         r = 1.f;
@@ -359,6 +411,10 @@ BF_DEV float erfinv_giles(float x) {
     float p;
     if (w < 5.f) {
         w = w - 2.5f;
+#ifdef BF_ESTRIN_PROBE
+        BF_POLY(p, w, 1.50140941f, 0.246640727f, -0.00417768164f, -0.00125372503f, 0.00021858087f, -4.39150654e-06f, -3.5233877e-06f, 3.43273939e-07f, 2.81022636e-08f);
+        return p * x;
+#endif
         p = 2.81022636e-08f;
         p = fmadd(p, w, 3.43273939e-07f);
         p = fmadd(p, w, -3.5233877e-06f);
@@ -370,6 +426,10 @@ BF_DEV float erfinv_giles(float x) {
         p = fmadd(p, w, 1.50140941f);
     } else {
         w = __builtin_sqrtf(w) - 3.f;
+#ifdef BF_ESTRIN_PROBE
+        BF_POLY(p, w, 2.83297682f, 1.00167406f, 0.00943887047f, -0.0076224613f, 0.00573950773f, -0.00367342844f, 0.00134934322f, 0.000100950558f, -0.000200214257f);
+        return p * x;
+#endif
         p = -0.000200214257f;
         p = fmadd(p, w, 0.000100950558f);
         p = fmadd(p, w, 0.00134934322f);
