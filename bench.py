@@ -353,6 +353,9 @@ def main():
         for h_ in sa_handles[n_streams:]:
             h_.close()
 
+    if "n_rays_closest" not in cnt:
+        raise SystemExit("bench.py: no ray counters came back — a step of %d paths does not fit the handle's path pool, so its renders did "
+                         "not join a rolling sequence (BF_WF_POOL?): run with --rolling 0" % w.paths)
     rays = cnt["n_rays_closest"] + cnt["n_rays_shadow"]
     paths = cnt["n_paths"]
     tot = torch.tensor([dt, float(rays), float(paths)], dtype=torch.float64, device=dev)

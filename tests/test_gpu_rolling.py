@@ -296,7 +296,8 @@ def test_rolling_sequence_across_endpoint_updates(hiplib, mode, iters, monkeypat
         l = _launch_like(lp, 1000 + k, flags=capi.BF_FLAG_ROLLING | capi.BF_FLAG_COUNT)
         g.render_device(l, hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
     st = g.flush(want_stats=True)
-    assert st.n_paths == K * n and st.n_launches_tail <= 1          # ONE sequence: the updates did not flush it
+    if os.environ.get("BF_ROLL_JOIN", "1") != "0":         # (BF_ROLL_JOIN=0, round 3's behaviour: every update flushes; same results)
+        assert st.n_paths == K * n and st.n_launches_tail <= 1          # ONE sequence: the updates did not flush it
     torch.cuda.synchronize()
     h = hist.cpu().numpy()
     r = rec.cpu().numpy().view(np.uint32).reshape(K, -1, 4)
