@@ -149,6 +149,8 @@ struct bf_tunables {
     bool shade_split = false;                // BF_SHADE_SPLIT=1: wf_shade walks the alive masks twice: slots without a real hit first, real hits second (measured: no net gain)
     uint32_t chain_min = 16;                 // BF_CHAIN_MIN: resolved real hits chain only while at least this many lanes hold one (0: always)
     uint32_t rf_min = 16, rf_th = 44, rf_tm = 24;      // BF_RF_MIN / BF_RF_TH / BF_RF_TM: wf_shade's lane refill and phase vote (bf_wavefront.h)
+    uint32_t grid_share = 3;                 // BF_GRID_SHARE: small pools (< grid_small slots) of handles that roll side by side launch 1 / min(peers, this) of the persistent grids (0 / 1: off)
+    uint32_t grid_small = 1u << 22;          // BF_GRID_SMALL
     bool roll_join = true;                   // BF_ROLL_JOIN=0: bf_scene_update_endpoints flushes an open rolling sequence (round 3's behaviour)
     uint32_t debug_surv_batches = 0;         // BF_DEBUG_SURV_BATCHES (tests): size of the survivor area in batches, sizing rule off
 };
@@ -186,6 +188,8 @@ static bf_tunables read_tunables() {
     t.rf_min = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_RF_MIN", 16), 64));
     t.rf_th = (uint32_t) std::max<long long>(1, std::min<long long>(num("BF_RF_TH", 44), 64));
     t.rf_tm = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_RF_TM", 24), 64));
+    t.grid_share = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_GRID_SHARE", 3), 16));
+    t.grid_small = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_GRID_SMALL", 1ll << 22), 1ll << 30));
     t.roll_join = num("BF_ROLL_JOIN", 1) != 0;
     t.debug_surv_batches = (uint32_t) std::max<long long>(0, std::min<long long>(num("BF_DEBUG_SURV_BATCHES", 0), 1 << 14));
     return t;
@@ -198,6 +202,9 @@ struct bf_scene {
     // handles that render the SAME triangle / node arrays hold the same token (a clone that took its own snapshot of a
     // translated scene does not): bf_scene_translate_meshes copies on write only while the token is shared
     std::shared_ptr<char> geom_token;
+    // handles cloned from one another are meant to be in flight together (one per stream): how many of them have a rolling sequence
+    // open right now — small pools then launch a share of the persistent grids each (wf_setup: grid_share)
+    std::shared_ptr<std::atomic<int>> peers_rolling;
     bool geom_private = false;             // d.tris / d.nodes / d.wnodes point at this handle's own translated copies
     // one host thread at a time per handle (the handle owns the path pool its render's state lives in)
     mutable std::atomic_flag busy = ATOMIC_FLAG_INIT;
@@ -388,6 +395,7 @@ bf_status bf_scene_destroy(bf_scene *s) {
     // kernels of this handle that are still in flight read the arrays freed below (an open rolling sequence is simply
     // abandoned: its histograms stay incomplete, as documented)
     if (s->has_last) (void) hipEventSynchronize(s->last_done);
+    if (s->roll.open && s->peers_rolling) s->peers_rolling->fetch_sub(1, std::memory_order_relaxed);
     for (void *p : s->owned) (void) hipFree(p);
     for (void *p : s->wf_owned) (void) hipFree(p);
     if (s->wf_host) (void) hipHostFree(s->wf_host);
@@ -776,6 +784,7 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->tun = read_tunables();
     sc->geom = std::make_shared<bf_geometry>();
     sc->geom_token = std::make_shared<char>(0);
+    sc->peers_rolling = std::make_shared<std::atomic<int>>(0);
     {
         bf_status ast = bind_arrays(sc, flat, nullptr, true);
         if (ast != BF_OK) {
@@ -1177,6 +1186,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     sc->tun = src->tun;
     sc->geom = src->geom;
     sc->geom_token = src->geom_token;      // replaced below if the clone takes its own snapshot
+    sc->peers_rolling = src->peers_rolling;
     std::memset(&sc->wf, 0, sizeof(sc->wf));
     sc->info = src->info;
     sc->device = src->device;
@@ -1459,6 +1469,17 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     const unsigned max_blocks = (unsigned) ((nb + batches_per_block - 1) / batches_per_block);
     c.grid_shade = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) std::max(2, scene->tun.shade_waves), max_blocks));
     c.grid_trace = std::max(1u, std::min((unsigned) scene->n_cus * (unsigned) scene->tun.trace_waves, max_blocks));
+    // Small pools never fill the chip: their launches sit at latency floors with nearly idle waves, and a grid sized for the whole GPU
+    // keeps the next handle's launch out until it has drained.  Handles that roll side by side (clones of one scene, one per stream)
+    // therefore launch a SHARE of the persistent grids each, so that their launches overlap: C3 0.50 -> 0.45 ms per step, a C4 shard
+    // 0.62 -> 0.57 with four handles (profiles/r04_grid_share_ab.txt); a handle that rolls alone keeps the full grids (a lone launch
+    // is 20 % slower on a third of them).
+    if (rolling && scene->tun.grid_share > 1u && wf.n_slots < scene->tun.grid_small) {
+        const unsigned peers = (unsigned) std::max(1, scene->peers_rolling->load(std::memory_order_relaxed));
+        const unsigned share = std::min(peers, (unsigned) scene->tun.grid_share);
+        c.grid_shade = std::max(1u, c.grid_shade / share);
+        c.grid_trace = std::max(1u, c.grid_trace / share);
+    }
     c.tail_max = wf_tail_threshold(scene, rolling ? wf.n_main / 2 : wf.n_slots);
     wf.surv_claims_max = (wf.n_surv / 64u) / std::max(1u, c.grid_shade * batches_per_block);      // >= 1 by the sizing above
     if (rolling && scene->tun.debug_surv_batches) {                                                   // (the test hook: no rule at all)
@@ -1818,6 +1839,7 @@ static bf_status wf_roll_render(const bf_scene *scene, const bf_launch *launch, 
         r.fb_call_iters = I;
         r.fb_is_flush = false;
     }
+    if (!r.open) scene->peers_rolling->fetch_add(1, std::memory_order_relaxed);
     r.open = true;
     r.count += K;
     return BF_OK;
@@ -1901,6 +1923,7 @@ static bf_status wf_roll_flush(const bf_scene *scene, hipStream_t stream, bool s
     scene->wf_iters += done_iters;
     scene->wf_trace_launches += done_iters;
     r.open = false;
+    scene->peers_rolling->fetch_sub(1, std::memory_order_relaxed);
     if (scene->tables_in_pool) {
         // the sequence's last table version becomes the handle's tables again (home buffers), behind the flush's kernels
         const bf_scene::TabLayout &t = scene->tab;
