@@ -490,3 +490,35 @@ def test_rolling_fuzz_scenes(hiplib, seed, receive):
         if k in (0, 4):
             _, ro, _ = o.render(l1, records=True, threads=8)
             _same_records(recs[k], ro)
+
+
+@pytest.mark.parametrize("share", ["", "1", "8"])
+def test_clones_rolling_side_by_side_share_the_grids(hiplib, share, monkeypatch):
+    """Small pools of handles that roll at the same time launch a share of the persistent grids each (bf_api.cpp: wf_setup,
+    BF_GRID_SHARE: default 3, 1 = off, 8 = an eighth of the grids with eight peers... here four): three clones and their source,
+    one stream and one rolling sequence each, renders issued round-robin — every per-path record equals the oracle's whatever
+    grid a launch ran on, and every path of every render lands."""
+    import torch
+    if share:
+        monkeypatch.setenv("BF_GRID_SHARE", share)
+    sd, lp = scenes.bus_radar(n_tris=20000, n_paths=1 << 15, bins=256, dr=0.1)
+    first = capi.Scene(sd)
+    hs = [first] + [first.clone() for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in hs]
+    seeds = [[100 * j + k for k in range(3)] for j in range(len(hs))]
+    seqs = [_Sequence(h, lp, seeds[j], extra_flags=capi.BF_FLAG_COUNT) for j, h in enumerate(hs)]
+    for k in range(3):
+        for j, q in enumerate(seqs):
+            q.issue(ks=[k], stream=streams[j].cuda_stream)
+    stats = [h.flush(stream=streams[j].cuda_stream, want_stats=True) for j, h in enumerate(hs)]
+    oracle = OracleScene(sd)
+    for j, q in enumerate(seqs):
+        h, recs = q.results()
+        assert stats[j].n_paths == 3 * lp.n_paths and stats[j].n_guard == 0
+        for k, seed in enumerate(seeds[j]):
+            l1 = _launch_like(lp, seed)
+            _, ro, _ = oracle.render(l1, records=True, threads=8)
+            _same_records(recs[k], ro)
+            assert h[k][4] == lp.n_paths
+    for h in hs[1:] + hs[:1]:
+        h.close()
