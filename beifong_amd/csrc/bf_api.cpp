@@ -224,6 +224,7 @@ struct bf_scene {
     mutable std::vector<void *> wf_owned;
     uint32_t n_materials = 0;
     bool any_back_material = false;        // some twosided material has a second nested BSDF (general kernels)
+    bool any_resample = false;             // some transmitter re-samples the path's wavelength (resample_freq: general kernels, DLaunch::resample)
     bfd::DSensor sensor_host;              // host copy of the device sensor record
     mutable uint32_t last_variant = 0;     // BF_VARIANT_* of the latest render (bf_stats.kernel_variant)
     uint32_t film_w = 1, film_h = 1;       // the sensor's film (bf_sensor.film_width / film_height)
@@ -644,8 +645,12 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
                 for (int k = 0; k < 3; ++k) de.wid[k] = e.array.elem_dims[k];
             }
             if (e.type == BF_TRANSMITTER_WIGNER || e.type == BF_TRANSMITTER_PHASED) {
-                if (e.resample_freq) return fail(BF_ERR_UNSUPPORTED, "emitter %u: resample_freq=true is not supported", i);
                 if (e.signal_type > BF_SIGNAL_LINFMCW) return fail(BF_ERR_INVALID, "emitter %u: unknown signal type", i);
+                // sample_delta_frequency (wignertransmitter.cpp:152-168) defines the frequency for "linfmcw" and "cw" only
+                if (e.resample_freq && e.signal_type == BF_SIGNAL_PULSE)
+                    return fail(BF_ERR_UNSUPPORTED, "emitter %u: resample_freq=true with signaltype \"pulse\" reads an uninitialised frequency in the "
+                                                    "reference (wignertransmitter.cpp:152-168); use \"linfmcw\" or \"cw\"", i);
+                de.resample = e.resample_freq ? 1u : 0u;
                 de.signal_type = e.signal_type;
                 de.amplitude = e.amplitude;
                 de.freq_centre = e.freq_centre;
@@ -932,6 +937,8 @@ bf_status bf_scene_create(const bf_scene_desc *desc, bf_scene **out) {
     sc->d.tab_cache = (sc->tun.tab_cache && desc->n_materials <= bfd::kTabMaxMaterials && rects.size() <= bfd::kTabMaxRects) ? 1u : 0u;
     sc->any_back_material = false;
     for (uint32_t i = 0; i < desc->n_materials; ++i) sc->any_back_material = sc->any_back_material || desc->materials[i].back_material != 0;
+    sc->any_resample = false;
+    for (const auto &e : emitters) sc->any_resample = sc->any_resample || e.resample != 0u;
     sc->shapes_host = shapes;
     sc->d.n_tris = (uint32_t) btris.size();
     sc->d.n_rects = (uint32_t) rects.size();
@@ -1002,8 +1009,10 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
     bool phased = f.sensor.type == BF_RECEIVER_PHASED || scene->sensor_array_dev != nullptr;
     for (const auto &e : f.emitters) phased = phased || e.type == BF_TRANSMITTER_PHASED;
     for (float *p : scene->array_dev) phased = phased || p != nullptr;
+    bool resample_new = false;
+    for (const auto &e : f.emitters) resample_new = resample_new || e.resample != 0u;
     const bool join = scene->roll.open && scene->roll.stream == stream && !phased && scene->sensor_host.filt_n == 0u && f.sensor.filt_n == 0u &&
-                      scene->tab_next + 1u < bfd::kRollRing && scene->tun.roll_join;
+                      scene->tab_next + 1u < bfd::kRollRing && scene->tun.roll_join && resample_new == scene->any_resample;
     {
         bf_status ost = order_after_last(scene, stream);
         if (ost == BF_OK && !join) ost = close_sequence(scene, stream);
@@ -1081,6 +1090,7 @@ bf_status bf_scene_update_endpoints(bf_scene *scene, const bf_scene_desc *desc, 
         }
     }
     scene->sensor_host = f.sensor;
+    scene->any_resample = resample_new;
     scene->film_w = desc->sensor.film_width;
     scene->adc_t = f.window_t ? f.window_t : f.sensor.t_bins;
     scene->adc_f = f.window_f ? f.window_f : f.sensor.f_bins;
@@ -1194,6 +1204,7 @@ bf_status bf_scene_clone(const bf_scene *src, bf_scene **out) {
     sc->emitter_types = src->emitter_types;
     sc->n_materials = src->n_materials;
     sc->any_back_material = src->any_back_material;
+    sc->any_resample = src->any_resample;
     sc->sensor_host = src->sensor_host;
     sc->film_w = src->film_w;
     sc->adc_t = src->adc_t;
@@ -1439,7 +1450,7 @@ static bf_status wf_setup(const bf_scene *scene, const bfd::DLaunch &lp, uint64_
     wf.iq = lp.iq;
     wf.has_render = lp.batch != 0u ? 1u : 0u;
     wf.offsets = lp.batch_offsets;
-    wf.has_dop = lp.doppler ? 1u : 0u;
+    wf.has_dop = (lp.doppler || lp.resample) ? 1u : 0u;
     wf.box_slack = lp.box_slack;
     const size_t nb = wf.n_slots / 64;
     for (int b = 0; b < 2; ++b) {      // alive | trace | shadow of one parity are contiguous: one memset per bounce
@@ -2012,6 +2023,7 @@ static bool lean_profile(const bf_scene *scene, const bf_launch *launch, bool re
     if (scene->sensor_host.win_off_t || scene->sensor_host.win_off_f) return false;      // ADC window away from the origin
     if (scene->sensor_host.crop_x || scene->sensor_host.crop_y) return false;            // film crop window away from the origin
     if (scene->any_back_material) return false;                                            // twosided with two nested BSDFs
+    if (scene->any_resample) return false;                                                 // resample_freq transmitters
     const uint32_t et = scene->emitter_types[0];
     if (receive_mode)
         return (et == BF_TRANSMITTER_AREA || et == BF_TRANSMITTER_WIGNER) && scene->sensor_host.type == BF_RECEIVER_OMNI &&
@@ -2117,6 +2129,9 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
     scene->last_variant = (lp.lean ? (uint32_t) BF_VARIANT_LEAN : 0u) | (lp.wide ? (uint32_t) BF_VARIANT_WIDE : 0u);      // reconstruction filter wider than a pixel: the kernels' kWide variants
     lp.count = ((launch->flags & (BF_FLAG_STATS | BF_FLAG_COUNT)) || stats_out) ? 1u : 0u;
     lp.doppler = (receive_mode && (launch->flags & BF_FLAG_DOPPLER)) ? 1u : 0u;
+    lp.resample = (receive_mode && scene->any_resample) ? 1u : 0u;
+    if (lp.resample && lp.doppler)
+        return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_DOPPLER with a resample_freq transmitter: both rewrite the path's wavelength (one slot of path state)");
     lp.mix = (receive_mode && (launch->flags & BF_FLAG_MIX_RESAMPLE)) ? 1u : 0u;
     lp.n_chan_all = lp.n_chan * n_renders;
     lp.lds_hist = (lp.n_chan_all <= (uint32_t) bfd::kMaxLdsHist && !(launch->flags & BF_FLAG_GLOBAL_ATOMICS)) ? 1u : 0u;

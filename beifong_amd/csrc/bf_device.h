@@ -69,6 +69,7 @@ struct DEmitter {
     // wigner transmitter signal model (wignertransmitter.cpp:53-110)
     uint32_t signal_type;
     float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
+    uint32_t resample;    // m_resample_freq (wignertransmitter.cpp:211-221, 430-441): eval / sample_direction re-draw the path's wavelength from the signal
     // phased array (phasedtransmitter.cpp:108-165): n_velems virtual elements, BF_VELEM_FLOATS floats each (device copy)
     const float *velems;
     uint32_t n_velems;
@@ -217,6 +218,8 @@ struct DLaunch {
     const float4 *batch_offsets;    // device [batch] (x, y, z, -), or nullptr: meshes as built
     uint32_t mix;                   // BF_FLAG_MIX_RESAMPLE (receive modes): the ADC's frequency axis is the beat frequency
     uint32_t doppler;               // BF_FLAG_DOPPLER (receive modes): Shape::doppler shifts the path's wavelength
+    uint32_t resample;        // some transmitter has resample_freq set: the path's wavelength changes on the way (PathState::lambda0) and
+                              // PathState::dlambda holds the wavelength the RECEIVER sampled (what "mix_resample" subtracts)
     float box_slack;                // offsets only: node boxes widened by this much on the ray's side (bf_device_core.h: RayBox)
     // Rolling sequence (batch = 1, batch_paths = paths per render, n_paths = supply so far): descriptor ring [kRollRing]
     const DRoll *roll;              // nullptr: not a rolling launch

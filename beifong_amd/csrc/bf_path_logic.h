@@ -339,12 +339,35 @@ BF_DEV float tx_eval_signal(CEmitter &e, float time, float frequency) {
     return e.amplitude * e.amplitude;
 }
 BF_DEV float freq_of(float c, float lambda_nm) { return (float) ((double) c * (1.0 / ((double) lambda_nm * 1e-9))); }
+// WignerTransmitter::sample_delta_frequency (wignertransmitter.cpp:152-168), the frequency only: the instantaneous frequency of the
+// chirp ("linfmcw") or the carrier ("cw") at `time`; the weight it returns is 1 whatever eval_signal says (:165).  "pulse" leaves
+// `frequencies` uninitialised there: refused at scene creation (bf_api.cpp).
+BF_DEV float tx_delta_frequency(CEmitter &e, float time) {
+    if (e.signal_type == BF_SIGNAL_LINFMCW) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        return e.freq_centre + (e.freq_ext / e.pulse_len) * (t - ti);
+    }
+    return e.freq_centre;
+}
+// m_resample_freq (wignertransmitter.cpp:211-221, 430-441; phasedtransmitter.cpp likewise): the interaction's wavelength is
+// overwritten with MTS_C * rcp(frequency) * 1e9 (a double product rounded to Float) before anything else reads it, and the signal
+// power is 1
+BF_DEV float tx_resampled_lambda(const DScene &sc, CEmitter &e, float time) {
+    return (float) ((double) (sc.c * rcp(tx_delta_frequency(e, time))) * 1e9);
+}
 
 // Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
-template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, CEmitter &e, const SI &si, float si_time, float lambda0) {
+template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, CEmitter &e, const SI &si, float si_time, float &lambda0) {
     CRect &rc = c_rects(sc)[e.rect];
     if (e.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.radiance * rc.area : 0.f;
-    float signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
+    float signal_power;
+    if (rare<V>(e.resample != 0u)) {
+        lambda0 = tx_resampled_lambda(sc, e, si_time);           // si.wavelengths = ... (the path carries it on: spawn_ray, :451)
+        signal_power = 1.f;
+    } else {
+        signal_power = tx_eval_signal(e, si_time, freq_of(sc.c, lambda0));
+    }
     if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {
         // phasedtransmitter.cpp:296-381: geom_gain = antenna / area * sample_wigner(ds with the uninitialised d, Q5)
         float geom_gain = 1.f * rcp(rc.area);
@@ -356,7 +379,7 @@ template <int V = 0> BF_DEV float transmitter_eval(const DScene &sc, CEmitter &e
 }
 // Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
 template <int V = 0>
-BF_DEV float transmitter_sample_direction(const DScene &sc, CEmitter &e, V3 ref_p, float ref_time, float lambda0,
+BF_DEV float transmitter_sample_direction(const DScene &sc, CEmitter &e, V3 ref_p, float ref_time, float &lambda0,
                                           float sx, float sy, DirSample &ds) {
     CRect &rc = c_rects(sc)[e.rect];
     V3 p = xf_point(rc.to_world, mk(sx * 2.f - 1.f, sy * 2.f - 1.f, 0.f));
@@ -377,7 +400,13 @@ BF_DEV float transmitter_sample_direction(const DScene &sc, CEmitter &e, V3 ref_
     float geom_gain = 1.f / ds.pdf;
     float t = ref_time;
     if ((double) ds.dist > 5e-7) t += -ds.dist / sc.c;                      // retarded time :422-425
-    float signal_power = tx_eval_signal(e, t, freq_of(sc.c, lambda0));
+    float signal_power;
+    if (rare<V>(e.resample != 0u)) {
+        lambda0 = tx_resampled_lambda(sc, e, t);                 // it.wavelengths = ... : whether or not the sample is used
+        signal_power = 1.f;
+    } else {
+        signal_power = tx_eval_signal(e, t, freq_of(sc.c, lambda0));
+    }
     if (rare<V>(e.type == BF_TRANSMITTER_PHASED)) {
         // phasedtransmitter.cpp:560-585: geom_gain *= W; ds.pdf *= W; ds.pdf = sqrt(ds.pdf^2); extents = 1
         float w = phased_sample_wigner(e.velems, e.n_velems, e.wid, p, -ds.d, lambda0);
@@ -496,6 +525,7 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc0, const DLaunch
         s.time = time;
         float w = receiver_sample_ray<RX>(sc, wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
+        if (rare<RX>(lp.resample != 0u)) s.dlambda = s.lambda0;      // the wavelength the receiver sampled (DLaunch::resample)
     } else {
         // render_sample — integrator.cpp:263-283
         if (rare<RX>(c_sensor(sc).type != BF_SENSOR_PERSPECTIVE && c_sensor(sc).type != BF_SENSOR_RADIANCEMETER)) {   // endpoint.h:241, perspective.cpp:130, radiancemeter.cpp:86-87
@@ -947,7 +977,9 @@ BF_DEV void film_put(const DScene &sc0, const DLaunch &lp, const PathState &s, f
         CSensor &se = c_sensor(sc);
         float tf0 = s.t_rx - se.adc_sampling_start;
         float tf1 = freq_of(sc.c, rare<RX>(lp.doppler != 0u) ? s.lambda0 + s.dlambda : s.lambda0);
-        if (rare<RX>(lp.mix != 0u)) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, s.lambda0));      // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601)
+        // "mix_resample": |f_after - f_rx| (integrator.cpp:1590-1601); with a re-sampling transmitter lambda0 is the wavelength the
+        // path ENDS with (ray_.wavelengths = si.wavelengths, pathtimefrequency.cpp:451) and dlambda the one the receiver drew
+        if (rare<RX>(lp.mix != 0u)) tf1 = __builtin_fabsf(tf1 - freq_of(sc.c, rare<RX>(lp.resample != 0u) ? s.dlambda : s.lambda0));
         tf0 *= (float) se.t_bins / se.t_bandwidth;
         tf1 *= (float) se.f_bins / se.f_bandwidth;
         float L = __builtin_fabsf(s.aux) * s.result;          // aux holds ray_weight in receive mode

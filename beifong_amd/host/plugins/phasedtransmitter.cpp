@@ -44,7 +44,9 @@ public:
         }
         (void) props.float_("phase", 0.f);                   // eval_signal forces the phase output to 0 (:143)
         m_gain = props.float_("gain", 1.f);
-        if (m_resample_freq) Throw("phasedtransmitter: resample_freq=true is not supported");
+        // sample_delta_frequency (wignertransmitter.cpp:152-168) defines the re-sampled frequency for "linfmcw" and "cw" only
+        if (m_resample_freq && m_signal == "pulse")
+            Throw("phasedtransmitter: resample_freq=true with signaltype \"pulse\" reads an uninitialised frequency in the reference");
     }
     bf_emitter flatten(int32_t shape) const override {
         if (shape < 0) Throw("phased transmitter without an associated Shape");
@@ -60,7 +62,7 @@ public:
         e.pulse_len = m_t_ext;
         e.prf = m_repfreq;
         e.gain = m_gain;
-        e.resample_freq = 0;
+        e.resample_freq = m_resample_freq ? 1u : 0u;
         return e;
     }
 private:

@@ -239,14 +239,16 @@ class SceneDesc:
         return len(self.emitters) - 1
 
     def add_wigner_transmitter(self, shape, signaltype="pulse", amplitude=1.0, freq_centre=1.0, freq_ext=1.0,
-                               pulse_len=1.0, prf=1.0, gain=1.0):
-        """wignertransmitter.cpp:53-110; chirp_len/crf/freq_sweep of "linfmcw" map onto pulse_len/prf/freq_ext."""
+                               pulse_len=1.0, prf=1.0, gain=1.0, resample_freq=False):
+        """wignertransmitter.cpp:53-110; chirp_len/crf/freq_sweep of "linfmcw" map onto pulse_len/prf/freq_ext.
+        resample_freq (:211-221, 430-441): eval / sample_direction overwrite the path's wavelength with the signal's
+        instantaneous frequency at the (retarded) time, signal power 1 ("linfmcw" and "cw" only)."""
         e = capi.bf_emitter()
         e.type, e.shape, e.radiance = capi.BF_TRANSMITTER_WIGNER, shape, 1.0
         e.to_world, e.to_object = _m16(np.eye(4)), _m16(np.eye(4))
         e.signal_type = {"cw": capi.BF_SIGNAL_CW, "pulse": capi.BF_SIGNAL_PULSE, "linfmcw": capi.BF_SIGNAL_LINFMCW}[signaltype]
         e.amplitude, e.freq_centre, e.freq_ext, e.pulse_len, e.prf, e.gain = amplitude, freq_centre, freq_ext, pulse_len, prf, gain
-        e.resample_freq = 0
+        e.resample_freq = int(bool(resample_freq))
         self.emitters.append(e)
         self.shapes[shape].emitter = len(self.emitters) - 1
         return len(self.emitters) - 1
@@ -309,10 +311,10 @@ class SceneDesc:
         return a
 
     def add_phased_transmitter(self, shape, array, signaltype="cw", amplitude=1.0, freq_centre=1.0, freq_ext=0.0, pulse_len=1.0,
-                               prf=1.0, gain=1.0):
+                               prf=1.0, gain=1.0, resample_freq=False):
         """phasedtransmitter.cpp: the signal model of the Wigner transmitter + the array's Wigner function."""
         i = self.add_wigner_transmitter(shape, signaltype=signaltype, amplitude=amplitude, freq_centre=freq_centre,
-                                        freq_ext=freq_ext, pulse_len=pulse_len, prf=prf, gain=gain)
+                                        freq_ext=freq_ext, pulse_len=pulse_len, prf=prf, gain=gain, resample_freq=resample_freq)
         self.emitters[i].type = capi.BF_TRANSMITTER_PHASED
         self.emitters[i].array = array
         return i

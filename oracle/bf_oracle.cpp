@@ -1554,14 +1554,38 @@ inline float freq_of(const OScene &sc, float lambda_nm) {
 }
 
 struct RxCtx {
-    float lambda0;     // ray.wavelengths[0] (nm)
+    float lambda0;     // ray.wavelengths[0] (nm): what the receiver sampled — and, with a resample_freq transmitter, what the path
+                       // carries NOW (Transmitter::eval / sample_direction overwrite the interaction's wavelengths, spawn_ray hands
+                       // them to the next ray, pathtimefrequency.cpp:451 to the caller's)
+    float lambda_rx;   // the receiver's sample, kept for receive_type "mix_resample" (f_rx, integrator.cpp:1590)
 };
 
+// WignerTransmitter::sample_delta_frequency — wignertransmitter.cpp:152-168: the frequency only (its weight is set to 1, :165).
+// "pulse" leaves `frequencies` uninitialised there (refused by the engine at scene creation).
+static float tx_delta_frequency(const bf_emitter &e, float time) {
+    if (e.signal_type == BF_SIGNAL_LINFMCW) {
+        float t = fmodulo_j(time, rcp(e.prf));
+        float ti = 0 + e.pulse_len / 2;
+        return e.freq_centre + (e.freq_ext / e.pulse_len) * (t - ti);
+    }
+    return e.freq_centre;
+}
+// m_resample_freq == true (wignertransmitter.cpp:211-221, 430-441): wavelengths = MTS_C * rcp(frequency) * 1e9
+static float tx_resampled_lambda(const OScene &sc, const bf_emitter &e, float time) {
+    return (float) ((double) (sc.physics.c * rcp(tx_delta_frequency(e, time))) * 1e9);
+}
+
 // Transmitter::eval — areatransmitter.cpp:65-73, wignertransmitter.cpp:193-271
-static float transmitter_eval(const OScene &sc, const Emitter &e, const SI &si, const RxCtx &cx) {
+static float transmitter_eval(const OScene &sc, const Emitter &e, const SI &si, RxCtx &cx) {
     const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
     if (e.d.type == BF_TRANSMITTER_AREA) return (si.wi.z > 0.f) ? e.d.radiance * (rc.area) : 0.f;
-    float signal_power = tx_eval_signal(e.d, si.time, freq_of(sc, cx.lambda0));
+    float signal_power;
+    if (e.d.resample_freq) {
+        cx.lambda0 = tx_resampled_lambda(sc, e.d, si.time);      // const_cast<SurfaceInteraction3f&>(si).wavelengths = ... (:220)
+        signal_power = 1.f;
+    } else {
+        signal_power = tx_eval_signal(e.d, si.time, freq_of(sc, cx.lambda0));
+    }
     if (e.d.type == BF_TRANSMITTER_PHASED) {
         // phasedtransmitter.cpp:296-381: geom_gain = antenna_texture (1) * rcp(surface_area) * sample_wigner(ds), ds.d the
         // same uninitialised direction (Q5): 0.  No 2 pi here.
@@ -1577,7 +1601,7 @@ static float transmitter_eval(const OScene &sc, const Emitter &e, const SI &si, 
 
 // Transmitter::sample_direction — areatransmitter.cpp:117-165, wignertransmitter.cpp:373-534
 static float transmitter_sample_direction(const OScene &sc, const Emitter &e, const SI &ref, float sx, float sy,
-                                          const RxCtx &cx, DirectionSample &ds) {
+                                          RxCtx &cx, DirectionSample &ds) {
     const Rect &rc = sc.rects[sc.shapes[e.d.shape].rect];
     ds = rect_sample_direction(rc, ref.p, ref.time, sx, sy);
     bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
@@ -1587,7 +1611,13 @@ static float transmitter_sample_direction(const OScene &sc, const Emitter &e, co
     }
     float geom_gain = 1.f / ds.pdf;
     if ((double) ds.dist > 5e-7) ds.time += -ds.dist / sc.physics.c;       // retarded time :422-425
-    float signal_power = tx_eval_signal(e.d, ds.time, freq_of(sc, cx.lambda0));
+    float signal_power;
+    if (e.d.resample_freq) {
+        cx.lambda0 = tx_resampled_lambda(sc, e.d, ds.time);      // const_cast<Interaction3f&>(it).wavelengths = ... (:439): used or not
+        signal_power = 1.f;
+    } else {
+        signal_power = tx_eval_signal(e.d, ds.time, freq_of(sc, cx.lambda0));
+    }
     if (e.d.type == BF_TRANSMITTER_PHASED) {
         // phasedtransmitter.cpp:560-585: Wgain = sample_wigner(-d); geom_gain *= Wgain; ds.pdf *= Wgain[0];
         // ds.pdf = sqrt(ds.pdf * ds.pdf); extents = 1
@@ -1620,7 +1650,7 @@ static float transmitter_pdf_direction(const OScene &sc, const Emitter &e, const
 }
 
 // Scene::sample_transmitter_direction — src/librender/scene.cpp:249-299
-static float scene_sample_transmitter_direction(const OScene &sc, const SI &ref, float sx, float sy, const RxCtx &cx,
+static float scene_sample_transmitter_direction(const OScene &sc, const SI &ref, float sx, float sy, RxCtx &cx,
                                                 DirectionSample &ds, uint32_t &n_shadow) {
     float spec;
     size_t k = sc.emitters.size();
@@ -1684,7 +1714,7 @@ static float shape_doppler(const OScene &sc, const SI &si, float lambda_nm) {
 }
 
 // PathTimeFrequencyIntegrator::sample — src/integrators/pathtimefrequency.cpp:103-460
-static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, const RxCtx &cx) {
+static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp, Ray ray, RxCtx &cx) {
     PathResult r;
     float eta = 1.f, emission_weight = 1.f, throughput = 1.f, result = 0.f, result_im = 0.f;
     bool active = true;
@@ -2082,10 +2112,11 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     Ray ray;
     RxCtx cx;
     float w = receiver_sample_ray(sc, time, wl, fx, fy, ax, ay, ray, cx);
+    cx.lambda_rx = cx.lambda0;
     out.pr = ptf_sample(sc, lp, smp, ray, cx);
     float tf0 = time - s.adc_sampling_start;                // :1625-1626
     float tf1 = freq_of(sc, (lp.flags & BF_FLAG_DOPPLER) ? cx.lambda0 + out.pr.dlambda : cx.lambda0);
-    if (lp.flags & BF_FLAG_MIX_RESAMPLE) tf1 = std::fabs(tf1 - freq_of(sc, cx.lambda0));     // receive_type "mix_resample" :1590-1601
+    if (lp.flags & BF_FLAG_MIX_RESAMPLE) tf1 = std::fabs(tf1 - freq_of(sc, cx.lambda_rx));     // receive_type "mix_resample" :1590-1601
     tf0 *= (float) s.t_bins / s.t_bandwidth;                // :1639
     tf1 *= (float) s.f_bins / s.f_bandwidth;
     float L = std::fabs(w) * out.pr.L;                      // :1643

@@ -1243,3 +1243,85 @@ def test_twosided_with_two_nested_bsdfs(hiplib, receive):
     with pytest.raises(capi.BeifongError, match="back_material"):
         capi.Scene(sd)
     sd.materials[front].back_material = bad
+
+
+def _fmcw_scene(n_paths=30000, resample=True, signal="linfmcw", transmitter="wigner", f_bins=32):
+    """C2-recv geometry with an FMCW transmitter: one chirp of sweep B over the whole ADC window T (crf = 1 / T), a receiver
+    band equal to the chirp's, a 64 x f_bins ADC whose frequency axis spans B (the beat frequencies of "mix_resample")."""
+    lam = 8.6e6                                                    # nm: ~35 GHz
+    if transmitter == "phased":
+        sd, lp = scenes.phased_receive(n_tris=5000, n_paths=n_paths, phased_rx=False, phased_tx=True)
+    else:
+        sd, lp = scenes.bus_receive(n_tris=5000, n_paths=n_paths, t_bins=64, lambda_band_nm=(lam * 0.999, lam * 1.001))
+    c, lmin, lmax = sd.physics.c, sd.physics.lambda_min_nm, sd.physics.lambda_max_nm
+    e = sd.emitters[0]
+    e.signal_type = {"linfmcw": capi.BF_SIGNAL_LINFMCW, "cw": capi.BF_SIGNAL_CW, "pulse": capi.BF_SIGNAL_PULSE}[signal]
+    band = c / (lmin * 1e-9) - c / (lmax * 1e-9)
+    e.freq_ext = band
+    e.pulse_len = sd.sensor.t_bandwidth                            # chirp_len = T
+    e.prf = 1.0 / sd.sensor.t_bandwidth
+    e.resample_freq = int(resample)
+    sd.sensor.f_bins = f_bins
+    sd.sensor.f_bandwidth = band
+    sd.finalize()
+    lp.bins_y = f_bins
+    return sd, lp
+
+
+def test_resample_freq_transmitter(hiplib):
+    """m_resample_freq (wignertransmitter.cpp:211-221, 430-441; phasedtransmitter.cpp likewise): Transmitter::eval and
+    sample_direction overwrite the interaction's wavelength with the signal's instantaneous frequency at the (retarded) time,
+    spawn_ray carries it on and the caller's ray ends with it (pathtimefrequency.cpp:451) — the ADC's frequency row is the
+    transmitter's frequency at emission ("raw") or its beat with what the receiver sampled ("mix_resample": the de-chirped FMCW
+    return).  Every per-path record and every histogram cell equals the oracle's: both pipelines, I/Q mode, a rolling sequence
+    (the receiver's sample rides in the path state), the phased transmitter; "pulse" and the Doppler hook are refused."""
+    sd, lp = _fmcw_scene()
+    h_raw, _, st = _render_compare(sd, lp)                          # ("raw": absolute frequencies, far above this ADC's rows)
+    assert st.kernel_variant == 0                                   # general kernels: the lean profile has no re-sampling
+    sd0, _ = _fmcw_scene(resample=False)
+    _, r_on, _ = capi.Scene(sd).render(lp, records=True)
+    _, r_off, _ = capi.Scene(sd0).render(lp, records=True)
+    assert not np.array_equal(r_on["L"], r_off["L"])                # the Wigner gains see the re-sampled wavelength, power 1
+    # "mix_resample": |f_tx(t_emit) - f_rx| — rows spread over the sweep
+    lp_mix = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_MIX_RESAMPLE)
+    h_mix, _, _ = _render_compare(sd, lp_mix)
+    rows = h_mix.reshape(32, 64, 3)[:, :, 2].sum(1)
+    assert rows.sum() > 0.3 * lp.n_paths and np.count_nonzero(rows) > 8 and not np.array_equal(h_mix, h_raw)
+    # I/Q mode and "cw" (the carrier: every return at f_centre)
+    lp_iq = capi.make_launch(capi.BF_MODE_RECEIVE_IQ, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y)
+    _render_compare(sd, lp_iq)
+    sd_cw, _ = _fmcw_scene(signal="cw")
+    h_cw, _, _ = _render_compare(sd_cw, lp_mix)                     # |f_centre - f_rx|: half the sweep at most
+    rows_cw = h_cw.reshape(32, 64, 3)[:, :, 2].sum(1)
+    assert rows_cw[:16].sum() > 0 and rows_cw[17:].sum() == 0
+    # the phased transmitter shares the signal model
+    sd_ph, lp_ph = _fmcw_scene(n_paths=8000, transmitter="phased")
+    _render_compare(sd_ph, lp_ph)
+    # a rolling sequence: paths wait in the pool between launches with BOTH wavelengths in their state
+    import torch
+    g = capi.Scene(sd)
+    seeds = [5, 6, 7]
+    nch = g.channels(lp_mix)
+    hist = torch.zeros((len(seeds), nch), dtype=torch.float32, device="cuda")
+    rec = torch.zeros((len(seeds), lp.n_paths, 4), dtype=torch.int32, device="cuda")
+    for k, seed in enumerate(seeds):
+        l = capi.make_launch(lp.mode, lp.n_paths, seed=seed, bins=lp.bins, bins_y=lp.bins_y,
+                             flags=capi.BF_FLAG_MIX_RESAMPLE | capi.BF_FLAG_ROLLING)
+        g.render_device(l, hist[k].data_ptr(), records_ptr=rec[k].data_ptr())
+    g.flush()
+    torch.cuda.synchronize()
+    o = OracleScene(sd)
+    for k, seed in enumerate(seeds):
+        l = capi.make_launch(lp.mode, lp.n_paths, seed=seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_MIX_RESAMPLE)
+        ho, ro, _ = o.render(l, records=True, threads=8)
+        rg = rec[k].cpu().numpy().view(np.uint32).reshape(-1, 4)
+        rg = np.ascontiguousarray(rg).view(capi.PATH_RECORD_DTYPE).reshape(-1)
+        assert np.array_equal(rg["L"].view(np.uint32), ro["L"].view(np.uint32)) and np.array_equal(rg["n_rays"], ro["n_rays"])
+        assert np.allclose(hist[k].cpu().numpy(), ho, rtol=2e-5, atol=lp.n_paths * 2.0 ** -22 * max(1.0, float(np.abs(ro["L"]).max())))
+    # refused: "pulse" (sample_delta_frequency leaves the frequency uninitialised), the Doppler hook next to re-sampling
+    sd_p, _ = _fmcw_scene(signal="pulse")
+    with pytest.raises(capi.BeifongError, match="pulse"):
+        capi.Scene(sd_p)
+    lp_d = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_DOPPLER)
+    with pytest.raises(capi.BeifongError, match="DOPPLER"):
+        capi.Scene(sd).render(lp_d)

@@ -365,6 +365,34 @@ def test_receive_type_mix_resample_and_doppler_property(mitsuba):
                                           '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'))
 
 
+def test_resample_freq_property_of_the_transmitters(mitsuba):
+    """wignertransmitter.cpp:431 / :211-221 `resample_freq`: accepted for "linfmcw" and "cw" (sample_delta_frequency defines the
+    frequency for those), flattened into bf_emitter.resample_freq, and the oracle then bins every return of a de-chirping
+    receiver ("mix_resample") at the beat frequency; "pulse" reads an uninitialised frequency in the reference: refused."""
+    from beifong_amd.mitsuba.core.xml import load_string
+    from beifong_amd.mitsuba._host import HostError
+    fmcw = RECEIVE_SCENE.replace('<string name="signaltype" value="pulse"/><float name="amplitude" value="1"/>\n'
+                                 '            <float name="pulse_len" value="0.000588235"/><float name="prf" value="6.640625"/>\n'
+                                 '            <float name="freq_centre" value="39375"/><float name="freq_ext" value="1700"/>',
+                                 '<string name="signaltype" value="linfmcw"/><float name="amplitude" value="1"/>'
+                                 '<float name="chirp_len" value="0.150588"/><float name="crf" value="6.640625"/>'
+                                 '<float name="freq_centre" value="39375"/><float name="freq_sweep" value="1700"/>'
+                                 '<boolean name="resample_freq" value="true"/>')
+    assert 'resample_freq' in fmcw
+    fmcw = fmcw.replace('<receiver type="omnidirectional">',
+                        '<receiver type="omnidirectional"><string name="receive_type" value="mix_resample"/>')
+    scene = load_string(fmcw)
+    rx = scene.receivers()[0]
+    d = scene.flat_desc(rx).desc
+    assert d.emitters[0].resample_freq == 1 and d.emitters[0].signal_type == capi.BF_SIGNAL_LINFMCW
+    lp, h, _ = _oracle_on_host_scene(scene, rx)
+    assert lp.flags == capi.BF_FLAG_MIX_RESAMPLE
+    assert h.reshape(1, 256, 3)[0, :, 2].sum() > 0          # beats inside the ADC's 90 kHz (without re-sampling: none, see above)
+    with pytest.raises(HostError, match="pulse"):
+        load_string(RECEIVE_SCENE.replace('<string name="signaltype" value="pulse"/>',
+                                          '<string name="signaltype" value="pulse"/><boolean name="resample_freq" value="true"/>'))
+
+
 def test_phase_integrator_plugin_and_nested_depths(mitsuba):
     """phase.cpp (built at HEAD) wraps pathtimefrequency: `bins` S{k}.Y channels after Y, A, W; the
     MonteCarloIntegrator parameters are those of the NESTED integrator (integrator.cpp:1713-1728)."""
