@@ -18,7 +18,7 @@ BF_SHAPE_RECTANGLE, BF_SHAPE_MESH = range(2)
 BF_EMITTER_SPOT, BF_EMITTER_AREA, BF_TRANSMITTER_AREA, BF_TRANSMITTER_WIGNER, BF_TRANSMITTER_PHASED, BF_EMITTER_POINT = range(6)
 BF_SIGNAL_CW, BF_SIGNAL_PULSE, BF_SIGNAL_LINFMCW = range(3)
 BF_SENSOR_FLUXMETER, BF_SENSOR_PERSPECTIVE, BF_RECEIVER_OMNI, BF_RECEIVER_WIGNER, BF_RECEIVER_PHASED, BF_SENSOR_IRRADIANCEMETER, BF_SENSOR_RADIANCEMETER = range(7)
-BF_ABI_VERSION = 3          # include/beifong_hip.h: BF_ABI_VERSION
+BF_ABI_VERSION = 4          # include/beifong_hip.h: BF_ABI_VERSION
 BF_VELEM_FLOATS = 32
 BF_SI_FLOATS = 27
 BF_MODE_PATH, BF_MODE_RANGE, BF_MODE_TIME, BF_MODE_RECEIVE_RAW, BF_MODE_RECEIVE_IQ = range(5)
@@ -76,7 +76,8 @@ class bf_sensor(C.Structure):
                 ("freq_centre", C.c_float), ("freq_ext", C.c_float), ("gain", C.c_float), ("rx_sig_is_delta", C.c_uint32),
                 ("array", bf_phased_array), ("rfilter", bf_rfilter),
                 ("window_offset_t", C.c_uint32), ("window_offset_f", C.c_uint32), ("window_t_bins", C.c_uint32), ("window_f_bins", C.c_uint32),
-                ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32)]
+                ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
+                ("rx_signal_type", C.c_uint32), ("rx_pulse_len", C.c_float), ("rx_prf", C.c_float)]
 
 
 class bf_physics(C.Structure):

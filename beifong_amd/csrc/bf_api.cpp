@@ -686,6 +686,10 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         sen.freq_ext = desc->sensor.freq_ext;
         sen.gain = desc->sensor.gain;
         sen.rx_sig_is_delta = desc->sensor.rx_sig_is_delta;
+        if (desc->sensor.rx_signal_type > BF_SIGNAL_LINFMCW) return fail(BF_ERR_INVALID, "sensor: unknown rx_signal_type %u", desc->sensor.rx_signal_type);
+        sen.rx_signal = desc->sensor.rx_signal_type;
+        sen.rx_pulse_len = desc->sensor.rx_pulse_len;
+        sen.rx_prf = desc->sensor.rx_prf;
         {
             const bf_sensor &ds = desc->sensor;
             if (ds.window_t_bins || ds.window_f_bins || ds.window_offset_t || ds.window_offset_f) {      // adc.cpp:80-91
@@ -2055,10 +2059,17 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
             if (scene->emitter_types[i] != BF_TRANSMITTER_AREA && scene->emitter_types[i] != BF_TRANSMITTER_WIGNER &&
                 scene->emitter_types[i] != BF_TRANSMITTER_PHASED)
                 return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);
-        // the Wigner and phased receivers sample their own local-oscillator signal under "mix_resample"
-        // (wignerreceiver.cpp:72-110,179-189): not built, so the flag is the omnidirectional receiver's only
-        if ((launch->flags & BF_FLAG_MIX_RESAMPLE) && scene->sensor_host.type != BF_RECEIVER_OMNI)
-            return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_MIX_RESAMPLE: only the omnidirectional receiver has receive_type \"mix_resample\"");
+        // the Wigner and phased receivers sample their own local-oscillator signal under "mix_resample" (wignerreceiver.cpp:72-110,
+        // 172-189): built for the delta signals — a chirp's or a carrier's instantaneous frequency at the receive time
+        // (sample_delta_frequency :149-166) —; "pulse" leaves that frequency uninitialised there and a signal that is not a delta
+        // weights a uniform frequency sample with eval_signal: refused
+        if ((launch->flags & BF_FLAG_MIX_RESAMPLE) && scene->sensor_host.type != BF_RECEIVER_OMNI) {
+            if (!scene->sensor_host.rx_sig_is_delta || scene->sensor_host.rx_signal == BF_SIGNAL_PULSE)
+                return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: its local oscillator must be a delta "
+                                                "signal (sig_is_delta) of type \"linfmcw\" or \"cw\"");
+            if (scene->sensor_host.rx_signal == BF_SIGNAL_LINFMCW && !(scene->sensor_host.rx_pulse_len > 0.f && scene->sensor_host.rx_prf > 0.f))
+                return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE: the receiver's chirp needs rx_pulse_len > 0 and rx_prf > 0");
+        }
     } else {
         if (launch->flags & BF_FLAG_MIX_RESAMPLE) return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE is a receive-mode flag");
         if (is_rx) return fail(BF_ERR_INVALID, "render modes need a sensor (fluxmeter / perspective), not a receiver");

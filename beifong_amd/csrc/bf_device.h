@@ -105,6 +105,8 @@ struct DSensor {
     float t_bandwidth, f_bandwidth;
     float freq_centre, freq_ext, gain;
     uint32_t rx_sig_is_delta;
+    uint32_t rx_signal;       // "mix_resample" on the Wigner / phased receiver: its local oscillator (bf_sensor::rx_signal_type, ...)
+    float rx_pulse_len, rx_prf;
     const float *velems;      // BF_RECEIVER_PHASED (phasedreceiver.cpp:115-172)
     uint32_t n_velems;
     float wid[3];

@@ -440,7 +440,7 @@ template <int V = 0> BF_DEV float transmitter_pdf_direction(const DScene &sc, CE
 
 // Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
 template <int V = 0>
-BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
+BF_DEV float receiver_sample_ray(const DScene &sc, float time, bool mix, float wl_sample, float px, float py, float ax, float ay, V3 &o, V3 &d,
                                  float &mint, float &maxt, float &lambda0) {
     CSensor &s = c_sensor(sc);
     CRect &rc = c_rects(sc)[s.rect];
@@ -458,6 +458,16 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float wl_sample, float px, fl
         return (hi - lo) * rc.area;
     }
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    if (mix) {
+        // receive_type "mix_resample", a delta signal: sample_frequency -> sample_delta_frequency(time) (wignerreceiver.cpp:172-189,
+        // 149-166): the local oscillator's instantaneous frequency at the sampled receive time, weight 1
+        freq = s.freq_centre;
+        if (s.rx_signal == BF_SIGNAL_LINFMCW) {
+            float t = fmodulo_j(time, rcp(s.rx_prf));
+            float ti = 0 + s.rx_pulse_len / 2;
+            freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+        }
+    }
     lambda0 = (float) ((double) (sc.c * rcp(freq)) * 1e9);
     if (s.type == BF_RECEIVER_PHASED) {
         // phasedreceiver.cpp:299-365: geom_gain = W(ds) * pdf * (1 - (ds.d . ds.n)^4), ds.d the LOCAL cosine direction
@@ -523,7 +533,7 @@ template <int RX = 2> BF_DEV void generate_path(const DScene &sc0, const DLaunch
         float wl = next_1d(s.rng);
         s.t_rx = time;
         s.time = time;
-        float w = receiver_sample_ray<RX>(sc, wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
+        float w = receiver_sample_ray<RX>(sc, time, rare<RX>(lp.mix != 0u), wl, fx, fy, ax, ay, s.ro, s.rd, s.rmint, s.rmaxt, s.lambda0);
         s.aux = w;                 // receive has no path-length scalar: aux carries |ray_weight|'s operand
         if (rare<RX>(lp.resample != 0u)) s.dlambda = s.lambda0;      // the wavelength the receiver sampled (DLaunch::resample)
     } else {

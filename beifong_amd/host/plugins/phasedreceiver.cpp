@@ -1,4 +1,4 @@
-// src/receivers/phasedreceiver.cpp:45-172 — Phasedreceiver (fork), receive_type "raw": the Wigner receiver with the
+// src/receivers/phasedreceiver.cpp:45-172 — Phasedreceiver (fork), receive_types "raw" / "raw_resample" and — delta signals — "mix_resample": the Wigner receiver with the
 // array's n_elems^2 virtual elements (sample_wigner :279-297) and the (1 - cos^4) taper of sample_ray_differential (:338)
 #include "../render.h"
 using namespace bfh;
@@ -8,17 +8,40 @@ public:
         if (props.has_property("to_world"))
             Throw("Found a 'to_world' transformation -- this is not allowed. The phased receiver inherits this "
                   "transformation from its parent shape.");
-        // "mix_resample" gives this receiver a local-oscillator signal model of its own (phasedreceiver.cpp sample_frequency /
-        // eval_signal, "signaltype" cw | pulse | linfmcw): not built; the omnidirectional receiver takes mix_resample
-        if (m_receive_type == "mix_resample")
-            Throw("phasedreceiver: receive_type \"mix_resample\" is not supported (\"raw\" and \"raw_resample\" are)");
         if (m_adc->reconstruction_filter()->radius() > 0.5f + 1500 * 5.9604644775390625e-8f)
             Log(Warn, "This sensor should only be used with a reconstruction filter of radius 0.5 or lower(e.g. default box)");
-        m_f_centre = props.float_("freq_centre", 1.f);
-        m_f_ext = props.float_("freq_ext", 1.f);
-        m_gain = props.float_("gain", 1.f);
-        // :258 reads m_sig_is_delta, which the raw branch never initialises; explicit here
-        m_sig_is_delta = props.bool_("sig_is_delta", false);
+        m_signal = BF_SIGNAL_CW;
+        m_t_ext = m_repfreq = 0.f;
+        if (m_receive_type == "mix_resample") {
+            // the receiver's local oscillator (phasedreceiver.cpp:72-110): its frequency sample is the signal's instantaneous frequency at
+            // the receive time (sample_frequency -> sample_delta_frequency, :149-189) for the delta signals; "pulse" leaves that
+            // frequency uninitialised there and a non-delta signal weights a uniform sample with eval_signal: refused
+            const std::string sig = props.string("signaltype", "cw");
+            (void) props.float_("amplitude", 1.f);                  // eval_signal only (not reached by a delta signal)
+            (void) props.float_("phase", 0.f);
+            if (sig == "linfmcw") {
+                m_signal = BF_SIGNAL_LINFMCW;
+                m_repfreq = props.float_("crf", 1.f);
+                m_t_ext = props.float_("chirp_len", 1.f);
+                m_f_centre = props.float_("freq_centre", 1.f);
+                m_f_ext = props.float_("freq_sweep", 1.f);
+                m_sig_is_delta = props.bool_("sig_is_delta", true);
+            } else if (sig == "cw") {
+                m_f_centre = props.float_("freq_centre", 1.f);
+                m_f_ext = props.float_("freq_ext", 0.f);
+                m_sig_is_delta = props.bool_("sig_is_delta", true);
+            } else {
+                Throw("phasedreceiver: receive_type \"mix_resample\" with signaltype \"%s\" is not supported (\"linfmcw\" and \"cw\" are)", sig.c_str());
+            }
+            if (!m_sig_is_delta) Throw("phasedreceiver: receive_type \"mix_resample\" needs a delta signal (sig_is_delta)");
+            m_gain = props.float_("gain", 1.f);
+        } else {
+            m_f_centre = props.float_("freq_centre", 1.f);
+            m_f_ext = props.float_("freq_ext", 1.f);
+            m_gain = props.float_("gain", 1.f);
+            // :258 reads m_sig_is_delta, which the raw branch never initialises; explicit here
+            m_sig_is_delta = props.bool_("sig_is_delta", false);
+        }
     }
     void flatten(bf_sensor &s, int32_t shape) const override {
         if (shape < 0) Throw("receiver must be the child of a shape");
@@ -36,9 +59,13 @@ public:
         s.freq_ext = m_f_ext;
         s.gain = m_gain;
         s.rx_sig_is_delta = m_sig_is_delta;
+        s.rx_signal_type = m_signal;
+        s.rx_pulse_len = m_t_ext;
+        s.rx_prf = m_repfreq;
     }
 private:
-    float m_f_centre, m_f_ext, m_gain;
+    float m_f_centre, m_f_ext, m_gain, m_t_ext, m_repfreq;
+    uint32_t m_signal;
     bool m_sig_is_delta;
     PhasedArray m_array;
 };

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 3
+#define BF_ABI_VERSION 4
 
 typedef int bf_status;
 enum {
@@ -200,6 +200,14 @@ typedef struct bf_sensor {
      * (p + crop_offset) + next_2d and the sensor takes (position - crop_offset) / crop_size (integrator.cpp:263,276-278); a
      * perspective camera's sample_to_camera already contains the crop (sensor.h:196-231).  Both zero without a crop window.   */
     uint32_t crop_offset_x, crop_offset_y;
+    /* Wigner / phased receiver under receive_type "mix_resample" (BF_FLAG_MIX_RESAMPLE): the receiver samples its frequency from a
+     * local-oscillator signal of its own (wignerreceiver.cpp:72-110, sample_frequency :172-189, sample_delta_frequency :149-166):
+     * BF_SIGNAL_LINFMCW — the chirp's instantaneous frequency freq_centre + (freq_ext / rx_pulse_len) * (t - rx_pulse_len / 2),
+     * t = fmodulo(time, 1 / rx_prf), freq_ext the sweep — or BF_SIGNAL_CW (freq_centre), at the sampled receive time, weight 1
+     * (sig_is_delta, the plugins' default for both).  Against a resample_freq transmitter the ADC's frequency axis is then the
+     * de-chirped beat.  Not read in the "raw" receive types; the omnidirectional receiver has no signal.  */
+    uint32_t rx_signal_type;
+    float rx_pulse_len, rx_prf;
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

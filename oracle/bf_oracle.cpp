@@ -1817,7 +1817,7 @@ static PathResult ptf_sample(const OScene &sc, const bf_launch &lp, Sampler &smp
 }
 
 // Receiver::sample_ray_differential — omnidirectional.cpp:72-107, wignerreceiver.cpp:208-269
-static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, float px, float py, float ax, float ay,
+static float receiver_sample_ray(const OScene &sc, float time, bool mix, float wl_sample, float px, float py, float ax, float ay,
                                  Ray &ray, RxCtx &cx) {
     const bf_sensor &s = sc.sensor;
     const Rect &rc = sc.rects[sc.shapes[s.shape].rect];
@@ -1838,6 +1838,17 @@ static float receiver_sample_ray(const OScene &sc, float time, float wl_sample, 
     }
     // wigner receiver, receive_type raw: frequency uniform in [fc - B/2, fc + B/2]
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    if (mix) {
+        // receive_type "mix_resample" with a delta signal (sig_is_delta, the default of "linfmcw" and "cw"): sample_frequency ->
+        // sample_delta_frequency(time) — wignerreceiver.cpp:172-189, 149-166: the local oscillator's instantaneous frequency at
+        // the sampled receive time, weight 1
+        freq = s.freq_centre;
+        if (s.rx_signal_type == BF_SIGNAL_LINFMCW) {
+            float t = fmodulo_j(time, rcp(s.rx_prf));
+            float ti = 0 + s.rx_pulse_len / 2;
+            freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+        }
+    }
     // Wavelength wavelength = MTS_C*rcp(frequencies)*1e9  (float * float, then * double literal)
     cx.lambda0 = (float) ((double) (sc.physics.c * rcp(freq)) * 1e9);
     if (s.type == BF_RECEIVER_PHASED) {
@@ -2111,7 +2122,7 @@ static SampleOut receive_sample(const OScene &sc, const bf_launch &lp, Sampler &
     float wl = smp.next_1d();                               // :1565
     Ray ray;
     RxCtx cx;
-    float w = receiver_sample_ray(sc, time, wl, fx, fy, ax, ay, ray, cx);
+    float w = receiver_sample_ray(sc, time, (lp.flags & BF_FLAG_MIX_RESAMPLE) != 0, wl, fx, fy, ax, ay, ray, cx);
     cx.lambda_rx = cx.lambda0;
     out.pr = ptf_sample(sc, lp, smp, ray, cx);
     float tf0 = time - s.adc_sampling_start;                // :1625-1626
@@ -2339,9 +2350,15 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
         g_err = "receive mode needs a receiver";
         return BF_ERR_INVALID;
     }
-    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && (!is_receive || s->sc.sensor.type != BF_RECEIVER_OMNI)) {
-        g_err = "BF_FLAG_MIX_RESAMPLE: receive modes with the omnidirectional receiver only";
+    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && !is_receive) {
+        g_err = "BF_FLAG_MIX_RESAMPLE: receive modes only";
         return BF_ERR_INVALID;
+    }
+    // the Wigner / phased receiver's own local oscillator: delta signals "linfmcw" / "cw" (wignerreceiver.cpp:149-189)
+    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && s->sc.sensor.type != BF_RECEIVER_OMNI &&
+        (!s->sc.sensor.rx_sig_is_delta || s->sc.sensor.rx_signal_type == BF_SIGNAL_PULSE)) {
+        g_err = "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: its local oscillator must be a delta signal of type linfmcw or cw";
+        return BF_ERR_UNSUPPORTED;
     }
     const OScene &sc = s->sc;
     const uint32_t nchan = launch_channels(*lp);

@@ -1115,8 +1115,8 @@ def test_doppler_hook_off_by_default_and_bit_exact_when_on(hiplib):
 def test_mix_resample_receive_type(hiplib):
     """BF_FLAG_MIX_RESAMPLE (receive_type "mix_resample", integrator.cpp:1588-1603): the frequency row is that of the beat
     |c / lambda_after - f_rx|.  With the Doppler hook every path's record and row equals the oracle's (both pipelines);
-    without it the beat is 0 and every sample is dropped, as at the reference's HEAD; the Wigner receiver and render modes
-    refuse the flag."""
+    without it the beat is 0 and every sample is dropped, as at the reference's HEAD; render modes refuse the flag, and so does a
+    Wigner receiver whose signal is no delta (test_fmcw_dechirp_with_the_receivers_local_oscillator has the delta case)."""
     sd, lp = _doppler_scene(3.0)
     sd.sensor.f_bandwidth = 0.5 * sd.physics.c / (sd.physics.lambda_min_nm * 1e-9)
     sd.finalize()
@@ -1135,9 +1135,9 @@ def test_mix_resample_receive_type(hiplib):
     g = capi.Scene(sd)
     hb, rb, _ = g.render_batch(lp_mix, 2, seeds=[lp.seed, lp.seed + 1], records=True)
     assert np.allclose(hb[0], h_mix, rtol=1e-4, atol=1e-3)
-    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=256, t_bins=4, receiver="wigner")
+    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=256, t_bins=4, receiver="wigner")      # (a Wigner receiver that is no delta signal)
     lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
-    with pytest.raises(capi.BeifongError):
+    with pytest.raises(capi.BeifongError, match="delta"):
         capi.Scene(sdw).render(lpw)
     sdr, lpr = scenes.bus_radar(n_tris=500, n_paths=256, bins=16, dr=0.5)
     lpr.flags = capi.BF_FLAG_MIX_RESAMPLE
@@ -1325,3 +1325,43 @@ def test_resample_freq_transmitter(hiplib):
     lp_d = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_DOPPLER)
     with pytest.raises(capi.BeifongError, match="DOPPLER"):
         capi.Scene(sd).render(lp_d)
+
+
+@pytest.mark.parametrize("receiver", ["wigner", "phased"])
+def test_fmcw_dechirp_with_the_receivers_local_oscillator(hiplib, receiver):
+    """receive_type "mix_resample" on the Wigner / phased receiver (wignerreceiver.cpp:72-110, 149-189): the receiver's frequency
+    sample is its own chirp's instantaneous frequency at the receive time; against a resample_freq transmitter with the same chirp
+    the ADC's frequency axis is the de-chirped beat |f_tx(t - delay) - f_lo(t)| = (sweep / chirp_len) * delay — every return of
+    one range in ONE frequency row, rows proportional to the time bin of the same return.  Per-path parity with the oracle in
+    both pipelines; the "raw" receive types of the same scene do not read the local oscillator."""
+    lam = 8.6e6
+    if receiver == "phased":
+        sd, lp = scenes.phased_receive(n_tris=5000, n_paths=20000, phased_rx=True, phased_tx=False)
+    else:
+        sd, lp = scenes.bus_receive(n_tris=5000, n_paths=30000, t_bins=64, receiver="wigner", lambda_band_nm=(lam * 0.999, lam * 1.001))
+    c = sd.physics.c
+    T = sd.sensor.t_bandwidth
+    f_c = sd.emitters[0].freq_centre
+    sweep = 0.002 * f_c
+    e = sd.emitters[0]
+    e.signal_type, e.freq_ext, e.pulse_len, e.prf, e.resample_freq = capi.BF_SIGNAL_LINFMCW, sweep, T, 1.0 / T, 1
+    s = sd.sensor
+    s.freq_centre, s.freq_ext, s.rx_sig_is_delta = f_c, sweep, 1
+    s.rx_signal_type, s.rx_pulse_len, s.rx_prf = capi.BF_SIGNAL_LINFMCW, T, 1.0 / T
+    s.f_bins, s.f_bandwidth = 64, sweep                   # beat = sweep * delay / T: the frequency row IS the delay's time bin
+    sd.finalize()
+    lp.bins_y = 64
+    lp_mix = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=64, flags=capi.BF_FLAG_MIX_RESAMPLE)
+    h, _, st = _render_compare(sd, lp_mix)
+    assert st.kernel_variant == 0
+    cube = h.reshape(64, lp.bins, 3)[:, :, 2]                                # [frequency row][time bin] sample counts
+    assert cube.sum() > 0.2 * lp.n_paths
+    # de-chirped: the beat is the delay's, whenever the return is received — the row profile (the scene's range profile: ground and
+    # bus) is the same in every part of the receive window (past the first returns' wrap into the previous chirp)
+    nt = lp.bins
+    p1, p2 = cube[:, nt // 4:nt // 2].sum(1), cube[:, nt // 2:].sum(1)
+    assert p1.sum() > 0 and p2.sum() > 0
+    assert np.corrcoef(p1 / p1.sum(), p2 / p2.sum())[0, 1] > 0.95
+    # "raw" on the same scene: parity too, and another histogram (absolute frequencies: outside this ADC)
+    h_raw, _, _ = _render_compare(sd, lp)
+    assert not np.array_equal(h_raw, h)

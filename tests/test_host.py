@@ -335,7 +335,8 @@ def test_receive_scene_with_fork_plugins(mitsuba):
 def test_receive_type_mix_resample_and_doppler_property(mitsuba):
     """receiver.cpp:21 receive_type: "mix_resample" (integrator.cpp:1588-1603) -> BF_FLAG_MIX_RESAMPLE on the omnidirectional
     receiver; the integrator's "doppler" switch (not a reference property; the reference carries the calls commented out)
-    -> BF_FLAG_DOPPLER; "mixer" (an empty branch in the reference) and mix_resample on the Wigner receiver are refused."""
+    -> BF_FLAG_DOPPLER; "mixer" (an empty branch in the reference) is refused; mix_resample on the Wigner receiver reads the
+    receiver's own local-oscillator properties (delta signals only)."""
     from beifong_amd.mitsuba.core.xml import load_string
     from beifong_amd.mitsuba._host import HostError
     mix = RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
@@ -360,9 +361,25 @@ def test_receive_type_mix_resample_and_doppler_property(mitsuba):
                                               '<receiver type="omnidirectional"><string name="receive_type" value="mixer"/>'))
     with pytest.raises(HostError, match="mixer"):
         scene.integrator().launch_for(scene.receivers()[0])
-    with pytest.raises(HostError, match="mix_resample"):
+    # the Wigner receiver under mix_resample has a local oscillator of its own: delta signals "linfmcw" / "cw" (wignerreceiver.cpp:72-110)
+    wig = RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
+                                '<string name="signaltype" value="linfmcw"/><float name="chirp_len" value="0.150588"/>'
+                                '<float name="crf" value="6.640625"/><float name="freq_centre" value="39375"/><float name="freq_sweep" value="1700"/>')
+    scene = load_string(wig)
+    rx = scene.receivers()[0]
+    d = scene.flat_desc(rx).desc
+    assert d.sensor.type == capi.BF_RECEIVER_WIGNER and d.sensor.rx_signal_type == capi.BF_SIGNAL_LINFMCW and d.sensor.rx_sig_is_delta == 1
+    assert abs(d.sensor.rx_pulse_len - 0.150588) < 1e-8 and abs(d.sensor.rx_prf - 6.640625) < 1e-6 and d.sensor.freq_ext == 1700.0
+    assert scene.integrator().launch_for(rx).flags == capi.BF_FLAG_MIX_RESAMPLE
+    with pytest.raises(HostError, match="pulse"):
         load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
-                                          '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'))
+                                          '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
+                                          '<string name="signaltype" value="pulse"/>'))
+    with pytest.raises(HostError, match="delta"):
+        load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                          '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
+                                          '<boolean name="sig_is_delta" value="false"/>'))
 
 
 def test_resample_freq_property_of_the_transmitters(mitsuba):
