@@ -137,7 +137,9 @@ typedef struct bf_emitter {
     /* wigner transmitter signal model (wignertransmitter.cpp:53-146)        */
     uint32_t signal_type;
     float amplitude, freq_centre, freq_ext, pulse_len, prf, gain;
-    uint32_t resample_freq;
+    uint32_t resample_freq;  /* m_resample_freq (:211-221, 430-441): eval / sample_direction overwrite the path's wavelength with
+                                MTS_C / f * 1e9, f the signal's instantaneous frequency ("linfmcw", "cw") at the interaction's /
+                                the retarded time, signal power 1; "pulse": BF_ERR_UNSUPPORTED (uninitialised in the reference) */
     bf_phased_array array;   /* BF_TRANSMITTER_PHASED                        */
 } bf_emitter;
 
@@ -278,8 +280,11 @@ enum {
     BF_FLAG_MIX_RESAMPLE = 16u, /* receive modes: receive_type "mix_resample" (integrator.cpp:1588-1603): the ADC's frequency
                                   coordinate is the BEAT frequency |c / lambda_after - c / lambda_rx| between the wavelength the
                                   path ends with and the one the receiver sampled, instead of c / lambda ("raw" / "raw_resample",
-                                  :1604-1623).  The two differ only by the Doppler hook, so without BF_FLAG_DOPPLER the beat is
-                                  exactly 0 and every sample falls outside the ADC (ceil(0 - 1) = -1), as at the reference's HEAD.
+                                  :1604-1623).  The two differ by the Doppler hook (without it the beat is exactly 0 and every
+                                  sample falls outside the ADC, ceil(0 - 1) = -1, as at the reference's HEAD) and by resample_freq
+                                  transmitters (bf_emitter): the beat of the transmitter's instantaneous frequency with what the
+                                  receiver sampled — uniformly from the band (omnidirectional) or from its own local oscillator
+                                  (Wigner / phased receiver: bf_sensor.rx_signal_type ..., delta signals only).
                                   receive_type "mixer" (:1624-1634) is an empty branch there and has no counterpart here. */
     BF_FLAG_ROLLING = 32u,     /* bf_render_device only: the render joins the handle's ROLLING SEQUENCE (below, bf_scene_flush) */
     BF_FLAG_TIMING = 64u,      /* rolling sequences: HIP events around every kernel launch; bf_scene_flush's statistics carry
