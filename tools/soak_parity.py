@@ -75,6 +75,22 @@ if len(sys.argv) > 2 and sys.argv[2] == "misc":
         sd, lp = scenes.trans_rad(spp=1 << 22)
         lp.seed = 1300 + seed
         check(f"C1 trans_rad fluxmeter + spot seed {1300 + seed}", sd, lp, flags=(0, capi.BF_FLAG_MEGAKERNEL))
+        # round 4: FMCW — a resample_freq chirp transmitter against the Wigner receiver's own local oscillator ("mix_resample"),
+        # 200 k-triangle bus, 2^22 paths, a 256 x 64 time / beat-frequency ADC
+        lam = 8.6e6
+        sd, lp = scenes.bus_receive(n_tris=200_000, n_paths=1 << 22, t_bins=256, dr=0.1, seed=1400 + seed, receiver="wigner",
+                                    lambda_band_nm=(lam * 0.999, lam * 1.001))
+        Tw, f_c = sd.sensor.t_bandwidth, sd.emitters[0].freq_centre
+        e, sn = sd.emitters[0], sd.sensor
+        e.signal_type, e.freq_ext, e.pulse_len, e.prf, e.resample_freq = capi.BF_SIGNAL_LINFMCW, 0.002 * f_c, Tw, 1.0 / Tw, 1
+        sn.freq_centre, sn.freq_ext, sn.rx_sig_is_delta = f_c, 0.002 * f_c, 1
+        sn.rx_signal_type, sn.rx_pulse_len, sn.rx_prf = capi.BF_SIGNAL_LINFMCW, Tw, 1.0 / Tw
+        sn.f_bins, sn.f_bandwidth = 64, 0.002 * f_c
+        sd.finalize()
+        lp.bins_y = 64
+        lp.flags = capi.BF_FLAG_MIX_RESAMPLE                 # (the oracle's render takes the launch as it stands)
+        check(f"C2-recv FMCW de-chirp (resample_freq + mix_resample, Wigner receiver) seed {1400 + seed}", sd, lp,
+              flags=(capi.BF_FLAG_MIX_RESAMPLE, capi.BF_FLAG_MIX_RESAMPLE | capi.BF_FLAG_MEGAKERNEL))
     print("FAILED" if fails else "all cases bit-exact")
     sys.exit(1 if fails else 0)
 
