@@ -77,7 +77,7 @@ class bf_sensor(C.Structure):
                 ("array", bf_phased_array), ("rfilter", bf_rfilter),
                 ("window_offset_t", C.c_uint32), ("window_offset_f", C.c_uint32), ("window_t_bins", C.c_uint32), ("window_f_bins", C.c_uint32),
                 ("crop_offset_x", C.c_uint32), ("crop_offset_y", C.c_uint32),
-                ("rx_signal_type", C.c_uint32), ("rx_pulse_len", C.c_float), ("rx_prf", C.c_float)]
+                ("rx_signal_type", C.c_uint32), ("rx_pulse_len", C.c_float), ("rx_prf", C.c_float), ("rx_amplitude", C.c_float)]
 
 
 class bf_physics(C.Structure):

@@ -690,6 +690,7 @@ static bf_status flatten(const bf_scene_desc *desc, Flat &f, bool with_meshes) {
         sen.rx_signal = desc->sensor.rx_signal_type;
         sen.rx_pulse_len = desc->sensor.rx_pulse_len;
         sen.rx_prf = desc->sensor.rx_prf;
+        sen.rx_amplitude = desc->sensor.rx_amplitude;
         {
             const bf_sensor &ds = desc->sensor;
             if (ds.window_t_bins || ds.window_f_bins || ds.window_offset_t || ds.window_offset_f) {      // adc.cpp:80-91
@@ -2060,15 +2061,14 @@ static bf_status render_common(const bf_scene *scene, const bf_launch *launch, c
                 scene->emitter_types[i] != BF_TRANSMITTER_PHASED)
                 return fail(BF_ERR_INVALID, "receive mode: emitter %u is not a transmitter", i);
         // the Wigner and phased receivers sample their own local-oscillator signal under "mix_resample" (wignerreceiver.cpp:72-110,
-        // 172-189): built for the delta signals — a chirp's or a carrier's instantaneous frequency at the receive time
-        // (sample_delta_frequency :149-166) —; "pulse" leaves that frequency uninitialised there and a signal that is not a delta
-        // weights a uniform frequency sample with eval_signal: refused
+        // 172-189): a delta signal's instantaneous frequency at the receive time (sample_delta_frequency :149-166: a chirp's or a
+        // carrier's; "pulse" leaves it uninitialised there: refused), or a uniform frequency weighted with eval_signal
         if ((launch->flags & BF_FLAG_MIX_RESAMPLE) && scene->sensor_host.type != BF_RECEIVER_OMNI) {
-            if (!scene->sensor_host.rx_sig_is_delta || scene->sensor_host.rx_signal == BF_SIGNAL_PULSE)
-                return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: its local oscillator must be a delta "
-                                                "signal (sig_is_delta) of type \"linfmcw\" or \"cw\"");
-            if (scene->sensor_host.rx_signal == BF_SIGNAL_LINFMCW && !(scene->sensor_host.rx_pulse_len > 0.f && scene->sensor_host.rx_prf > 0.f))
-                return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE: the receiver's chirp needs rx_pulse_len > 0 and rx_prf > 0");
+            if (scene->sensor_host.rx_sig_is_delta && scene->sensor_host.rx_signal == BF_SIGNAL_PULSE)
+                return fail(BF_ERR_UNSUPPORTED, "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: a \"pulse\" local oscillator that is a delta "
+                                                "signal reads an uninitialised frequency in the reference (wignerreceiver.cpp:149-166)");
+            if (scene->sensor_host.rx_signal != BF_SIGNAL_CW && !(scene->sensor_host.rx_pulse_len > 0.f && scene->sensor_host.rx_prf > 0.f))
+                return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE: the receiver's chirp / pulse needs rx_pulse_len > 0 and rx_prf > 0");
         }
     } else {
         if (launch->flags & BF_FLAG_MIX_RESAMPLE) return fail(BF_ERR_INVALID, "BF_FLAG_MIX_RESAMPLE is a receive-mode flag");

@@ -106,7 +106,7 @@ struct DSensor {
     float freq_centre, freq_ext, gain;
     uint32_t rx_sig_is_delta;
     uint32_t rx_signal;       // "mix_resample" on the Wigner / phased receiver: its local oscillator (bf_sensor::rx_signal_type, ...)
-    float rx_pulse_len, rx_prf;
+    float rx_pulse_len, rx_prf, rx_amplitude;
     const float *velems;      // BF_RECEIVER_PHASED (phasedreceiver.cpp:115-172)
     uint32_t n_velems;
     float wid[3];

@@ -458,14 +458,26 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float time, bool mix, float w
         return (hi - lo) * rc.area;
     }
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    float signal_power = 1.f;
     if (mix) {
-        // receive_type "mix_resample", a delta signal: sample_frequency -> sample_delta_frequency(time) (wignerreceiver.cpp:172-189,
-        // 149-166): the local oscillator's instantaneous frequency at the sampled receive time, weight 1
-        freq = s.freq_centre;
-        if (s.rx_signal == BF_SIGNAL_LINFMCW) {
-            float t = fmodulo_j(time, rcp(s.rx_prf));
-            float ti = 0 + s.rx_pulse_len / 2;
-            freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+        // receive_type "mix_resample" (wignerreceiver.cpp:172-189): the receiver's own local oscillator
+        if (s.rx_sig_is_delta) {
+            // sample_delta_frequency(time) (:149-166): the instantaneous frequency at the sampled receive time, weight 1
+            freq = s.freq_centre;
+            if (s.rx_signal == BF_SIGNAL_LINFMCW) {
+                float t = fmodulo_j(time, rcp(s.rx_prf));
+                float ti = 0 + s.rx_pulse_len / 2;
+                freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+            }
+        } else {
+            // the uniform sample above, weighted with eval_signal(time, f) (:118-142)
+            signal_power = s.rx_amplitude * s.rx_amplitude;
+            if (s.rx_signal != BF_SIGNAL_CW) {
+                float t = fmodulo_j(time, rcp(s.rx_prf));
+                float ti = 0 + s.rx_pulse_len / 2;
+                float fi = s.rx_signal == BF_SIGNAL_LINFMCW ? s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti) : s.freq_centre;
+                signal_power = rect_j((t - ti) / s.rx_pulse_len) > 0.f ? wchirp_j(t - ti, freq - fi, s.rx_pulse_len, s.rx_amplitude) : 0.f;
+            }
         }
     }
     lambda0 = (float) ((double) (sc.c * rcp(freq)) * 1e9);
@@ -476,13 +488,13 @@ BF_DEV float receiver_sample_ray(const DScene &sc, float time, bool mix, float w
         float geom = w * rc.inv_area * (1 - dn * dn * dn * dn);
         float ext = rc.area * kPi;
         if (!s.rx_sig_is_delta) ext = (float) ((double) (ext * (sc.c * rcp(s.freq_ext))) * 1e9);
-        return 1.f * s.gain * geom * ext;
+        return signal_power * s.gain * geom * ext;
     }
     float ws = rect_sample_wigner(rc, o, local, lambda0);   // ds.d is the LOCAL cosine direction (:249-252)
     float geom_gain = ws * rc.inv_area;
     float extents = rc.area * kPi;
     if (!s.rx_sig_is_delta) extents = (float) ((double) (extents * (sc.c * rcp(s.freq_ext))) * 1e9);
-    return 1.f * s.gain * geom_gain * extents;
+    return signal_power * s.gain * geom_gain * extents;
 }
 
 // Mode specialisation: RX = 0 compiles the render modes only (path / range / time), RX = 1 the receive modes only,

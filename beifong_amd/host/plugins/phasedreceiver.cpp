@@ -12,12 +12,13 @@ public:
             Log(Warn, "This sensor should only be used with a reconstruction filter of radius 0.5 or lower(e.g. default box)");
         m_signal = BF_SIGNAL_CW;
         m_t_ext = m_repfreq = 0.f;
+        m_amplitude = 1.f;
         if (m_receive_type == "mix_resample") {
             // the receiver's local oscillator (phasedreceiver.cpp:72-110): its frequency sample is the signal's instantaneous frequency at
-            // the receive time (sample_frequency -> sample_delta_frequency, :149-189) for the delta signals; "pulse" leaves that
-            // frequency uninitialised there and a non-delta signal weights a uniform sample with eval_signal: refused
+            // the receive time for a delta signal (sample_frequency -> sample_delta_frequency, :149-189), a uniform frequency weighted
+            // with eval_signal (:118-142) otherwise; a "pulse" that is a delta reads an uninitialised frequency there: refused
             const std::string sig = props.string("signaltype", "cw");
-            (void) props.float_("amplitude", 1.f);                  // eval_signal only (not reached by a delta signal)
+            m_amplitude = props.float_("amplitude", 1.f);
             (void) props.float_("phase", 0.f);
             if (sig == "linfmcw") {
                 m_signal = BF_SIGNAL_LINFMCW;
@@ -26,14 +27,24 @@ public:
                 m_f_centre = props.float_("freq_centre", 1.f);
                 m_f_ext = props.float_("freq_sweep", 1.f);
                 m_sig_is_delta = props.bool_("sig_is_delta", true);
+            } else if (sig == "pulse") {
+                m_signal = BF_SIGNAL_PULSE;
+                m_repfreq = props.float_("prf", 1.f);
+                m_t_ext = props.float_("pulse_len", 1.f);
+                m_f_centre = props.float_("freq_centre", 1.f);
+                m_f_ext = props.float_("freq_ext", 1.f);
+                m_sig_is_delta = props.bool_("sig_is_delta", false);
+                if (m_sig_is_delta)
+                    Throw("phasedreceiver: receive_type \"mix_resample\" with a \"pulse\" that is a delta signal reads an uninitialised frequency "
+                          "in the reference");
             } else if (sig == "cw") {
                 m_f_centre = props.float_("freq_centre", 1.f);
                 m_f_ext = props.float_("freq_ext", 0.f);
                 m_sig_is_delta = props.bool_("sig_is_delta", true);
             } else {
-                Throw("phasedreceiver: receive_type \"mix_resample\" with signaltype \"%s\" is not supported (\"linfmcw\" and \"cw\" are)", sig.c_str());
+                // :100-109 — any other signaltype is a delta signal whose frequency sample_delta_frequency never sets
+                Throw("phasedreceiver: receive_type \"mix_resample\" with signaltype \"%s\" is not supported (\"linfmcw\", \"cw\" and \"pulse\" are)", sig.c_str());
             }
-            if (!m_sig_is_delta) Throw("phasedreceiver: receive_type \"mix_resample\" needs a delta signal (sig_is_delta)");
             m_gain = props.float_("gain", 1.f);
         } else {
             m_f_centre = props.float_("freq_centre", 1.f);
@@ -62,9 +73,10 @@ public:
         s.rx_signal_type = m_signal;
         s.rx_pulse_len = m_t_ext;
         s.rx_prf = m_repfreq;
+        s.rx_amplitude = m_amplitude;
     }
 private:
-    float m_f_centre, m_f_ext, m_gain, m_t_ext, m_repfreq;
+    float m_f_centre, m_f_ext, m_gain, m_t_ext, m_repfreq, m_amplitude;
     uint32_t m_signal;
     bool m_sig_is_delta;
     PhasedArray m_array;

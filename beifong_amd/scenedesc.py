@@ -256,7 +256,7 @@ class SceneDesc:
     # ---- receivers + ADC (gen-3) ----
     def set_receiver(self, shape, kind="omnidirectional", adc_sampling_start=0.0, adc_sampling_end=0.0, t_bins=1024,
                      f_bins=1024, t_bandwidth=3.81e-6, f_bandwidth=250e6, freq_centre=1.0, freq_ext=1.0, gain=1.0,
-                     sig_is_delta=False, array=None, rx_signaltype="cw", rx_chirp_len=0.0, rx_crf=0.0):
+                     sig_is_delta=False, array=None, rx_signaltype="cw", rx_chirp_len=0.0, rx_crf=0.0, rx_amplitude=1.0):
         """receiver.cpp:16-62 + adc.cpp:18-46 (box rfilter, full window).  rx_signaltype / rx_chirp_len / rx_crf: the local
         oscillator a Wigner / phased receiver samples its frequency from under receive_type "mix_resample"
         (wignerreceiver.cpp:72-110; freq_ext is then the sweep, sig_is_delta must be set)."""
@@ -272,7 +272,7 @@ class SceneDesc:
         s.t_bins, s.f_bins, s.t_bandwidth, s.f_bandwidth = t_bins, f_bins, t_bandwidth, f_bandwidth
         s.freq_centre, s.freq_ext, s.gain, s.rx_sig_is_delta = freq_centre, freq_ext, gain, int(sig_is_delta)
         s.rx_signal_type = {"cw": capi.BF_SIGNAL_CW, "pulse": capi.BF_SIGNAL_PULSE, "linfmcw": capi.BF_SIGNAL_LINFMCW}[rx_signaltype]
-        s.rx_pulse_len, s.rx_prf = rx_chirp_len, rx_crf
+        s.rx_pulse_len, s.rx_prf, s.rx_amplitude = rx_chirp_len, rx_crf, rx_amplitude
 
     # ---- phased arrays (phasedtransmitter.cpp:108-165 == phasedreceiver.cpp:115-172) ----
     def phased_array(self, n_elems, elem_dims, elem_spacing, elem_axis, steering_vector=(0.0, 0.0, 0.0), array_loc=None):

@@ -207,9 +207,13 @@ typedef struct bf_sensor {
      * BF_SIGNAL_LINFMCW — the chirp's instantaneous frequency freq_centre + (freq_ext / rx_pulse_len) * (t - rx_pulse_len / 2),
      * t = fmodulo(time, 1 / rx_prf), freq_ext the sweep — or BF_SIGNAL_CW (freq_centre), at the sampled receive time, weight 1
      * (sig_is_delta, the plugins' default for both).  Against a resample_freq transmitter the ADC's frequency axis is then the
-     * de-chirped beat.  Not read in the "raw" receive types; the omnidirectional receiver has no signal.  */
+     * de-chirped beat.  A signal that is NO delta (rx_sig_is_delta = 0: the plugins' default for "pulse") draws the frequency
+     * uniformly from [freq_centre - freq_ext / 2, freq_centre + freq_ext / 2] and weights the ray with eval_signal(time, f)
+     * (:118-142: the chirp's / pulse's Wigner function with rx_amplitude, or rx_amplitude^2 for "cw").  "pulse" as a delta reads an
+     * uninitialised frequency in the reference: BF_ERR_UNSUPPORTED.  Not read in the "raw" receive types; the omnidirectional
+     * receiver has no signal.  */
     uint32_t rx_signal_type;
-    float rx_pulse_len, rx_prf;
+    float rx_pulse_len, rx_prf, rx_amplitude;
 } bf_sensor;
 
 /* ---------------- scene --------------------------------------------------- */

@@ -1838,15 +1838,27 @@ static float receiver_sample_ray(const OScene &sc, float time, bool mix, float w
     }
     // wigner receiver, receive_type raw: frequency uniform in [fc - B/2, fc + B/2]
     float freq = wl_sample * s.freq_ext + (s.freq_centre - s.freq_ext / 2);
+    float signal_power = 1.f;
     if (mix) {
-        // receive_type "mix_resample" with a delta signal (sig_is_delta, the default of "linfmcw" and "cw"): sample_frequency ->
-        // sample_delta_frequency(time) — wignerreceiver.cpp:172-189, 149-166: the local oscillator's instantaneous frequency at
-        // the sampled receive time, weight 1
-        freq = s.freq_centre;
-        if (s.rx_signal_type == BF_SIGNAL_LINFMCW) {
-            float t = fmodulo_j(time, rcp(s.rx_prf));
-            float ti = 0 + s.rx_pulse_len / 2;
-            freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+        // receive_type "mix_resample" — wignerreceiver.cpp:172-189: the receiver's own local oscillator
+        if (s.rx_sig_is_delta) {
+            // sample_delta_frequency(time) (:149-166; the default of "linfmcw" and "cw"): the instantaneous frequency at the
+            // sampled receive time, weight 1
+            freq = s.freq_centre;
+            if (s.rx_signal_type == BF_SIGNAL_LINFMCW) {
+                float t = fmodulo_j(time, rcp(s.rx_prf));
+                float ti = 0 + s.rx_pulse_len / 2;
+                freq = s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti);
+            }
+        } else {
+            // the uniform sample above, weighted with eval_signal(time, frequency) (:118-142; the default of "pulse")
+            signal_power = s.rx_amplitude * s.rx_amplitude;
+            if (s.rx_signal_type != BF_SIGNAL_CW) {
+                float t = fmodulo_j(time, rcp(s.rx_prf));
+                float ti = 0 + s.rx_pulse_len / 2;
+                float fi = s.rx_signal_type == BF_SIGNAL_LINFMCW ? s.freq_centre + (s.freq_ext / s.rx_pulse_len) * (t - ti) : s.freq_centre;
+                signal_power = rect_j((t - ti) / s.rx_pulse_len) > 0.f ? wchirp_j(t - ti, freq - fi, s.rx_pulse_len, s.rx_amplitude) : 0.f;
+            }
         }
     }
     // Wavelength wavelength = MTS_C*rcp(frequencies)*1e9  (float * float, then * double literal)
@@ -1859,13 +1871,13 @@ static float receiver_sample_ray(const OScene &sc, float time, bool mix, float w
         float geom = w * rc.inv_area * (1 - dn * dn * dn * dn);
         float ext = area * kPi;
         if (!s.rx_sig_is_delta) ext = (float) ((double) (ext * (sc.physics.c * rcp(s.freq_ext))) * 1e9);
-        return 1.f * s.gain * geom * ext;
+        return signal_power * s.gain * geom * ext;
     }
     float ws = rect_sample_wigner(rc, p, local, cx.lambda0);     // ds.d is the LOCAL cosine direction (:249-252)
     float geom_gain = ws * rc.inv_area;
     float extents = area * kPi;
     if (!s.rx_sig_is_delta) extents = (float) ((double) (extents * (sc.physics.c * rcp(s.freq_ext))) * 1e9);
-    return 1.f * s.gain * geom_gain * extents;
+    return signal_power * s.gain * geom_gain * extents;
 }
 
 // ImageBlock::put, box-filter branch (filter radius <= 0.5 + RayEpsilon) — src/librender/imageblock.cpp:113,166-172 for a
@@ -2355,9 +2367,9 @@ bf_status bfo_render(const bfo_scene *s, const bf_launch *lp, int rng_mode, int 
         return BF_ERR_INVALID;
     }
     // the Wigner / phased receiver's own local oscillator: delta signals "linfmcw" / "cw" (wignerreceiver.cpp:149-189)
-    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && s->sc.sensor.type != BF_RECEIVER_OMNI &&
-        (!s->sc.sensor.rx_sig_is_delta || s->sc.sensor.rx_signal_type == BF_SIGNAL_PULSE)) {
-        g_err = "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: its local oscillator must be a delta signal of type linfmcw or cw";
+    if ((lp->flags & BF_FLAG_MIX_RESAMPLE) && s->sc.sensor.type != BF_RECEIVER_OMNI && s->sc.sensor.rx_sig_is_delta &&
+        s->sc.sensor.rx_signal_type == BF_SIGNAL_PULSE) {
+        g_err = "BF_FLAG_MIX_RESAMPLE on the Wigner / phased receiver: a pulse that is a delta signal reads an uninitialised frequency in the reference";
         return BF_ERR_UNSUPPORTED;
     }
     const OScene &sc = s->sc;

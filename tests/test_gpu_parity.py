@@ -1135,7 +1135,9 @@ def test_mix_resample_receive_type(hiplib):
     g = capi.Scene(sd)
     hb, rb, _ = g.render_batch(lp_mix, 2, seeds=[lp.seed, lp.seed + 1], records=True)
     assert np.allclose(hb[0], h_mix, rtol=1e-4, atol=1e-3)
-    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=256, t_bins=4, receiver="wigner")      # (a Wigner receiver that is no delta signal)
+    sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=256, t_bins=4, receiver="wigner")
+    sdw.sensor.rx_signal_type, sdw.sensor.rx_sig_is_delta = capi.BF_SIGNAL_PULSE, 1          # (a "pulse" that is a delta: uninitialised in the reference)
+    sdw.finalize()
     lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
     with pytest.raises(capi.BeifongError, match="delta"):
         capi.Scene(sdw).render(lpw)
@@ -1365,3 +1367,22 @@ def test_fmcw_dechirp_with_the_receivers_local_oscillator(hiplib, receiver):
     # "raw" on the same scene: parity too, and another histogram (absolute frequencies: outside this ADC)
     h_raw, _, _ = _render_compare(sd, lp)
     assert not np.array_equal(h_raw, h)
+
+
+@pytest.mark.parametrize("signal", ["pulse", "linfmcw", "cw"])
+def test_mix_resample_receiver_signal_that_is_no_delta(hiplib, signal):
+    """The other branch of the Wigner receiver's sample_frequency under "mix_resample" (wignerreceiver.cpp:179-186): a uniform
+    frequency from [f_centre - f_ext / 2, f_centre + f_ext / 2] weighted with the receiver's eval_signal(time, f) (:118-142 —
+    the pulse's / chirp's Wigner function, or amplitude^2 for "cw"), and the band's extent in the ray weight (:258).  Per-path
+    parity with the oracle against a resample_freq transmitter."""
+    sd, lp = _fmcw_scene(n_paths=20000)
+    s = sd.sensor
+    s.type = capi.BF_RECEIVER_WIGNER
+    s.rx_sig_is_delta = 0
+    s.rx_signal_type = {"pulse": capi.BF_SIGNAL_PULSE, "linfmcw": capi.BF_SIGNAL_LINFMCW, "cw": capi.BF_SIGNAL_CW}[signal]
+    s.rx_pulse_len, s.rx_prf, s.rx_amplitude = 0.25 * s.t_bandwidth, 1.0 / s.t_bandwidth, 1.5
+    s.freq_centre, s.freq_ext = sd.emitters[0].freq_centre, sd.emitters[0].freq_ext
+    sd.finalize()
+    lp_mix = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_MIX_RESAMPLE)
+    h, _, _ = _render_compare(sd, lp_mix)
+    assert h.reshape(32, 64, 3)[:, :, 2].sum() > 0

@@ -372,14 +372,18 @@ def test_receive_type_mix_resample_and_doppler_property(mitsuba):
     assert d.sensor.type == capi.BF_RECEIVER_WIGNER and d.sensor.rx_signal_type == capi.BF_SIGNAL_LINFMCW and d.sensor.rx_sig_is_delta == 1
     assert abs(d.sensor.rx_pulse_len - 0.150588) < 1e-8 and abs(d.sensor.rx_prf - 6.640625) < 1e-6 and d.sensor.freq_ext == 1700.0
     assert scene.integrator().launch_for(rx).flags == capi.BF_FLAG_MIX_RESAMPLE
-    with pytest.raises(HostError, match="pulse"):
-        load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
-                                          '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
-                                          '<string name="signaltype" value="pulse"/>'))
+    # "pulse" is no delta by default: a uniform frequency weighted with the receiver's eval_signal; as a delta it is refused
+    pul = load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
+                                            '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
+                                            '<string name="signaltype" value="pulse"/><float name="amplitude" value="2"/>'
+                                            '<float name="pulse_len" value="0.01"/><float name="prf" value="6.640625"/>'
+                                            '<float name="freq_centre" value="39375"/><float name="freq_ext" value="1700"/>'))
+    ds = pul.flat_desc(pul.receivers()[0]).desc.sensor
+    assert (ds.rx_signal_type, ds.rx_sig_is_delta, ds.rx_amplitude) == (capi.BF_SIGNAL_PULSE, 0, 2.0) and abs(ds.rx_pulse_len - 0.01) < 1e-9
     with pytest.raises(HostError, match="delta"):
         load_string(RECEIVE_SCENE.replace('<receiver type="omnidirectional">',
                                           '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
-                                          '<boolean name="sig_is_delta" value="false"/>'))
+                                          '<string name="signaltype" value="pulse"/><boolean name="sig_is_delta" value="true"/>'))
 
 
 def test_resample_freq_property_of_the_transmitters(mitsuba):

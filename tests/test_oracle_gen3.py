@@ -201,8 +201,11 @@ def test_mix_resample_bins_the_beat_frequency():
     lp.flags = capi.BF_FLAG_MIX_RESAMPLE
     none, _, st0 = OracleScene(sd).render(lp, threads=4)
     assert not none.any()
-    # render modes and the Wigner receiver do not take the flag
+    # render modes do not take the flag; the Wigner receiver has a local oscillator of its own under it (round 4), except a
+    # "pulse" that is a delta signal (an uninitialised frequency in the reference)
     sdw, lpw = scenes.bus_receive(n_tris=500, n_paths=16, t_bins=4, receiver="wigner")
+    sdw.sensor.rx_signal_type, sdw.sensor.rx_sig_is_delta = capi.BF_SIGNAL_PULSE, 1
+    sdw.finalize()
     lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
     with pytest.raises(Exception):
         OracleScene(sdw).render(lpw, threads=1)
