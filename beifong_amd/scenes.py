@@ -181,6 +181,39 @@ def plate_doppler(wavelength_m=0.1, n_paths=1 << 16, t_bins=1, plate_x=5.0, plat
     return sd, launch
 
 
+def fmcw_plate(plate_x=5.0, r_max=12.8, n_paths=1 << 18, t_bins=8, f_bins=64, plate_size=0.5, seed=9):
+    """The de-chirped FMCW return of a plate (round 4): coincident 20 x 50 mm TX / RX apertures at (0, 0, 0.3) looking +x, a Wigner
+    transmitter with resample_freq that sweeps B = 1e-3 f_c over the receive window T = 4 * (2 r_max / c), a Wigner receiver whose
+    local oscillator is the same chirp (receive_type "mix_resample", a delta signal), a diffuse plate facing them at x = plate_x.
+    The ADC's f_bins frequency rows span the beat of r_max: a return from range r lands in row ceil(f_bins * r / r_max - 1)
+    whenever it is received (launch: BF_MODE_RECEIVE_RAW | BF_FLAG_MIX_RESAMPLE)."""
+    sd = SceneDesc()
+    lam_nm = 0.1 * 1e9
+    sd.physics.lambda_min_nm, sd.physics.lambda_max_nm = lam_nm * (1 - 1e-3), lam_nm * (1 + 1e-3)
+    c = sd.physics.c
+    d0 = T.rotate([1, 0, 0], 90) * T.rotate([0, 1, 0], 90)
+    aperture = T.translate([0, 0, 0.3]) * d0 * T.scale([20e-3, 50e-3, 1])
+    txa = sd.add_rectangle(aperture, sd.add_diffuse(0.0))
+    rxa = sd.add_rectangle(aperture, sd.add_diffuse(0.5))
+    t_win, f_c = 4.0 * (2.0 * r_max / c), c / 0.1
+    sweep = 1e-3 * f_c
+    sd.add_wigner_transmitter(txa, signaltype="linfmcw", amplitude=1.0, freq_centre=f_c, freq_ext=sweep, pulse_len=t_win,
+                              prf=1.0 / t_win, resample_freq=True)
+    sd.set_receiver(rxa, kind="wigner", adc_sampling_start=0.0, adc_sampling_end=t_win, t_bins=t_bins, f_bins=f_bins,
+                    t_bandwidth=t_win, f_bandwidth=sweep * (2.0 * r_max / c) / t_win, freq_centre=f_c, freq_ext=sweep,
+                    sig_is_delta=True, rx_signaltype="linfmcw", rx_chirp_len=t_win, rx_crf=1.0 / t_win)
+    g = np.linspace(-0.5 * plate_size, 0.5 * plate_size, 9)
+    yy, zz = np.meshgrid(g, g, indexing="ij")
+    v = np.stack([np.full(yy.size, plate_x), yy.ravel(), zz.ravel() + 0.3], -1).astype(np.float32)
+    idx = np.arange(81).reshape(9, 9)
+    a, b, cc, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, cc], -1), np.stack([a, cc, d], -1)]).astype(np.uint32)
+    sd.add_mesh(np.ascontiguousarray(v), np.ascontiguousarray(f), sd.add_diffuse(0.8, twosided=True))
+    sd.finalize()
+    launch = capi.make_launch(capi.BF_MODE_RECEIVE_RAW, n_paths, seed=seed, bins=t_bins, bins_y=f_bins, flags=capi.BF_FLAG_MIX_RESAMPLE)
+    return sd, launch
+
+
 def single_mesh(v, f, normals=None, texcoords=None):
     """Bare mesh scene for Scene::ray_intersect tests (test_kdtrees.py style)."""
     sd = SceneDesc()

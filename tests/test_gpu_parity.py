@@ -1386,3 +1386,18 @@ def test_mix_resample_receiver_signal_that_is_no_delta(hiplib, signal):
     lp_mix = capi.make_launch(lp.mode, lp.n_paths, seed=lp.seed, bins=lp.bins, bins_y=lp.bins_y, flags=capi.BF_FLAG_MIX_RESAMPLE)
     h, _, _ = _render_compare(sd, lp_mix)
     assert h.reshape(32, 64, 3)[:, :, 2].sum() > 0
+
+
+def test_fmcw_beat_row_is_the_range_of_a_plate(hiplib):
+    """A physical known answer for the de-chirp path (resample_freq transmitter + the Wigner receiver's local oscillator under
+    "mix_resample"): a 0.5 m plate R = 5 m in front of coincident TX / RX apertures; both ends sweep B over the receive window T, so
+    a return delayed by 2 R / c beats at B / T * 2 R / c whenever it is received.  With an ADC whose 64 frequency rows span the beat
+    of 12.8 m, the plate's energy sits in rows 24 / 25 (SignalBlock::put: ceil(64 r / 12.8 - 1), r = 5.00 .. 5.01 m) — and the
+    engine's every path equals the oracle's."""
+    sd, lp = scenes.fmcw_plate(plate_x=5.0, r_max=12.8, n_paths=1 << 18)
+    h, _, _ = _render_compare(sd, lp)
+    energy = np.abs(h.reshape(64, 8, 3)[:, :, 0]).sum(1)               # per beat row, over the receive window
+    assert energy.sum() > 0
+    # slant ranges 5.000 .. 5.013 m (the plate is 0.5 m wide): pos = 64 * r / 12.8 = 25.0 .. 25.06 -> rows 24 (r = 5 exactly) and 25
+    assert int(np.argmax(energy)) in (24, 25), energy[20:30]
+    assert energy[24:26].sum() > 0.95 * energy.sum()

@@ -209,3 +209,24 @@ def test_mix_resample_bins_the_beat_frequency():
     lpw.flags = capi.BF_FLAG_MIX_RESAMPLE
     with pytest.raises(Exception):
         OracleScene(sdw).render(lpw, threads=1)
+
+
+@pytest.mark.parametrize("plate_x", [3.0, 5.0, 9.0])
+def test_fmcw_dechirp_known_answer_the_beat_row_is_the_range(plate_x):
+    """A PHYSICAL pin of the fork-specific de-chirp path (nothing of the reference's pins it): a resample_freq chirp transmitter,
+    the Wigner receiver's local oscillator under "mix_resample" (wignertransmitter.cpp:152-168, 211-221, 430-441;
+    wignerreceiver.cpp:149-189; integrator.cpp:1588-1603) and a plate at range r — the beat B / T * 2 r / c puts the plate's
+    energy into ADC row ceil(64 r / 12.8 - 1) (slant ranges r .. r + 0.02 m), whenever the return is received."""
+    sd, lp = scenes.fmcw_plate(plate_x=plate_x, r_max=12.8, n_paths=1 << 17)
+    h, _, st = OracleScene(sd).render(lp, threads=8)
+    energy = np.abs(h.reshape(64, 8, 3)[:, :, 0]).sum(1)
+    assert energy.sum() > 0
+    pos = 64.0 * plate_x / 12.8
+    rows = (int(np.ceil(pos - 1.0)), int(np.ceil(pos - 1.0)) + 1)
+    assert int(np.argmax(energy)) in rows, (rows, np.flatnonzero(energy))
+    assert energy[rows[0]:rows[1] + 1].sum() > 0.95 * energy.sum()
+    # every row of the receive window shows the same range: the beat does not depend on the receive time
+    per_t = np.abs(h.reshape(64, 8, 3)[:, :, 0])
+    for k in range(8):
+        if per_t[:, k].sum() > 0 and k >= 2:            # (the first returns wrap into the previous chirp: other rows)
+            assert int(np.argmax(per_t[:, k])) in rows
