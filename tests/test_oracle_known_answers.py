@@ -761,3 +761,30 @@ def test_denormal_flushing_of_the_reference_changes_nothing_on_the_radar_scenes(
         (h0, r0, s0), (h1, r1, s1) = out
         assert np.array_equal(r0, r1) and np.array_equal(h0, h1)
         assert (s0.n_rays_closest, s0.n_rays_shadow, s0.n_bounces) == (s1.n_rays_closest, s1.n_rays_shadow, s1.n_bounces)
+
+
+@pytest.mark.parametrize("plate_x", [2.0, 5.0, 11.3])
+def test_range_histogram_of_a_plate_peaks_at_its_round_trip(plate_x):
+    """A physical pin of the north-star path itself (range o pathlength, BASELINE config 2's semantics): the C2 radar front end
+    (20 x 50 mm TX aperture with an area emitter, perspective RX, both at (0, 0, 0.3) looking +x) and a 0.5 m diffuse plate at
+    range r.  The path length of the direct return RX -> plate -> TX (next-event estimation) is 2 r .. 2 r + 0.03 m, so with
+    dr = 0.1 m the histogram's energy sits in bins floor(2 r / dr) and the next one."""
+    from beifong_amd import scenes
+    from beifong_amd.scenedesc import SceneDesc
+    sd = SceneDesc()
+    scenes._radar_frontend(sd)
+    g = np.linspace(-0.25, 0.25, 9)
+    yy, zz = np.meshgrid(g, g, indexing="ij")
+    v = np.stack([np.full(yy.size, plate_x), yy.ravel(), zz.ravel() + 0.3], -1).astype(np.float32)
+    idx = np.arange(81).reshape(9, 9)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.uint32)
+    sd.add_mesh(np.ascontiguousarray(v), np.ascontiguousarray(f), sd.add_diffuse(0.8, twosided=True))
+    sd.finalize()
+    lp = capi.make_launch(capi.BF_MODE_RANGE, 1 << 16, seed=3, bins=256, bin_width=0.1, color_mode=capi.BF_COLOR_RGB)
+    h, _, st = OracleScene(sd).render(lp, threads=8)
+    prof = h[5:5 + 256]
+    assert prof.sum() > 0
+    k = int(np.floor(2.0 * plate_x / 0.1 + 1e-4))
+    assert int(np.argmax(prof)) in (k, k + 1), (k, np.flatnonzero(prof)[:8])
+    assert prof[k:k + 2].sum() > 0.9 * prof.sum()        # (the rest: plate -> aperture -> plate bounces, 2 r further out)
