@@ -86,6 +86,37 @@ def test_receive_mix_resample_through_the_plugin_surface(mitsuba, hiplib):
         mitsuba.set_variant("scalar_rgb")
 
 
+def test_fmcw_dechirp_through_the_plugin_surface(mitsuba, hiplib):
+    # XML -> wignertransmitter resample_freq + wignerreceiver receive_type "mix_resample" (its own chirp) -> flat description ->
+    # HIP == oracle: the ADC of the host object holds the de-chirped returns
+    from beifong_amd.mitsuba.core.xml import load_string
+    xml = RECEIVE_SCENE.replace('<string name="signaltype" value="pulse"/><float name="amplitude" value="1"/>\n'
+                                '            <float name="pulse_len" value="0.000588235"/><float name="prf" value="6.640625"/>\n'
+                                '            <float name="freq_centre" value="39375"/><float name="freq_ext" value="1700"/>',
+                                '<string name="signaltype" value="linfmcw"/><float name="amplitude" value="1"/>'
+                                '<float name="chirp_len" value="0.150588"/><float name="crf" value="6.640625"/>'
+                                '<float name="freq_centre" value="39375"/><float name="freq_sweep" value="1700"/>'
+                                '<boolean name="resample_freq" value="true"/>')
+    xml = xml.replace('<receiver type="omnidirectional">',
+                      '<receiver type="wignerreceiver"><string name="receive_type" value="mix_resample"/>'
+                      '<string name="signaltype" value="linfmcw"/><float name="chirp_len" value="0.150588"/>'
+                      '<float name="crf" value="6.640625"/><float name="freq_centre" value="39375"/><float name="freq_sweep" value="1700"/>')
+    assert "resample_freq" in xml and "wignerreceiver" in xml
+    mitsuba.set_variant("scalar_spectral")
+    try:
+        scene = load_string(xml)
+        rx = scene.receivers()[0]
+        scene.integrator().receive(scene, rx)
+        bmp = np.array(rx.adc().bitmap(raw=True))
+        lp = scene.integrator().launch_for(rx)
+        assert lp.flags == capi.BF_FLAG_MIX_RESAMPLE
+        ref, _, _ = OracleScene(scene.flat_desc(rx)).render(lp, threads=8)
+        assert np.allclose(bmp.reshape(-1), ref, rtol=2e-5, atol=1e-3)
+        assert bmp[0, :, 2].sum() > 0            # beats inside the ADC's 90 kHz
+    finally:
+        mitsuba.set_variant("scalar_rgb")
+
+
 def test_bfrender_cli(hiplib, tmp_path):
     # mitsuba -m scalar_rgb -Dspp=.. scene.xml (src/mitsuba/mitsuba.cpp:173-183)
     p = tmp_path / "scene.xml"
