@@ -20,7 +20,7 @@ run tw4 BF_TRACE_WAVES=4
 run tw6 BF_TRACE_WAVES=6
 run sw2 BF_SHADE_WAVES=2
 run tail2 BF_TAIL_WAVES=2
-run pool_small BF_WF_POOL=65536
+run pool_1m BF_WF_POOL=1048576      # (a 65 536-slot pool is smaller than the bench steps of tests/test_gpu_bench.py: they then do not roll)
 run refill8 BF_TRACE_REFILL=8 BF_TRACE_STRAGGLERS=1
 run refill60 BF_TRACE_REFILL=60 BF_TRACE_STRAGGLERS=40
 run sync BF_WF_SYNC=1
