@@ -440,6 +440,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            # the dominant kernel and ITS fraction of the HBM roofline, beside the whole-path `roofline.frac` (both also inside `roofline`)
+            "dominant_kernel": kernels[0]["kernel"],
+            "dominant_kernel_frac": kernels[0]["frac"],
             "config": {
                 "workload": w.label % (info.n_triangles, w.paths // 64, w.paths),
                 "name": w.cfg,
